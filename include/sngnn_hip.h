@@ -1,0 +1,188 @@
+/*
+ * sngnn_hip.h - C ABI of the MI355X (gfx950) implementation of SNGNN's
+ * similarity-navigated aggregation path.
+ *
+ * The reference (MinhZou/SNGNN) is pure Python and has no FFI of its own; the
+ * seam this library replaces is the body of the three conv layers'
+ * ``forward(x, edge_index)`` after ``self.lin`` (models/models.py:116-137,
+ * 233-242, 322-329) together with their ``message`` hooks (:139-158, :244-263,
+ * :331-334) and the third-party calls underneath them (PyG propagate /
+ * add_self_loops / remove_self_loops, torch_scatter.scatter_max / scatter(mean),
+ * torch_sparse.SparseTensor) - plus the Sim-GFA toolbox's cosine statistics
+ * (SimGFAToolbox/dense.py:138-179).  Each entry point cites the reference lines
+ * it stands in for.  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer; nothing here takes
+ *     or returns a torch type;
+ *   - fp32 values, row-major, dense (leading dimension == number of columns);
+ *   - ``stream`` is a hipStream_t passed as void* (NULL = the null stream);
+ *     forward/backward entry points only enqueue work: no allocation, no host
+ *     synchronisation, safe to capture in a hipGraph;
+ *   - every function returns 0 on success or a negative SNGNN_E* code;
+ *     sngnn_last_error() gives the message of the calling thread's last failure.
+ */
+#ifndef SNGNN_HIP_H
+#define SNGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNGNN_OK            0
+#define SNGNN_EINVAL       -1   /* bad argument (NULL, negative size, C unsupported) */
+#define SNGNN_ERANGE       -2   /* node id outside [0, N) in edge_index            */
+#define SNGNN_EHIP         -3   /* a HIP runtime call failed                       */
+#define SNGNN_ENOMEM       -4   /* allocation failed                               */
+
+/* weight value stored for an edge that was NOT selected (training-mode output
+ * of sngnn_agg_forward); a selected edge stores its cosine, which is > -1.1 */
+#define SNGNN_UNSELECTED   (-4.0f)
+
+/* largest supported number of channels per node row */
+#define SNGNN_MAX_CHANNELS  512
+
+const char *sngnn_last_error(void);
+/* "gfx950;rocm-x.y;..." build identification */
+const char *sngnn_build_info(void);
+
+/* ------------------------------------------------------------------------
+ * Graph structure (built once per edge_index / self-loop mode and cached by
+ * the caller; the reference redoes this work on every forward).
+ * ------------------------------------------------------------------------ */
+typedef struct sngnn_graph sngnn_graph_t;
+
+/*
+ * Replaces: add_self_loops + remove_self_loops (models.py:117-120, 234-236,
+ * 323) and the COO->per-target grouping that PyG's propagate / torch_scatter
+ * perform implicitly on every call (models.py:132, 239, 326).
+ *
+ *   edge_index_dev  int64 [2, E] row-major (row 0 = source, row 1 = target),
+ *                   exactly what the reference passes as ``edge_index``
+ *   add_loops       append (v, v) for every v at the END of the list
+ *   remove_loops    then drop EVERY edge with src == dst (so add+remove == remove)
+ *
+ * The resulting list of E' edges keeps the reference's order; the library
+ * stores it as CSR by target with the original relative order inside each row
+ * (stable), which is what makes "first occurrence wins a tie" reproducible.
+ * Synchronises the stream (one-time setup).
+ */
+int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N,
+                       int add_loops, int remove_loops, void *stream,
+                       sngnn_graph_t **out_graph);
+void sngnn_graph_destroy(sngnn_graph_t *g);
+
+int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g);
+int64_t sngnn_graph_num_edges(const sngnn_graph_t *g);      /* E' */
+int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g);
+int64_t sngnn_graph_src_min(const sngnn_graph_t *g);         /* models.py:125 */
+/* bytes of device workspace sngnn_agg_forward/backward need for C channels */
+int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C);
+
+/* Copy one of the graph's arrays to host memory (tests / inspection).
+ *   which: 0 rowptr   int32 [N+1]   CSR by target
+ *          1 col      int32 [E']    source id of each CSR edge
+ *          2 eid      int32 [E']    position of the CSR edge in the E' edge list
+ *          3 cscptr   int32 [N+1]   CSC by source
+ *          4 csc_eid  int32 [E']    CSR edge index of each CSC entry
+ *          5 rperm    int32 [N]     rows sorted by in-degree, descending (stable)
+ */
+int sngnn_graph_copy_array(const sngnn_graph_t *g, int which, void *host_dst);
+/* device pointer to the same arrays (owned by the graph) */
+const void *sngnn_graph_array_dev(const sngnn_graph_t *g, int which);
+
+/* ------------------------------------------------------------------------
+ * Fused aggregation:  F.normalize + per-edge cosine + top-k/threshold
+ * selection + similarity-weighted scatter-mean.
+ * ------------------------------------------------------------------------ */
+/*
+ * Replaces: models.py:122+132+139-158 (SNConv_plus_plus, the out_1 branch),
+ * :238-239+244-263 (SNConv_plus), :325-326+331-334 (SNConv) and, underneath,
+ * PyG propagate's four index_select gathers, torch_scatter.scatter_max (x top_k
+ * rounds) and torch_scatter.scatter(reduce='mean').
+ *
+ *   h        dev f32 [N, C]   output of self.lin (NOT normalised)
+ *   top_k    < 0: SNConv - every edge weighted by its cosine, no selection
+ *            >= 0: keep, per target, the top_k in-edges by (cosine descending,
+ *            edge position ascending) and of those only the ones with
+ *            cosine >= (float)thr; all other edges get weight 0
+ *   out      dev f32 [N, C]   (1 / max(indeg', 1)) * sum_e weight_e * h[src_e]
+ *                             (the mean divides by the FULL in-degree)
+ * Optional outputs (NULL to skip):
+ *   wsel     dev f32 [E']     per CSR edge: its cosine if selected, else
+ *                             SNGNN_UNSELECTED (saved for backward)
+ *   inv_norm dev f32 [N]      1 / max(||h_i||_2, 1e-12)
+ *   sel_src  dev i32 [N, top_k]  selected source ids in rank order, -1 padded
+ *   sel_w    dev f32 [N, top_k]  their cosines (0 padded)
+ *   workspace dev, sngnn_graph_workspace_bytes(g, C) bytes (may be NULL when
+ *            that is 0)
+ */
+int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
+                      float thr, float *out, float *wsel, float *inv_norm,
+                      int32_t *sel_src, float *sel_w, void *workspace,
+                      void *stream);
+
+/*
+ * Replaces: autograd through the op list above (triggered at train.py:86).
+ * Deterministic: no floating-point atomics; every sum has a fixed order.
+ *
+ *   grad_out dev f32 [N, C]   dL/d out
+ *   wsel, inv_norm            as written by sngnn_agg_forward on the same h
+ *   grad_h   dev f32 [N, C]   dL/d h through all three routes (message value,
+ *                             norm_i, norm_j) and F.normalize's Jacobian
+ */
+int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
+                       const float *grad_out, const float *wsel,
+                       const float *inv_norm, float *grad_h, void *workspace,
+                       void *stream);
+
+/* ------------------------------------------------------------------------
+ * SNGNN++ adjacency-linear branch and blend.
+ * ------------------------------------------------------------------------ */
+/*
+ * Replaces: models.py:124-130 - SparseTensor(row - row.min(), col)
+ * .to_torch_sparse_coo_tensor() followed by Linear(num_nodes, C) on it:
+ *   out0[i] = b + sum over edges e with src_e - src_min == i of W[:, dst_e].
+ *   wt   dev f32 [N, C]  the TRANSPOSE of the reference's w.weight ([C, N]);
+ *                        row d is W[:, d] so every gather is one contiguous row
+ *   bias dev f32 [C] or NULL
+ */
+int sngnn_adj_linear_forward(const sngnn_graph_t *g, const float *wt,
+                             const float *bias, int C, float *out0, void *stream);
+/*
+ * Gradient of the above w.r.t. wt:  dwt[d] = sum over in-edges e of d of
+ * g0[src_e - src_min]  (dense [N, C], like the reference's dense w.weight.grad).
+ */
+int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0, int C,
+                              float *dwt, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Sim-GFA toolbox (SimGFAToolbox/dense.py).
+ * ------------------------------------------------------------------------ */
+/* dense.py:138-141: S = normalize(x) normalize(x)^T, dev f32 [N, N]. */
+int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S, void *stream);
+/*
+ * Fused statistics of S without materialising it (dense.py:9-30, 104-130,
+ * 144-149, 167-179): class_sum dev f64 [n_classes, n_classes] receives the sum
+ * of S over every (class_i, class_j) block INCLUDING the diagonal, diag_sum dev
+ * f64 [1] the sum of S's diagonal.  y dev int32 [N] (all zeros for the global
+ * mean).  Both outputs must be zeroed by the caller.
+ */
+int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, const int32_t *y,
+                            int n_classes, double *class_sum, double *diag_sum,
+                            void *stream);
+/*
+ * dense.py:152-164: per-edge cosine of raw features for an arbitrary COO edge
+ * list: sim[e] = <n[a_e], n[b_e]>, a = edge_index[0], b = edge_index[1].
+ */
+int sngnn_edge_cosine(const float *x, int64_t N, int64_t F,
+                      const int64_t *edge_index_dev, int64_t E, float *sim,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNGNN_HIP_H */

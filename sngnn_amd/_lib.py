@@ -1,0 +1,76 @@
+"""ctypes binding of ``libsngnn_hip.so`` (the C ABI declared in include/sngnn_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, an exception is raised.  (The CPU oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsngnn_hip.so")
+
+OK, EINVAL, ERANGE, EHIP, ENOMEM = 0, -1, -2, -3, -4
+UNSELECTED = -4.0
+MAX_CHANNELS = 512
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+# name -> (restype, argtypes); mirrors include/sngnn_hip.h one to one
+SIGNATURES = {
+    "sngnn_last_error": (C.c_char_p, []),
+    "sngnn_build_info": (C.c_char_p, []),
+    "sngnn_graph_create": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "sngnn_graph_destroy": (None, [_vp]),
+    "sngnn_graph_num_nodes": (_i64, [_vp]),
+    "sngnn_graph_num_edges": (_i64, [_vp]),
+    "sngnn_graph_max_in_degree": (_i64, [_vp]),
+    "sngnn_graph_src_min": (_i64, [_vp]),
+    "sngnn_graph_workspace_bytes": (_i64, [_vp, _i32]),
+    "sngnn_graph_copy_array": (_i32, [_vp, _i32, _vp]),
+    "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
+    "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "sngnn_cosine_dense": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "sngnn_cosine_class_sums": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_edge_cosine": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SngnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SngnnError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C sngnn_amd/csrc` (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sngnn_last_error().decode("utf-8", "replace")
+        exc = ValueError if rc in (EINVAL, ERANGE) else SngnnError
+        raise exc(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,338 @@
+// Backward of the fused similarity-navigated aggregation (gfx950).
+//
+// Replaces autograd through the reference's op list (models/models.py:122,132,
+// 139-158 / 238-239,244-263 / 325-326,331-334; triggered at train.py:86):
+// gradients reach h through the message value x_j, and through norm_i and norm_j
+// of every KEPT edge (weight[idx] = norm[idx], models.py:156,261); the selection
+// itself is not differentiable.
+//
+// With g'_i = G_i / max(deg_i,1), n_v = h_v * inv_v and, for a kept edge
+// e = (j -> i) with cosine w_e:
+//     ds_e  = <g'_i, h_j>
+//     dnT_i = sum_{e into i}  ds_e * n_j          (pass T, CSR rows, by target)
+//     msg_j = sum_{e out of j} w_e * g'_i          (pass S, CSC rows, by source)
+//     dnS_j = sum_{e out of j} ds_e * n_i
+//     dn_v  = dnT_v + dnS_v
+//     dh_v  = msg_v + (dn_v - n_v <n_v, dn_v>) * inv_v        (F.normalize's Jacobian;
+//             without the projection where the eps clamp is active)
+// Both passes are gathers with a fixed summation order: no floating-point
+// atomics, bitwise reproducible.  Row classes by degree as in the forward.
+#pragma once
+#include "device_utils.h"
+
+namespace sngnn {
+
+struct BwdArgs {
+    const float *h, *gout, *wsel, *inv;
+    int C, N;
+    const int32_t *rowptr, *col, *rperm;
+    const int32_t *cscptr, *csc_eid, *csc_dst, *sperm;
+    float *ds, *dnT, *grad_h;
+    int n_split, n_med_end, n_tasks;
+    const int32_t *task_slot, *task_chunk, *split_task0;
+    float *partT;
+    int n_ssplit, n_smed_end, n_stasks;
+    const int32_t *stask_slot, *stask_chunk, *ssplit_task0;
+    float *partS;
+    int nbA, nbB;
+};
+
+__device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<VEC, G, R> &x)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc.x[r][v] = fmaf(w, x.x[r][v], acc.x[r][v]);
+}
+
+// ------------------------------- pass T ------------------------------------
+// one kept in-edge of target i: ds_e and its contribution to dnT_i
+template <int VEC, int G, int R>
+__device__ __forceinline__ void t_edge(const BwdArgs &a, int e, const Row<VEC, G, R> &gp, int lg,
+                                       Row<VEC, G, R> &acc)
+{
+    Row<VEC, G, R> x;
+    const int j = a.col[e];
+    x.load(a.h + (size_t)j * a.C, a.C, lg);
+    const float invj = a.inv[j];
+    const float d = group_sum<G>(gp.dot_partial(x));
+    if (lg == 0) a.ds[e] = d;
+    fma_row<VEC, G, R>(acc, d * invj, x);
+}
+
+// kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[];
+// lanes cover the range 64 at a time
+__device__ __forceinline__ int kept_list(const float *__restrict__ wsel, int rs, int e0, int e1,
+                                         int *list)
+{
+    const int lane = lane_id();
+    int n = 0;
+    for (int base = e0; base < e1; base += 64) {
+        const int t = base + lane;
+        const bool kept = t < e1 && is_kept(wsel[rs + t]);
+        const unsigned long long m = __ballot(kept);
+        if (kept) list[n + prefix_popc(m)] = t;
+        n += __popcll(m);
+    }
+    return n;
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
+    if (slot >= a.N) return;                     // group-uniform
+    const int i = a.rperm[slot];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    RowT gp, acc;
+    gp.load(a.gout + (size_t)i * a.C, a.C, lg);
+    gp.div((float)max(deg, 1));
+    acc.zero();
+    for (int t = 0; t < deg; ++t)
+        if (is_kept(a.wsel[rs + t])) t_edge<VEC, G, R>(a, rs + t, gp, lg, acc);
+    acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    int i, e0, e1, tq = 0;
+    if (task) {
+        tq = blk * WAVES + wave;
+        if (tq >= a.n_tasks) return;
+        i = a.rperm[a.task_slot[tq]];
+        e0 = a.task_chunk[tq] * CHUNK;
+    } else {
+        const int slot = a.n_split + blk * WAVES + wave;
+        if (slot >= a.n_med_end) return;
+        i = a.rperm[slot];
+        e0 = 0;
+    }
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    e1 = task ? min(deg, e0 + CHUNK) : deg;
+    RowT gp, acc;
+    gp.load(a.gout + (size_t)i * a.C, a.C, lg);
+    gp.div((float)deg);
+    acc.zero();
+    const int nsel = kept_list(a.wsel, rs, e0, e1, lds_wave);
+    wave_lds_sync();
+    for (int q0 = 0; q0 < nsel; q0 += NG) {
+        const int q = q0 + gid;
+        if (q < nsel) t_edge<VEC, G, R>(a, rs + lds_wave[q], gp, lg, acc);
+    }
+    acc.reduce_across_groups();
+    if (gid == 0) {
+        float *dst = task ? a.partT + (size_t)tq * a.C : a.dnT + (size_t)i * a.C;
+        acc.store(dst, a.C, lg);
+    }
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
+{
+    __shared__ int lds[WAVES][CHUNK];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) t_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
+    else t_role_small<VEC, G, R>(a, b - a.nbA - a.nbB);
+}
+
+// split targets: dnT_i = sum of the tasks' partial rows, in task order
+__global__ void k_bwd_t_fin(const BwdArgs a)
+{
+    const int p = blockIdx.x;
+    const int i = a.rperm[p];
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += a.partT[(size_t)t * a.C + c];
+        a.dnT[(size_t)i * a.C + c] = s;
+    }
+}
+
+// ------------------------------- pass S ------------------------------------
+// one kept out-edge (CSC entry q) of source v
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_edge(const BwdArgs &a, int q, float w, int lg,
+                                       Row<VEC, G, R> &msg, Row<VEC, G, R> &dns)
+{
+    Row<VEC, G, R> x, gi;
+    const int i = a.csc_dst[q];
+    const int e = a.csc_eid[q];
+    const int deg = a.rowptr[i + 1] - a.rowptr[i];
+    x.load(a.h + (size_t)i * a.C, a.C, lg);
+    gi.load(a.gout + (size_t)i * a.C, a.C, lg);
+    gi.div((float)deg);
+    fma_row<VEC, G, R>(msg, w, gi);
+    fma_row<VEC, G, R>(dns, a.ds[e] * a.inv[i], x);
+}
+
+// dh_v from msg_v and dn_v = dnT_v + dnS_v
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VEC, G, R> &msg,
+                                         Row<VEC, G, R> &dn)
+{
+    Row<VEC, G, R> t, hv;
+    t.load(a.dnT + (size_t)v * a.C, a.C, lg);
+    dn.add(t);
+    hv.load(a.h + (size_t)v * a.C, a.C, lg);
+    const float invv = a.inv[v];
+    hv.scale(invv);                               // n_v
+    float proj = group_sum<G>(hv.dot_partial(dn));
+    if (invv == 1.0f / EPS_NORM) proj = 0.f;      // eps clamp active: n = h / eps
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+            msg.x[r][c] += (dn.x[r][c] - hv.x[r][c] * proj) * invv;
+    msg.store(a.grad_h + (size_t)v * a.C, a.C, lg);
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_smed_end + (blk * WAVES + wave) * RPW + gid;
+    if (slot >= a.N) return;
+    const int v = a.sperm[slot];
+    const int qs = a.cscptr[v];
+    const int od = a.cscptr[v + 1] - qs;
+    RowT msg, dns;
+    msg.zero();
+    dns.zero();
+    for (int t = 0; t < od; ++t) {
+        const float w = a.wsel[a.csc_eid[qs + t]];
+        if (is_kept(w)) s_edge<VEC, G, R>(a, qs + t, w, lg, msg, dns);
+    }
+    s_finish<VEC, G, R>(a, v, lg, msg, dns);
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    int v, e0, tq = 0;
+    if (task) {
+        tq = blk * WAVES + wave;
+        if (tq >= a.n_stasks) return;
+        v = a.sperm[a.stask_slot[tq]];
+        e0 = a.stask_chunk[tq] * CHUNK;
+    } else {
+        const int slot = a.n_ssplit + blk * WAVES + wave;
+        if (slot >= a.n_smed_end) return;
+        v = a.sperm[slot];
+        e0 = 0;
+    }
+    const int qs = a.cscptr[v];
+    const int od = a.cscptr[v + 1] - qs;
+    const int e1 = task ? min(od, e0 + CHUNK) : od;
+    int *s_q = lds_wave;                                         // [CHUNK] CSC positions
+    float *s_w = reinterpret_cast<float *>(lds_wave + CHUNK);   // [CHUNK] their cosines
+    int nsel = 0;
+    for (int base = e0; base < e1; base += 64) {
+        const int t = base + lane;
+        const float w = t < e1 ? a.wsel[a.csc_eid[qs + t]] : SNGNN_UNSELECTED;
+        const bool kept = is_kept(w);
+        const unsigned long long m = __ballot(kept);
+        if (kept) { const int o = nsel + prefix_popc(m); s_q[o] = qs + t; s_w[o] = w; }
+        nsel += __popcll(m);
+    }
+    wave_lds_sync();
+    RowT msg, dns;
+    msg.zero();
+    dns.zero();
+    for (int q0 = 0; q0 < nsel; q0 += NG) {
+        const int q = q0 + gid;
+        if (q < nsel) s_edge<VEC, G, R>(a, s_q[q], s_w[q], lg, msg, dns);
+    }
+    msg.reduce_across_groups();
+    dns.reduce_across_groups();
+    if (task) {
+        if (gid == 0) {
+            msg.store(a.partS + (size_t)tq * 2 * a.C, a.C, lg);
+            dns.store(a.partS + (size_t)tq * 2 * a.C + a.C, a.C, lg);
+        }
+    } else if (gid == 0) {
+        s_finish<VEC, G, R>(a, v, lg, msg, dns);
+    }
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
+{
+    __shared__ int lds[WAVES][2 * CHUNK];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) s_role_wave<VEC, G, R>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
+    else s_role_small<VEC, G, R>(a, b - a.nbA - a.nbB);
+}
+
+// split sources: one wave per source sums the tasks' partial rows, then finishes
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(64) void k_bwd_s_fin(const BwdArgs a)
+{
+    using RowT = Row<VEC, G, R>;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int p = blockIdx.x;
+    const int v = a.sperm[p];
+    const int t0 = a.ssplit_task0[p], t1 = a.ssplit_task0[p + 1];
+    if (gid != 0) return;
+    RowT msg, dns, t;
+    msg.zero();
+    dns.zero();
+    for (int tq = t0; tq < t1; ++tq) {
+        t.load(a.partS + (size_t)tq * 2 * a.C, a.C, lg);
+        msg.add(t);
+        t.load(a.partS + (size_t)tq * 2 * a.C + a.C, a.C, lg);
+        dns.add(t);
+    }
+    s_finish<VEC, G, R>(a, v, lg, msg, dns);
+}
+
+template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    BwdArgs a = a0;
+    // pass T (targets)
+    a.nbA = ceil_div(a.n_tasks, WAVES);
+    a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
+    int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
+    if (a.nbA + a.nbB + nbC > 0) k_bwd_t<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.n_split > 0) k_bwd_t_fin<<<a.n_split, 256, 0, st>>>(a);
+    // pass S (sources)
+    a.nbA = ceil_div(a.n_stasks, WAVES);
+    a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
+    nbC = ceil_div(a.N - a.n_smed_end, (int64_t)WAVES * RPW);
+    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+int launch_agg_bwd_v1(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+int launch_agg_bwd_v2(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+int launch_agg_bwd_v4(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+
+}  // namespace sngnn

@@ -1,0 +1,52 @@
+// C-ABI entry of the fused aggregation forward (see agg_fwd_impl.h for the kernels).
+#include "agg_fwd_impl.h"
+
+using namespace sngnn;
+
+extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
+                                 float thr, float *out, float *wsel, float *inv_norm,
+                                 int32_t *sel_src, float *sel_w, void *workspace, void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    SN_REQUIRE(g->N == 0 || (h != nullptr && out != nullptr), SNGNN_EINVAL, "h/out is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    SN_REQUIRE(((uintptr_t)h % (cfg.vec * 4)) == 0 && ((uintptr_t)out % (cfg.vec * 4)) == 0,
+               SNGNN_EINVAL, "h/out must be aligned to the row vector width");
+    SN_REQUIRE((sel_src == nullptr) == (sel_w == nullptr), SNGNN_EINVAL,
+               "sel_src and sel_w go together");
+    SN_REQUIRE(sel_src == nullptr || top_k >= 0, SNGNN_EINVAL, "sel_src needs top_k >= 0");
+    SN_REQUIRE(sngnn_graph_workspace_bytes(g, C) == 0 || workspace != nullptr || g->n_tasks == 0,
+               SNGNN_EINVAL, "workspace is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (g->N == 0) return SNGNN_OK;
+    if (top_k > (1 << 20)) top_k = 1 << 20;     // more than any row can use
+
+    if (sel_src && top_k > 0) {
+        SN_HIP(hipMemsetAsync(sel_src, 0xFF, (size_t)g->N * top_k * 4, st));
+        SN_HIP(hipMemsetAsync(sel_w, 0, (size_t)g->N * top_k * 4, st));
+    }
+
+    FwdArgs a;
+    a.h = h; a.C = C; a.N = (int)g->N;
+    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
+    a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
+    a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
+    a.sel_src = top_k > 0 ? sel_src : nullptr; a.sel_w = top_k > 0 ? sel_w : nullptr;
+    a.n_split = g->n_split;
+    a.n_med_end = g->rows_gt(SMALL_T);
+    a.n_tasks = g->n_tasks;
+    a.task_slot = g->task_slot; a.task_chunk = g->task_chunk;
+    a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
+    a.scores = (float *)workspace;
+    a.partial = a.scores ? a.scores + g->split_edges : nullptr;
+    a.nbA = ceil_div(g->n_tasks, WAVES);
+    a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
+    const int max_split = g->n_split ? g->rdeg[0] : 0;
+    switch (cfg.vec) {
+    case 1: return launch_agg_fwd_v1(cfg, a, max_split, st);
+    case 2: return launch_agg_fwd_v2(cfg, a, max_split, st);
+    default: return launch_agg_fwd_v4(cfg, a, max_split, st);
+    }
+}

@@ -1,0 +1,562 @@
+// Fused forward of the similarity-navigated aggregation (gfx950).
+//
+// One launch computes, for every target row i of the CSR-by-target graph,
+//     s_e   = <h_i, h_j> / (max(|h_i|,eps) * max(|h_j|,eps))      per in-edge e = (j -> i)
+//     keep  = top_k by (s desc, edge position asc) AND s >= thr    (or all, top_k < 0)
+//     out_i = (1 / max(deg_i, 1)) * sum_{e kept} s_e * h_j
+// i.e. models/models.py:122+132+139-158, :238-239+244-263, :325-326+331-334 of the
+// reference without materialising any per-edge [E', C] tensor.
+//
+// Rows are processed in order of descending in-degree (graph.rperm) in three
+// classes, each a block range of the same launch:
+//   A  split rows  (deg > WAVE_T): one wave per CHUNK-edge task scores its edges
+//      (edge-balanced); a second launch (k_agg_fin) selects and sums per row;
+//   B  wave rows   (SMALL_T < deg <= WAVE_T): one wave per row, its 64/G lane
+//      groups stride over the row's edges;
+//   C  small rows  (deg <= SMALL_T): one G-lane group per row, 64/G rows per wave.
+// A row whose degree is <= top_k needs no ranking (only the threshold), so its
+// weighted sum is accumulated in the same pass that scores it ("streaming");
+// otherwise scores go to LDS (or HBM scratch for split rows), the row's top-k
+// is selected, and only the <= top_k kept source rows are gathered again.
+//
+// The kernels are HBM/Infinity-Cache bound gathers of 4*C-byte rows; each lane
+// group reads one whole source row per load (VEC*4 B per lane, coalesced).
+#pragma once
+#include "device_utils.h"
+
+namespace sngnn {
+
+struct FwdArgs {
+    const float *h;
+    int C, N;
+    const int32_t *rowptr, *col, *rperm;
+    int k;            // < 0: no selection
+    float thr;
+    float *out, *wsel, *inv_norm;
+    int32_t *sel_src;
+    float *sel_w;
+    int n_split, n_med_end;     // slots [0,n_split) split, [n_split,n_med_end) wave, rest small
+    int n_tasks;
+    const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
+    float *scores, *partial;    // workspace
+    int nbA, nbB;               // blocks of class A and B; the rest are class C
+};
+
+constexpr int LDS_PER_WAVE = 512;   // 32-bit words
+
+template <int R> struct Unroll { static constexpr int U = (R >= 4) ? 1 : (R == 2 ? 2 : 4); };
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i,
+                                            const Row<VEC, G, R> &x)
+{
+    float d = group_sum<G>(a.dot_partial(x));
+    float q = group_sum<G>(x.dot_partial(x));
+    float s = d * (inv_i * inv_norm_of(q));
+    return s + 0.0f;     // -0.0 -> +0.0: the reference orders floats, not bit patterns
+}
+
+// ---------------------------------------------------------------------------
+// Wave-level top-k over up to 128 scores held in LDS (2 per lane).
+// Returns the number of kept edges; list[] receives their row-local indices in
+// ascending order; sc[idx] keeps the score, flag via return of `kept` per lane.
+// ---------------------------------------------------------------------------
+struct WaveSel {
+    bool kept0, kept1;
+    unsigned long long key0, key1;
+    int nsel;
+};
+
+__device__ __forceinline__ WaveSel wave_select(const float *sc, int deg, int k, float thr)
+{
+    const int lane = lane_id();
+    const int i0 = lane, i1 = lane + 64;
+    const bool v0 = i0 < deg, v1 = i1 < deg;
+    const float s0 = v0 ? sc[i0] : 0.f, s1 = v1 ? sc[i1] : 0.f;
+    WaveSel r;
+    r.key0 = v0 ? sel_key(s0, i0) : 0ull;
+    r.key1 = v1 ? sel_key(s1, i1) : 0ull;
+    const bool p0 = v0 && s0 >= thr, p1 = v1 && s1 >= thr;
+    const int cnt_thr = __popcll(__ballot(p0)) + __popcll(__ballot(p1));
+    if (cnt_thr <= k) {            // the threshold alone decides
+        r.kept0 = p0; r.kept1 = p1; r.nsel = cnt_thr;
+        return r;
+    }
+    // k-th largest key by bitwise search (keys are unique)
+    unsigned long long T = 0;
+    for (int b = 63; b >= 32; --b) {
+        const unsigned long long cand = T | (1ull << b);
+        const int c = __popcll(__ballot(r.key0 >= cand)) + __popcll(__ballot(r.key1 >= cand));
+        if (c >= k) T = cand;
+    }
+    T |= 0xFFFFFF80ull;            // positions < 128: the upper 25 low-word bits are all ones
+    for (int b = 6; b >= 0; --b) {
+        const unsigned long long cand = T | (1ull << b);
+        const int c = __popcll(__ballot(r.key0 >= cand)) + __popcll(__ballot(r.key1 >= cand));
+        if (c >= k) T = cand;
+    }
+    r.kept0 = v0 && r.key0 >= T;
+    r.kept1 = v1 && r.key1 >= T;
+    r.nsel = k;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Class C: deg <= SMALL_T, one group per row.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    constexpr int U = Unroll<R>::U;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
+    const bool valid = slot < a.N;
+    const int i = valid ? a.rperm[slot] : 0;
+    const int rs = valid ? a.rowptr[i] : 0;
+    const int deg = valid ? a.rowptr[i + 1] - rs : 0;
+    const bool emit = a.sel_src != nullptr && a.k >= 0;
+    const bool rank = a.k >= 0 && deg > a.k;
+    const bool need_sc = rank || emit;
+
+    int *s_col = lds_wave + gid * SMALL_T;                       // [RPW][SMALL_T]
+    float *s_sc = reinterpret_cast<float *>(lds_wave + 128) + gid * SMALL_T;
+    float *s_w = reinterpret_cast<float *>(lds_wave + 256) + gid * SMALL_T;
+    int *s_rank = lds_wave + 384 + gid * SMALL_T;
+
+    for (int t = lg; t < deg; t += G) s_col[t] = a.col[rs + t];
+    wave_lds_sync();
+
+    RowT hi;
+    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+    if (valid && lg == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+
+    RowT acc;
+    acc.zero();
+    const int dmax = wave_max_i(deg);
+    for (int t0 = 0; t0 < dmax; t0 += U) {
+        int j[U];
+        bool act[U];
+        RowT x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            act[u] = (t0 + u) < deg;
+            j[u] = act[u] ? s_col[t0 + u] : i;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
+            if (act[u]) {
+                if (need_sc && lg == 0) s_sc[t0 + u] = s;
+                if (!rank) {
+                    const bool sel = (a.k < 0) || (s >= a.thr);
+                    if (sel) acc.axpy(s, x[u]);
+                    if (a.wsel && lg == 0) a.wsel[rs + t0 + u] = sel ? s : SNGNN_UNSELECTED;
+                }
+            }
+        }
+    }
+
+    if (need_sc) {
+        wave_lds_sync();
+        // rank of every edge of the row under (score desc, position asc)
+        for (int e = lg; e < deg; e += G) {
+            const float se = s_sc[e];
+            int rk = 0;
+            for (int b = 0; b < deg; ++b) {
+                const float sb = s_sc[b];
+                rk += (sb > se) || (sb == se && b < e);
+            }
+            const bool sel = rk < a.k && se >= a.thr;
+            s_w[e] = sel ? se : SNGNN_UNSELECTED;
+            s_rank[e] = rk;
+            if (rank && a.wsel) a.wsel[rs + e] = sel ? se : SNGNN_UNSELECTED;
+            if (emit && sel) {
+                a.sel_src[(size_t)i * a.k + rk] = s_col[e];
+                a.sel_w[(size_t)i * a.k + rk] = se;
+            }
+        }
+        if (rank) {
+            wave_lds_sync();
+            // second pass: gather only the kept source rows, in edge order
+            // (group-divergent trip count: no cross-lane operation inside)
+            for (int t = 0; t < deg; ++t) {
+                const float w = s_w[t];
+                if (w != SNGNN_UNSELECTED) {
+                    RowT x;
+                    x.load(a.h + (size_t)s_col[t] * a.C, a.C, lg);
+                    acc.axpy(w, x);
+                }
+            }
+        }
+    }
+    if (valid) {
+        acc.div((float)max(deg, 1));
+        acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scoring pass shared by classes A and B: the wave's 64/G groups stride over
+// the edges [e0, e1) of row i (row-local indices).
+//   STREAM: accumulate kept rows into acc (threshold only) and write wsel
+//   sc_out: where to put the scores (LDS or HBM scratch), or nullptr
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int e0, int e1,
+                                            const Row<VEC, G, R> &hi, float inv_i, bool stream,
+                                            float *sc_out, Row<VEC, G, R> &acc)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    constexpr int U = Unroll<R>::U;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    for (int base = e0; base < e1; base += NG * U) {
+        int t[U], j[U];
+        bool act[U];
+        RowT x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            t[u] = base + u * NG + gid;
+            act[u] = t[u] < e1;
+            j[u] = act[u] ? a.col[rs + t[u]] : i;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
+            if (act[u]) {
+                if (sc_out && lg == 0) sc_out[t[u]] = s;
+                if (stream) {
+                    const bool sel = (a.k < 0) || (s >= a.thr);
+                    if (sel) acc.axpy(s, x[u]);
+                    if (a.wsel && lg == 0) a.wsel[rs + t[u]] = sel ? s : SNGNN_UNSELECTED;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Class B: SMALL_T < deg <= WAVE_T, one wave per row.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void role_wave(const FwdArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_split + blk * WAVES + wave;
+    if (slot >= a.n_med_end) return;            // wave-uniform
+    const int i = a.rperm[slot];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const bool emit = a.sel_src != nullptr && a.k >= 0;
+    const bool rank = a.k >= 0 && deg > a.k;
+    const bool need_sc = rank || emit;
+
+    float *s_sc = reinterpret_cast<float *>(lds_wave);     // [WAVE_T]
+    int *s_list = lds_wave + WAVE_T;                         // [WAVE_T]
+
+    RowT hi;
+    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+    if (lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+
+    RowT acc;
+    acc.zero();
+    score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, acc);
+
+    if (need_sc) {
+        wave_lds_sync();
+        const WaveSel ws = wave_select(s_sc, deg, a.k, a.thr);
+        const int i0 = lane, i1 = lane + 64;
+        // kept list in ascending position order
+        const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
+        const int n0 = __popcll(m0);
+        if (ws.kept0) s_list[prefix_popc(m0)] = i0;
+        if (ws.kept1) s_list[n0 + prefix_popc(m1)] = i1;
+        const int nsel = n0 + __popcll(m1);
+        if (rank && a.wsel) {
+            if (i0 < deg) a.wsel[rs + i0] = ws.kept0 ? s_sc[i0] : SNGNN_UNSELECTED;
+            if (i1 < deg) a.wsel[rs + i1] = ws.kept1 ? s_sc[i1] : SNGNN_UNSELECTED;
+        }
+        wave_lds_sync();
+        if (emit) {
+            // rank of a kept edge = number of keys above it
+            for (int q = 0; q < nsel; ++q) {
+                const int idx = s_list[q];
+                const unsigned long long kq = sel_key(s_sc[idx], idx);
+                const int rk = __popcll(__ballot(ws.key0 > kq)) + __popcll(__ballot(ws.key1 > kq));
+                if (lane == 0) {
+                    a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
+                    a.sel_w[(size_t)i * a.k + rk] = s_sc[idx];
+                }
+            }
+        }
+        if (rank) {
+            for (int q0 = 0; q0 < nsel; q0 += NG) {
+                const int q = q0 + gid;
+                if (q < nsel) {
+                    const int idx = s_list[q];
+                    RowT x;
+                    x.load(a.h + (size_t)a.col[rs + idx] * a.C, a.C, lg);
+                    acc.axpy(s_sc[idx], x);
+                }
+            }
+        }
+    }
+    acc.reduce_across_groups();
+    if (gid == 0) {
+        acc.div((float)deg);
+        acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Class A: one CHUNK-edge task of a split row.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void role_task(const FwdArgs &a, int blk)
+{
+    using RowT = Row<VEC, G, R>;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int tq = blk * WAVES + wave;
+    if (tq >= a.n_tasks) return;                // wave-uniform
+    const int p = a.task_slot[tq], c = a.task_chunk[tq];
+    const int i = a.rperm[p];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const int e0 = c * CHUNK, e1 = min(deg, e0 + CHUNK);
+    const bool emit = a.sel_src != nullptr && a.k >= 0;
+    const bool rank = a.k >= 0 && deg > a.k;
+
+    RowT hi;
+    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+    if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+
+    RowT acc;
+    acc.zero();
+    float *sc = (rank || emit) ? a.scores + a.split_soff[p] : nullptr;
+    score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, acc);
+    if (!rank) {
+        acc.reduce_across_groups();
+        if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
+    }
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_agg_fwd(const FwdArgs a)
+{
+    __shared__ int lds[WAVES][LDS_PER_WAVE];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) role_task<VEC, G, R>(a, b);
+    else if (b < a.nbA + a.nbB) role_wave<VEC, G, R>(a, b - a.nbA, lw);
+    else role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+}
+
+// ---------------------------------------------------------------------------
+// Finalize of split rows: one FIN_BLOCK-thread workgroup per row.
+// ---------------------------------------------------------------------------
+struct __align__(16) FinShared {
+    int red[2][FIN_BLOCK / 64];
+    int wave_off[FIN_BLOCK / 64];
+    int nsel;
+    int pad[3];
+};
+static_assert(sizeof(FinShared) % 16 == 0, "keep the dynamic LDS base 16-byte aligned");
+static_assert(WAVE_T == 128 && SMALL_T == 16, "wave_select / role_small LDS layouts assume these");
+
+__device__ __forceinline__ int block_count(int c, FinShared &sh, int &parity)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    c = wave_sum_i(c);
+    if (lane == 0) sh.red[parity][wave] = c;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < FIN_BLOCK / 64; ++w) tot += sh.red[parity][w];
+    parity ^= 1;
+    return tot;
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_scores)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    constexpr int NW = FIN_BLOCK / 64;
+    extern __shared__ __align__(16) unsigned char dyn[];
+    __shared__ FinShared sh;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int p = blockIdx.x;
+    const int i = a.rperm[p];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const bool emit = a.sel_src != nullptr && a.k >= 0;
+    const bool rank = a.k >= 0 && deg > a.k;
+    const int kk = a.k < 0 ? 0 : min(a.k, deg);
+
+    // dynamic LDS: [C * NW] partial rows | [kk] kept list | [lds_scores] scores
+    float *s_part = reinterpret_cast<float *>(dyn);
+    int *s_list = reinterpret_cast<int *>(s_part + (size_t)a.C * NW);
+    float *s_scl = reinterpret_cast<float *>(s_list + (a.k < 0 ? 0 : a.k));
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+
+    if (!rank && !emit) {
+        // streaming row: add the tasks' partial rows in task order
+        for (int c = tid; c < a.C; c += FIN_BLOCK) {
+            float s = 0.f;
+            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+            a.out[(size_t)i * a.C + c] = s / (float)deg;
+        }
+        return;
+    }
+
+    const float *g_sc = a.scores + a.split_soff[p];
+    const float *sc = g_sc;
+    if (deg <= lds_scores) {
+        for (int e = tid; e < deg; e += FIN_BLOCK) s_scl[e] = g_sc[e];
+        sc = s_scl;
+    }
+    __syncthreads();
+
+    int parity = 0;
+    int c = 0;
+    for (int e = tid; e < deg; e += FIN_BLOCK) c += (sc[e] >= a.thr);
+    const int cnt_thr = block_count(c, sh, parity);
+    unsigned long long T = 0;
+    const bool thr_only = cnt_thr <= a.k;
+    if (!thr_only) {
+        int lowbits = 1;
+        while ((1 << lowbits) < deg) ++lowbits;
+        for (int b = 63; b >= 0; --b) {
+            if (b == 31) { T |= ~((1ull << lowbits) - 1ull) & 0xFFFFFFFFull; b = lowbits - 1; }
+            const unsigned long long cand = T | (1ull << b);
+            c = 0;
+            for (int e = tid; e < deg; e += FIN_BLOCK) c += (sel_key(sc[e], e) >= cand);
+            if (block_count(c, sh, parity) >= a.k) T = cand;
+        }
+    }
+    // ordered compaction of the kept edges (+ wsel)
+    if (tid == 0) sh.nsel = 0;
+    __syncthreads();
+    for (int base = 0; base < deg; base += FIN_BLOCK) {
+        const int e = base + tid;
+        const float s = e < deg ? sc[e] : 0.f;
+        const bool kept = e < deg && (thr_only ? (s >= a.thr) : (sel_key(s, e) >= T));
+        const unsigned long long m = __ballot(kept);
+        if (lane == 0) sh.wave_off[wave] = __popcll(m);
+        __syncthreads();
+        int off = sh.nsel;
+        for (int w = 0; w < wave; ++w) off += sh.wave_off[w];
+        if (kept) s_list[off + prefix_popc(m)] = e;
+        if (rank && a.wsel && e < deg) a.wsel[rs + e] = kept ? s : SNGNN_UNSELECTED;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < NW; ++w) tot += sh.wave_off[w];
+            sh.nsel += tot;
+        }
+        __syncthreads();
+    }
+    const int nsel = sh.nsel;
+
+    if (emit) {
+        for (int q = tid; q < nsel; q += FIN_BLOCK) {
+            const int idx = s_list[q];
+            const unsigned long long kq = sel_key(sc[idx], idx);
+            int rk = 0;
+            for (int r = 0; r < nsel; ++r) {
+                const int ir = s_list[r];
+                rk += sel_key(sc[ir], ir) > kq;
+            }
+            a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
+            a.sel_w[(size_t)i * a.k + rk] = sc[idx];
+        }
+    }
+
+    RowT acc;
+    acc.zero();
+    if (rank) {
+        for (int q0 = 0; q0 < nsel; q0 += NW * NG) {
+            const int q = q0 + wave * NG + gid;
+            if (q < nsel) {
+                const int idx = s_list[q];
+                RowT x;
+                x.load(a.h + (size_t)a.col[rs + idx] * a.C, a.C, lg);
+                acc.axpy(sc[idx], x);
+            }
+        }
+        acc.reduce_across_groups();
+        if (gid == 0) acc.store(s_part + (size_t)wave * a.C, a.C, lg);
+        __syncthreads();
+        for (int ch = tid; ch < a.C; ch += FIN_BLOCK) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += s_part[(size_t)w * a.C + ch];
+            a.out[(size_t)i * a.C + ch] = s / (float)deg;
+        }
+    } else {
+        // emit on a streaming row: the sum itself still comes from the partials
+        for (int ch = tid; ch < a.C; ch += FIN_BLOCK) {
+            float s = 0.f;
+            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + ch];
+            a.out[(size_t)i * a.C + ch] = s / (float)deg;
+        }
+    }
+    (void)kk;
+}
+
+template <int VEC, int G, int R> int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    const int n_small = a.N - a.n_med_end;
+    const int nbC = ceil_div(n_small, (int64_t)WAVES * RPW);
+    const int grid = a.nbA + a.nbB + nbC;
+    if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
+    if (a.n_split > 0) {
+        const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)(a.k < 0 ? 0 : a.k) * 4;
+        const size_t budget = 120 * 1024;
+        int lds_scores = 0;
+        if (fixed < budget) lds_scores = (int)std::min<size_t>((budget - fixed) / 4, (size_t)max_split_deg);
+        const size_t dyn = fixed + (size_t)lds_scores * 4;
+        if (dyn > 150 * 1024) { set_error("top_k too large for the split-row finalize"); return SNGNN_EINVAL; }
+        if (dyn > 48 * 1024)
+            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin<VEC, G, R>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        k_agg_fin<VEC, G, R><<<a.n_split, FIN_BLOCK, dyn, st>>>(a, lds_scores);
+    }
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+// one translation unit per VEC instantiates these
+int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
+int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
+int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
+
+#define SNGNN_DISPATCH_GR(FN, VEC, cfg, ...)                                   \
+    switch ((cfg).g * 100 + (cfg).r) {                                         \
+    case 801: return FN<VEC, 8, 1>(__VA_ARGS__);                               \
+    case 1601: return FN<VEC, 16, 1>(__VA_ARGS__);                             \
+    case 3201: return FN<VEC, 32, 1>(__VA_ARGS__);                             \
+    case 6401: return FN<VEC, 64, 1>(__VA_ARGS__);                             \
+    case 6402: return FN<VEC, 64, 2>(__VA_ARGS__);                             \
+    case 6404: return FN<VEC, 64, 4>(__VA_ARGS__);                             \
+    case 6408: return FN<VEC, 64, 8>(__VA_ARGS__);                             \
+    default: sngnn::set_error("unsupported channel layout"); return SNGNN_EINVAL; \
+    }
+
+}  // namespace sngnn

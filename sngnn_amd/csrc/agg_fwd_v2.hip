@@ -1,0 +1,11 @@
+// Instantiates the fused aggregation forward for rows read 2 float(s) per lane.
+#include "agg_fwd_impl.h"
+
+namespace sngnn {
+
+int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_agg_fwd, 2, cfg, a, max_split_deg, st)
+}
+
+}  // namespace sngnn

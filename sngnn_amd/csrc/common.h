@@ -1,0 +1,94 @@
+// Shared host/device definitions of libsngnn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "sngnn_hip.h"
+
+namespace sngnn {
+
+// ---- row classes of the aggregation kernels (by in-degree) -----------------
+constexpr int SMALL_T = 16;    // deg <= SMALL_T : one G-lane group per row
+constexpr int WAVE_T = 128;    // deg <= WAVE_T  : one wave per row
+constexpr int CHUNK = 128;     // deg >  WAVE_T  : split into CHUNK-edge wave tasks
+constexpr int BLOCK = 256;     // threads per workgroup of the main kernels
+constexpr int WAVES = BLOCK / 64;
+constexpr int FIN_BLOCK = 1024;   // threads per workgroup of the split-row finalize
+constexpr float EPS_NORM = 1e-12f;   // F.normalize eps (models.py:122,238,325)
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define SN_HIP(expr)                                                       \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) return sngnn::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define SN_REQUIRE(cond, code, msg)                                        \
+    do {                                                                   \
+        if (!(cond)) { sngnn::set_error(msg); return (code); }             \
+    } while (0)
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Lane layout of one node row for C channels:
+//   VEC floats per lane per step, G lanes per group, R steps  (C <= VEC*G*R).
+struct RowCfg { int vec, g, r; };
+inline bool row_cfg(int C, RowCfg &cfg)
+{
+    if (C < 1 || C > SNGNN_MAX_CHANNELS) return false;
+    int vec = (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1;
+    int lanes = C / vec;
+    int g = 8;
+    while (g < lanes && g < 64) g <<= 1;
+    int r = (lanes + g - 1) / g;
+    int rr = 1;
+    while (rr < r) rr <<= 1;
+    if (rr > 8) return false;
+    cfg = {vec, g, rr};
+    return true;
+}
+
+}  // namespace sngnn
+
+// The graph object behind the opaque handle.
+struct sngnn_graph {
+    int64_t N = 0, E_in = 0, Ep = 0;
+    int add_loops = 0, remove_loops = 0;
+    // device arrays
+    int32_t *rowptr = nullptr, *col = nullptr, *eid = nullptr;
+    int32_t *cscptr = nullptr, *csc_eid = nullptr, *csc_dst = nullptr;
+    int32_t *rperm = nullptr, *sperm = nullptr;
+    // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
+    int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
+    int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
+    int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
+    // split sources (out-degree > WAVE_T) = the first n_ssplit slots of sperm
+    int32_t *stask_slot = nullptr, *stask_chunk = nullptr;  // [n_stasks]
+    int32_t *ssplit_task0 = nullptr;  // [n_ssplit+1]
+    // host copies
+    std::vector<int32_t> rdeg;   // in-degrees, descending  (rdeg[p] = deg(rperm[p]))
+    std::vector<int32_t> sdeg;   // out-degrees, descending
+    int64_t max_in_deg = 0, max_out_deg = 0, src_min = 0;
+    int n_split = 0, n_tasks = 0;
+    int64_t split_edges = 0;
+    int n_ssplit = 0, n_stasks = 0;
+    int device = 0;
+
+    // number of rows with in-degree > t (rdeg is descending)
+    int rows_gt(int64_t t) const
+    {
+        int lo = 0, hi = (int)rdeg.size();
+        while (lo < hi) { int m = (lo + hi) / 2; if (rdeg[m] > t) lo = m + 1; else hi = m; }
+        return lo;
+    }
+    int srcs_gt(int64_t t) const
+    {
+        int lo = 0, hi = (int)sdeg.size();
+        while (lo < hi) { int m = (lo + hi) / 2; if (sdeg[m] > t) lo = m + 1; else hi = m; }
+        return lo;
+    }
+};

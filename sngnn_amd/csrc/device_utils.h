@@ -1,0 +1,182 @@
+// Device-side helpers shared by the aggregation kernels (gfx950, wave = 64).
+#pragma once
+#include "common.h"
+
+namespace sngnn {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Butterfly sum over the G lanes of a group; every lane ends with the same bits.
+template <int G> __device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Sum of the per-group values over the 64/G groups of a wave (same lane offset).
+template <int G> __device__ __forceinline__ float cross_group_sum(float v)
+{
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Orders LDS traffic between the lanes of ONE wave (DS ops of a wave execute in
+// issue order; the fences stop the compiler from moving accesses across).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// fp32 -> uint32 whose unsigned order equals the float order (-0.0 must have
+// been canonicalised to +0.0 by the caller: the reference compares floats).
+__device__ __forceinline__ unsigned f2key(float s)
+{
+    unsigned u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Selection key: larger == better.  (cosine descending, position ascending.)
+__device__ __forceinline__ unsigned long long sel_key(float s, unsigned idx)
+{
+    return ((unsigned long long)f2key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// One node row spread over the G lanes of a group: lane lg holds VEC consecutive
+// channels per step, R steps.  Channels beyond C read as zero.
+template <int VEC, int G, int R> struct Row {
+    float x[R][VEC];
+
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] = 0.f;
+    }
+
+    __device__ __forceinline__ void load(const float *__restrict__ row, int C, int lg)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c0 = (r * G + lg) * VEC;
+            if (c0 < C) {
+                if constexpr (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(row + c0);
+                    x[r][0] = t.x; x[r][1] = t.y; x[r][2] = t.z; x[r][3] = t.w;
+                } else if constexpr (VEC == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(row + c0);
+                    x[r][0] = t.x; x[r][1] = t.y;
+                } else {
+                    x[r][0] = row[c0];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x[r][v] = 0.f;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float *__restrict__ row, int C, int lg) const
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int c0 = (r * G + lg) * VEC;
+            if (c0 < C) {
+                if constexpr (VEC == 4) {
+                    *reinterpret_cast<float4 *>(row + c0) = make_float4(x[r][0], x[r][1], x[r][2], x[r][3]);
+                } else if constexpr (VEC == 2) {
+                    *reinterpret_cast<float2 *>(row + c0) = make_float2(x[r][0], x[r][1]);
+                } else {
+                    row[c0] = x[r][0];
+                }
+            }
+        }
+    }
+
+    // per-lane partial of <this, o> (fma chain in channel order)
+    __device__ __forceinline__ float dot_partial(const Row &o) const
+    {
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) d = fmaf(x[r][v], o.x[r][v], d);
+        return d;
+    }
+
+    // this += w * o   with the product rounded before the add, like ATen's
+    // (weight * x_j) followed by scatter_add
+    __device__ __forceinline__ void axpy(float w, const Row &o)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] = __fadd_rn(x[r][v], __fmul_rn(w, o.x[r][v]));
+    }
+
+    __device__ __forceinline__ void add(const Row &o)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] += o.x[r][v];
+    }
+
+    __device__ __forceinline__ void scale(float w)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] *= w;
+    }
+
+    __device__ __forceinline__ void div(float d)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] = x[r][v] / d;
+    }
+
+    // sum the per-group rows of a wave (all lanes end with the total)
+    __device__ __forceinline__ void reduce_across_groups()
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] = cross_group_sum<G>(x[r][v]);
+    }
+};
+
+// 1 / max(||row||_2, eps) from the group-summed sum of squares
+__device__ __forceinline__ float inv_norm_of(float sumsq)
+{
+    return 1.0f / fmaxf(sqrtf(sumsq), EPS_NORM);
+}
+
+}  // namespace sngnn

@@ -1,0 +1,372 @@
+// Graph structure build for libsngnn_hip (gfx950).
+//
+// Replaces the per-forward self-loop handling of the reference's conv layers
+// (models/models.py:117-120, 234-236, 323: PyG add_self_loops then optionally
+// remove_self_loops) and the per-target grouping that PyG propagate /
+// torch_scatter do implicitly on every call, by a one-time device build of
+//   * CSR by target, edges of a row in their original relative order (stable
+//     radix sort on the target id) - "edge position" is the reference's
+//     tie-breaker (torch_scatter scatter_max CPU: first occurrence wins),
+//   * CSC by source (for the atomics-free backward),
+//   * rows / sources sorted by degree, descending (work balancing),
+//   * the split-row task lists for rows longer than one wave handles.
+// Sorting and scanning use rocPRIM through hipCUB (setup, not the hot path).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "common.h"
+
+namespace sngnn {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file +
+            ":" + std::to_string(line);
+    return SNGNN_EHIP;
+}
+
+// candidate t in [0, E + n_loops): original edge or appended self-loop
+__global__ void k_mark(const int64_t *__restrict__ ei, int64_t E, int64_t T, int64_t N,
+                       int remove_loops, int32_t *__restrict__ keep, int32_t *__restrict__ bad)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    int64_t s, d;
+    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = t - E; }
+    if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(bad, 1); keep[t] = 0; return; }
+    keep[t] = (remove_loops && s == d) ? 0 : 1;
+}
+
+__global__ void k_compact(const int64_t *__restrict__ ei, int64_t E, int64_t T,
+                          const int32_t *__restrict__ keep, const int32_t *__restrict__ pos,
+                          int32_t *__restrict__ src32, int32_t *__restrict__ dst32)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || !keep[t]) return;
+    int64_t s, d;
+    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = t - E; }
+    src32[pos[t]] = (int32_t)s;
+    dst32[pos[t]] = (int32_t)d;
+}
+
+__global__ void k_iota(int32_t *a, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = (int32_t)t;
+}
+
+__global__ void k_gather(const int32_t *__restrict__ idx, const int32_t *__restrict__ table,
+                         int32_t *__restrict__ out, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = table[idx[t]];
+}
+
+// ptr[i] = first position p with sorted_keys[p] >= i   (i in [0, N])
+__global__ void k_lower_bound(const int32_t *__restrict__ keys, int64_t n, int64_t N,
+                              int32_t *__restrict__ ptr)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t m = (lo + hi) >> 1;
+        if (keys[m] < (int32_t)i) lo = m + 1; else hi = m;
+    }
+    ptr[i] = (int32_t)lo;
+}
+
+__global__ void k_degree(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ deg)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) deg[i] = ptr[i + 1] - ptr[i];
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? 0 : SNGNN_ENOMEM; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+static inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+static int bits_for(int64_t n)
+{
+    int b = 1;
+    while (((int64_t)1 << b) < n && b < 31) ++b;
+    return b;
+}
+
+// stable sort of (key, value) pairs by key ascending / descending
+static int sort_pairs(const int32_t *kin, int32_t *kout, const int32_t *vin, int32_t *vout,
+                      int64_t n, int end_bit, bool descending, hipStream_t st)
+{
+    size_t tmp_bytes = 0;
+    if (descending)
+        SN_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, kin, kout, vin, vout,
+                                                           (int)n, 0, end_bit, st));
+    else
+        SN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, vin, vout, (int)n,
+                                                  0, end_bit, st));
+    DevBuf tmp;
+    if (tmp.alloc(tmp_bytes)) { set_error("out of device memory (sort scratch)"); return SNGNN_ENOMEM; }
+    if (descending)
+        SN_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tmp_bytes, kin, kout, vin, vout,
+                                                           (int)n, 0, end_bit, st));
+    else
+        SN_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, kin, kout, vin, vout, (int)n, 0,
+                                                  end_bit, st));
+    SN_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+template <class T> static int dev_alloc(T **p, int64_t n)
+{
+    if (hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)) != hipSuccess) {
+        set_error("out of device memory (graph arrays)");
+        return SNGNN_ENOMEM;
+    }
+    return 0;
+}
+
+// Task lists for rows (or sources) whose degree exceeds WAVE_T: the first
+// n_split slots of the degree-sorted permutation, CHUNK edges per task.
+static int build_tasks(const std::vector<int32_t> &deg_desc, int n_split, int32_t **task_slot,
+                       int32_t **task_chunk, int32_t **task0, int32_t **soff, int *n_tasks,
+                       int64_t *split_edges)
+{
+    std::vector<int32_t> slot, chunk, t0(n_split + 1, 0), so(n_split + 1, 0);
+    int64_t off = 0;
+    for (int p = 0; p < n_split; ++p) {
+        int nch = (deg_desc[p] + CHUNK - 1) / CHUNK;
+        t0[p] = (int32_t)slot.size();
+        so[p] = (int32_t)off;
+        for (int c = 0; c < nch; ++c) { slot.push_back(p); chunk.push_back(c); }
+        off += deg_desc[p];
+    }
+    t0[n_split] = (int32_t)slot.size();
+    so[n_split] = (int32_t)off;
+    *n_tasks = (int)slot.size();
+    if (split_edges) *split_edges = off;
+    int rc;
+    if ((rc = dev_alloc(task_slot, (int64_t)slot.size()))) return rc;
+    if ((rc = dev_alloc(task_chunk, (int64_t)slot.size()))) return rc;
+    if ((rc = dev_alloc(task0, n_split + 1))) return rc;
+    if (soff && (rc = dev_alloc(soff, n_split + 1))) return rc;
+    if (!slot.empty()) {
+        SN_HIP(hipMemcpy(*task_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice));
+        SN_HIP(hipMemcpy(*task_chunk, chunk.data(), chunk.size() * 4, hipMemcpyHostToDevice));
+    }
+    SN_HIP(hipMemcpy(*task0, t0.data(), t0.size() * 4, hipMemcpyHostToDevice));
+    if (soff) SN_HIP(hipMemcpy(*soff, so.data(), so.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t N, int add_loops,
+                 int remove_loops, hipStream_t st)
+{
+    const int64_t n_loops = (add_loops && !remove_loops) ? N : 0;   // add+remove == remove
+    const int64_t T = E + n_loops;
+    SN_REQUIRE(T < ((int64_t)1 << 31) - 1 && N < ((int64_t)1 << 31) - 1, SNGNN_EINVAL,
+               "graph too large for 32-bit indices");
+    SN_HIP(hipGetDevice(&g->device));
+    g->N = N; g->E_in = E; g->add_loops = add_loops; g->remove_loops = remove_loops;
+    int rc;
+
+    // 1. mark + validate, 2. scan, 3. compact to int32 (src, dst) in list order
+    DevBuf keep, pos, bad, src32, dst32;
+    if (keep.alloc((size_t)T * 4) || pos.alloc((size_t)T * 4) || bad.alloc(4)) {
+        set_error("out of device memory (graph build)");
+        return SNGNN_ENOMEM;
+    }
+    SN_HIP(hipMemsetAsync(bad.p, 0, 4, st));
+    int64_t Ep = 0;
+    if (T > 0) {
+        k_mark<<<grid1(T), 256, 0, st>>>(ei, E, T, N, remove_loops, keep.as<int32_t>(),
+                                         bad.as<int32_t>());
+        size_t tmp_bytes = 0;
+        SN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep.as<int32_t>(),
+                                                pos.as<int32_t>(), (int)T, st));
+        DevBuf tmp;
+        if (tmp.alloc(tmp_bytes)) { set_error("out of device memory (scan scratch)"); return SNGNN_ENOMEM; }
+        SN_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, keep.as<int32_t>(),
+                                                pos.as<int32_t>(), (int)T, st));
+        int32_t last_pos = 0, last_keep = 0, h_bad = 0;
+        SN_HIP(hipMemcpyAsync(&last_pos, pos.as<int32_t>() + (T - 1), 4, hipMemcpyDeviceToHost, st));
+        SN_HIP(hipMemcpyAsync(&last_keep, keep.as<int32_t>() + (T - 1), 4, hipMemcpyDeviceToHost, st));
+        SN_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
+        SN_HIP(hipStreamSynchronize(st));
+        SN_REQUIRE(!h_bad, SNGNN_ERANGE, "edge_index contains a node id outside [0, N)");
+        Ep = (int64_t)last_pos + last_keep;
+    }
+    g->Ep = Ep;
+    if (src32.alloc((size_t)Ep * 4) || dst32.alloc((size_t)Ep * 4)) {
+        set_error("out of device memory (graph build)");
+        return SNGNN_ENOMEM;
+    }
+    if (T > 0)
+        k_compact<<<grid1(T), 256, 0, st>>>(ei, E, T, keep.as<int32_t>(), pos.as<int32_t>(),
+                                            src32.as<int32_t>(), dst32.as<int32_t>());
+
+    if ((rc = dev_alloc(&g->rowptr, N + 1)) || (rc = dev_alloc(&g->col, Ep)) ||
+        (rc = dev_alloc(&g->eid, Ep)) || (rc = dev_alloc(&g->cscptr, N + 1)) ||
+        (rc = dev_alloc(&g->csc_eid, Ep)) || (rc = dev_alloc(&g->csc_dst, Ep)) ||
+        (rc = dev_alloc(&g->rperm, N)) || (rc = dev_alloc(&g->sperm, N)))
+        return rc;
+
+    const int nbits = bits_for(std::max<int64_t>(N, 2));
+    DevBuf iota, keys_sorted, deg, deg_sorted;
+    if (iota.alloc((size_t)std::max(Ep, N) * 4) || keys_sorted.alloc((size_t)std::max(Ep, N) * 4) ||
+        deg.alloc((size_t)N * 4) || deg_sorted.alloc((size_t)N * 4)) {
+        set_error("out of device memory (graph build)");
+        return SNGNN_ENOMEM;
+    }
+    int32_t *d_iota = iota.as<int32_t>(), *d_keys = keys_sorted.as<int32_t>();
+    if (std::max(Ep, N) > 0) k_iota<<<grid1(std::max(Ep, N)), 256, 0, st>>>(d_iota, std::max(Ep, N));
+
+    // 4. CSR by target: stable sort of list positions by dst
+    if (Ep > 0) {
+        if ((rc = sort_pairs(dst32.as<int32_t>(), d_keys, d_iota, g->eid, Ep, nbits, false, st))) return rc;
+        k_gather<<<grid1(Ep), 256, 0, st>>>(g->eid, src32.as<int32_t>(), g->col, Ep);
+    }
+    k_lower_bound<<<grid1(N + 1), 256, 0, st>>>(d_keys, Ep, N, g->rowptr);
+    DevBuf dst_csr;   // target of each CSR edge (== sorted keys); keep a copy for CSC
+    if (dst_csr.alloc((size_t)Ep * 4)) { set_error("out of device memory (graph build)"); return SNGNN_ENOMEM; }
+    if (Ep > 0) SN_HIP(hipMemcpyAsync(dst_csr.p, d_keys, (size_t)Ep * 4, hipMemcpyDeviceToDevice, st));
+
+    // 5. rows by in-degree, descending (stable => ascending row id inside a degree)
+    g->rdeg.assign((size_t)N, 0);
+    if (N > 0) {
+        k_degree<<<grid1(N), 256, 0, st>>>(g->rowptr, N, deg.as<int32_t>());
+        if ((rc = sort_pairs(deg.as<int32_t>(), deg_sorted.as<int32_t>(), d_iota, g->rperm, N, 31, true, st)))
+            return rc;
+        SN_HIP(hipMemcpy(g->rdeg.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+    g->max_in_deg = N ? g->rdeg[0] : 0;
+
+    // 6. CSC by source: stable sort of CSR positions by col
+    if (Ep > 0) {
+        if ((rc = sort_pairs(g->col, d_keys, d_iota, g->csc_eid, Ep, nbits, false, st))) return rc;
+        k_gather<<<grid1(Ep), 256, 0, st>>>(g->csc_eid, dst_csr.as<int32_t>(), g->csc_dst, Ep);
+        int32_t mn = 0;
+        SN_HIP(hipMemcpy(&mn, d_keys, 4, hipMemcpyDeviceToHost));
+        g->src_min = mn;
+    }
+    k_lower_bound<<<grid1(N + 1), 256, 0, st>>>(d_keys, Ep, N, g->cscptr);
+    g->sdeg.assign((size_t)N, 0);
+    if (N > 0) {
+        k_degree<<<grid1(N), 256, 0, st>>>(g->cscptr, N, deg.as<int32_t>());
+        if ((rc = sort_pairs(deg.as<int32_t>(), deg_sorted.as<int32_t>(), d_iota, g->sperm, N, 31, true, st)))
+            return rc;
+        SN_HIP(hipMemcpy(g->sdeg.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+    g->max_out_deg = N ? g->sdeg[0] : 0;
+
+    // 7. split-row / split-source task lists
+    g->n_split = g->rows_gt(WAVE_T);
+    if ((rc = build_tasks(g->rdeg, g->n_split, &g->task_slot, &g->task_chunk, &g->split_task0,
+                          &g->split_soff, &g->n_tasks, &g->split_edges)))
+        return rc;
+    g->n_ssplit = g->srcs_gt(WAVE_T);
+    if ((rc = build_tasks(g->sdeg, g->n_ssplit, &g->stask_slot, &g->stask_chunk, &g->ssplit_task0,
+                          nullptr, &g->n_stasks, nullptr)))
+        return rc;
+    SN_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace sngnn
+
+#define SN_STR2(x) #x
+#define SN_STR(x) SN_STR2(x)
+using namespace sngnn;
+
+extern "C" {
+
+const char *sngnn_last_error(void) { return g_err.c_str(); }
+
+const char *sngnn_build_info(void)
+{
+    return "libsngnn_hip;arch=gfx950;hip=" SN_STR(HIP_VERSION_MAJOR) "." SN_STR(HIP_VERSION_MINOR);
+}
+
+int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int add_loops,
+                       int remove_loops, void *stream, sngnn_graph_t **out_graph)
+{
+    SN_REQUIRE(out_graph != nullptr, SNGNN_EINVAL, "out_graph is NULL");
+    *out_graph = nullptr;
+    SN_REQUIRE(E >= 0 && N >= 0, SNGNN_EINVAL, "negative size");
+    SN_REQUIRE(E == 0 || edge_index_dev != nullptr, SNGNN_EINVAL, "edge_index is NULL");
+    sngnn_graph *g = new (std::nothrow) sngnn_graph();
+    SN_REQUIRE(g != nullptr, SNGNN_ENOMEM, "out of host memory");
+    int rc = build(g, edge_index_dev, E, N, add_loops != 0, remove_loops != 0, (hipStream_t)stream);
+    if (rc != 0) { sngnn_graph_destroy(g); return rc; }
+    *out_graph = g;
+    return SNGNN_OK;
+}
+
+void sngnn_graph_destroy(sngnn_graph_t *g)
+{
+    if (!g) return;
+    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
+                    g->sperm, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
+                    g->stask_slot, g->stask_chunk, g->ssplit_task0};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete g;
+}
+
+int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g) { return g ? g->N : -1; }
+int64_t sngnn_graph_num_edges(const sngnn_graph_t *g) { return g ? g->Ep : -1; }
+int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g) { return g ? g->max_in_deg : -1; }
+int64_t sngnn_graph_src_min(const sngnn_graph_t *g) { return g ? g->src_min : -1; }
+
+int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
+{
+    if (!g || C < 1) return -1;
+    // forward: scores of split rows + one partial row per split task
+    int64_t fwd = g->split_edges * 4 + (int64_t)g->n_tasks * C * 4;
+    // backward: d(cosine) per edge + target-side d(normalised row) per node
+    //           + one partial row per split-source task
+    int64_t bwd = g->Ep * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_stasks * C * 4 * 2 +
+                  (int64_t)g->n_tasks * C * 4;
+    int64_t b = std::max(fwd, bwd);
+    return (b + 255) / 256 * 256;
+}
+
+static const void *graph_array(const sngnn_graph_t *g, int which, int64_t *n)
+{
+    switch (which) {
+    case 0: *n = g->N + 1; return g->rowptr;
+    case 1: *n = g->Ep; return g->col;
+    case 2: *n = g->Ep; return g->eid;
+    case 3: *n = g->N + 1; return g->cscptr;
+    case 4: *n = g->Ep; return g->csc_eid;
+    case 5: *n = g->N; return g->rperm;
+    default: *n = 0; return nullptr;
+    }
+}
+
+int sngnn_graph_copy_array(const sngnn_graph_t *g, int which, void *host_dst)
+{
+    SN_REQUIRE(g && host_dst, SNGNN_EINVAL, "NULL argument");
+    int64_t n = 0;
+    const void *p = graph_array(g, which, &n);
+    SN_REQUIRE(p != nullptr, SNGNN_EINVAL, "unknown array id");
+    if (n > 0) SN_HIP(hipMemcpy(host_dst, p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SNGNN_OK;
+}
+
+const void *sngnn_graph_array_dev(const sngnn_graph_t *g, int which)
+{
+    if (!g) return nullptr;
+    int64_t n = 0;
+    return graph_array(g, which, &n);
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""Device graph structure, built once per (edge_index, self-loop mode).
+
+The reference redoes ``add_self_loops`` / ``remove_self_loops`` and the implicit
+per-target grouping on every forward (models/models.py:117-120, 234-236, 323);
+here the C library builds CSR-by-target / CSC-by-source once and the conv layers
+look it up in a small cache keyed on the identity and version of ``edge_index``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_ARRAYS = {"rowptr": 0, "col": 1, "eid": 2, "cscptr": 3, "csc_eid": 4, "rperm": 5}
+
+
+class Graph:
+    """Owns a ``sngnn_graph_t`` handle."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
+                 remove_loops: bool):
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+        if not edge_index.is_cuda:
+            raise ValueError("edge_index must live on the GPU (there is no CPU path)")
+        lib = _lib.load()
+        ei = edge_index.contiguous()
+        self.device = ei.device
+        self.add_loops, self.remove_loops = bool(add_loops), bool(remove_loops)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = lib.sngnn_graph_create(ei.data_ptr(), ei.size(1), int(num_nodes),
+                                        int(add_loops), int(remove_loops), stream,
+                                        C.byref(handle))
+        _lib.check(rc, "sngnn_graph_create")
+        self._h = handle
+        self.num_nodes = int(lib.sngnn_graph_num_nodes(handle))
+        self.num_edges = int(lib.sngnn_graph_num_edges(handle))
+        self.max_in_degree = int(lib.sngnn_graph_max_in_degree(handle))
+        self.src_min = int(lib.sngnn_graph_src_min(handle))
+        self._ws: Dict[int, torch.Tensor] = {}
+
+    @property
+    def handle(self):
+        return self._h
+
+    def workspace(self, channels: int) -> torch.Tensor:
+        """Scratch for forward/backward at ``channels`` (cached per width; calls on
+        one graph are expected on one stream at a time)."""
+        ws = self._ws.get(channels)
+        if ws is None:
+            nbytes = int(_lib.load().sngnn_graph_workspace_bytes(self._h, channels))
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws[channels] = ws
+        return ws
+
+    def array(self, name: str) -> np.ndarray:
+        """Host copy of one of the structure arrays (tests / inspection)."""
+        which = _ARRAYS[name]
+        n = {0: self.num_nodes + 1, 3: self.num_nodes + 1, 5: self.num_nodes}.get(which,
+                                                                                  self.num_edges)
+        out = np.empty(n, dtype=np.int32)
+        _lib.check(_lib.load().sngnn_graph_copy_array(self._h, which, out.ctypes.data),
+                   "sngnn_graph_copy_array")
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.load().sngnn_graph_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class GraphCache:
+    """Per-module cache: (edge_index storage, shape, version, loop mode) -> Graph."""
+
+    def __init__(self, max_entries: int = 4):
+        self._entries: Dict[Tuple, Tuple[Graph, torch.Tensor]] = {}
+        self._max = max_entries
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
+            remove_loops: bool) -> Graph:
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
+               int(num_nodes), bool(add_loops), bool(remove_loops), str(edge_index.device))
+        hit = self._entries.get(key)
+        if hit is None:
+            if len(self._entries) >= self._max:
+                self._entries.pop(next(iter(self._entries)))
+            # the entry keeps edge_index alive, so its address cannot be recycled
+            # for a different tensor while the key is cached
+            hit = (Graph(edge_index, num_nodes, add_loops, remove_loops), edge_index)
+            self._entries[key] = hit
+        return hit[0]
+
+    def clear(self):
+        self._entries.clear()
+
+
+# Graphs are shared between the layers of a model (same edge_index, same mode).
+GLOBAL_CACHE = GraphCache(max_entries=16)

@@ -1,0 +1,154 @@
+"""Operator-level Python entry points over the C ABI (include/sngnn_hip.h).
+
+``aggregate`` is the fused replacement of everything the reference's conv layers
+do after ``self.lin``: F.normalize, the per-edge cosine, the top-k / threshold
+loop over torch_scatter.scatter_max and the mean aggregation
+(models/models.py:122+132+139-158, :238-239+244-263, :325-326+331-334).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .graph import Graph
+
+
+def _check_rows(t: torch.Tensor, n: int, what: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise ValueError(f"{what} must be float32 (the reference path is fp32 only)")
+    if not t.is_cuda:
+        raise ValueError(f"{what} must live on the GPU (there is no CPU path)")
+    if t.dim() != 2 or t.size(0) != n:
+        raise ValueError(f"{what} must have shape [{n}, C], got {tuple(t.shape)}")
+    if not 1 <= t.size(1) <= _lib.MAX_CHANNELS:
+        raise ValueError(f"{what}: C must be in [1, {_lib.MAX_CHANNELS}]")
+    return t.contiguous()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def aggregate_forward(graph: Graph, h: torch.Tensor, top_k: Optional[int], thr: float, *,
+                      save_for_backward: bool = False, want_selection: bool = False):
+    """Returns (out, wsel, inv_norm, sel_src, sel_w); the optional ones are None
+    unless requested.  ``top_k=None`` is SNConv (no selection)."""
+    lib = _lib.load()
+    n = graph.num_nodes
+    h = _check_rows(h, n, "h")
+    c = h.size(1)
+    k = -1 if top_k is None else int(top_k)
+    if top_k is not None and k < 0:
+        raise ValueError("top_k must be >= 0")
+    out = torch.empty_like(h)
+    wsel = inv = sel_src = sel_w = None
+    if save_for_backward:
+        wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=h.device)
+        inv = torch.empty(n, dtype=torch.float32, device=h.device)
+    if want_selection:
+        if k < 0:
+            raise ValueError("the selection is only defined for top_k >= 0")
+        sel_src = torch.empty((n, k), dtype=torch.int32, device=h.device)
+        sel_w = torch.empty((n, k), dtype=torch.float32, device=h.device)
+    ws = graph.workspace(c)
+    with torch.cuda.device(h.device):
+        rc = lib.sngnn_agg_forward(graph.handle, h.data_ptr(), c, k, float(thr), out.data_ptr(),
+                                   _lib.ptr(wsel), _lib.ptr(inv), _lib.ptr(sel_src),
+                                   _lib.ptr(sel_w), ws.data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_agg_forward")
+    return out, wsel, inv, sel_src, sel_w
+
+
+def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
+                       wsel: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    n = graph.num_nodes
+    h = _check_rows(h, n, "h")
+    grad_out = _check_rows(grad_out, n, "grad_out")
+    c = h.size(1)
+    grad_h = torch.empty_like(h)
+    ws = graph.workspace(c)
+    with torch.cuda.device(h.device):
+        rc = lib.sngnn_agg_backward(graph.handle, h.data_ptr(), c, grad_out.data_ptr(),
+                                    wsel.data_ptr(), inv.data_ptr(), grad_h.data_ptr(),
+                                    ws.data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_agg_backward")
+    return grad_h
+
+
+class _Aggregate(torch.autograd.Function):
+    """autograd seam of the fused aggregation.  The output is freshly allocated
+    and not saved, so the models' in-place ReLU on it is safe (models.py:81,206,298)."""
+
+    @staticmethod
+    def forward(ctx, h, graph, top_k, thr):
+        need_grad = h.requires_grad and torch.is_grad_enabled()
+        out, wsel, inv, _, _ = aggregate_forward(graph, h, top_k, thr,
+                                                 save_for_backward=need_grad)
+        if need_grad:
+            ctx.graph = graph
+            ctx.save_for_backward(h, wsel, inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h, wsel, inv = ctx.saved_tensors
+        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, inv)
+        return grad_h, None, None, None
+
+
+def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float) -> torch.Tensor:
+    """Differentiable fused aggregation: [N, C] -> [N, C]."""
+    return _Aggregate.apply(h, graph, top_k, thr)
+
+
+def adj_linear_forward(graph: Graph, wt: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    wt = _check_rows(wt, graph.num_nodes, "wt")
+    c = wt.size(1)
+    out0 = torch.empty_like(wt)
+    b = None if bias is None else bias.contiguous()
+    with torch.cuda.device(wt.device):
+        rc = lib.sngnn_adj_linear_forward(graph.handle, wt.data_ptr(), _lib.ptr(b), c,
+                                          out0.data_ptr(), _stream(wt.device))
+    _lib.check(rc, "sngnn_adj_linear_forward")
+    return out0
+
+
+def adj_linear_backward(graph: Graph, g0: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    g0 = _check_rows(g0, graph.num_nodes, "g0")
+    dwt = torch.empty_like(g0)
+    with torch.cuda.device(g0.device):
+        rc = lib.sngnn_adj_linear_backward(graph.handle, g0.data_ptr(), g0.size(1),
+                                           dwt.data_ptr(), _stream(g0.device))
+    _lib.check(rc, "sngnn_adj_linear_backward")
+    return dwt
+
+
+class _AdjLinear(torch.autograd.Function):
+    """``Linear(num_nodes, C)`` applied to the sparse adjacency (models.py:124-130).
+    ``weight`` is the reference-shaped [C, N] parameter stored column-major, i.e.
+    ``weight.t()`` is a contiguous [N, C] table whose rows are gathered."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, graph):
+        wt = weight.t()
+        if not wt.is_contiguous():
+            wt = wt.contiguous()
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        return adj_linear_forward(graph, wt, bias)
+
+    @staticmethod
+    def backward(ctx, g0):
+        g0 = g0.contiguous()
+        dwt = adj_linear_backward(ctx.graph, g0)
+        db = g0.sum(dim=0) if ctx.has_bias else None
+        return dwt.t(), db, None
+
+
+def adj_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], graph: Graph) -> torch.Tensor:
+    return _AdjLinear.apply(weight, bias, graph)
