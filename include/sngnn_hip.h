@@ -149,15 +149,17 @@ int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
  *   wt   dev f32 [N, C]  the TRANSPOSE of the reference's w.weight ([C, N]);
  *                        row d is W[:, d] so every gather is one contiguous row
  *   bias dev f32 [C] or NULL
+ *   workspace: sngnn_graph_workspace_bytes(g, C) bytes, as for the aggregation
  */
 int sngnn_adj_linear_forward(const sngnn_graph_t *g, const float *wt,
-                             const float *bias, int C, float *out0, void *stream);
+                             const float *bias, int C, float *out0,
+                             void *workspace, void *stream);
 /*
  * Gradient of the above w.r.t. wt:  dwt[d] = sum over in-edges e of d of
  * g0[src_e - src_min]  (dense [N, C], like the reference's dense w.weight.grad).
  */
 int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0, int C,
-                              float *dwt, void *stream);
+                              float *dwt, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
  * Sim-GFA toolbox (SimGFAToolbox/dense.py).

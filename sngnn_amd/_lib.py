@@ -33,8 +33,8 @@ SIGNATURES = {
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
     "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
-    "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_cosine_dense": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "sngnn_cosine_class_sums": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_edge_cosine": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),

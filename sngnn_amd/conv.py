@@ -1,0 +1,165 @@
+"""SNConv / SNConv_plus / SNConv_plus_plus with the reference's constructor
+signatures, parameter names and init order (models/models.py:305-334, 214-263,
+89-158), running the fused HIP aggregation instead of PyG's per-edge message
+passing.  ``forward(x, edge_index) -> [N, out_channels]`` as in the reference.
+
+What stays PyTorch: ``self.lin`` (one rocBLAS GEMM, models.py:121,237,324), the
+bias add and the scalar blend.  Everything between ``lin`` and the bias is one
+call into libsngnn_hip (plus one for the SNGNN++ adjacency branch).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.parameter import Parameter
+
+from . import ops
+from .graph import GLOBAL_CACHE
+
+
+def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remove_loops: bool):
+    if edge_index.device != x.device:
+        raise ValueError("x and edge_index must be on the same device")
+    return GLOBAL_CACHE.get(edge_index, x.size(0), add_loops, remove_loops)
+
+
+class SNConv(nn.Module):
+    """models.py:305-334: self-loops added (never removed), every in-edge weighted
+    by its cosine, mean over the full in-degree, ``bias=True`` by default."""
+
+    def __init__(self, in_channels, out_channels, aggr='mean', bias: bool = True):
+        super().__init__()
+        if aggr != 'mean':
+            raise ValueError("only aggr='mean' is implemented (the reference never uses another)")
+        self.lin = nn.Linear(in_channels, out_channels)
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:        # PyG inits.zeros(None) is a no-op
+            self.bias.data.fill_(0)
+
+    def forward(self, x, edge_index):
+        graph = _graph_for(x, edge_index, True, False)
+        h = self.lin(x)
+        out = ops.aggregate(h, graph, None, 0.0)
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+class SNConv_plus(nn.Module):
+    """models.py:214-263: per target keep the ``top_k`` highest-cosine in-edges that
+    also reach ``thr``; ``is_remove_self_loops`` drops ALL loops (added and original)."""
+
+    def __init__(self, in_channels, out_channels, num_nodes, top_k=2, thr=0.0,
+                 is_remove_self_loops=True, bias: bool = False, aggr='mean'):
+        super().__init__()
+        if aggr != 'mean':
+            raise ValueError("only aggr='mean' is implemented (the reference never uses another)")
+        self.top_k = top_k
+        self.thr = thr
+        self.num_nodes = num_nodes
+        self.is_remove_self_loops = is_remove_self_loops
+        self.lin = nn.Linear(in_channels, out_channels)
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+
+    def forward(self, x, edge_index):
+        graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
+        h = self.lin(x)
+        out = ops.aggregate(h, graph, int(self.top_k), float(self.thr))
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+
+class _AdjLinearParams(nn.Module):
+    """Holds ``w.weight`` [C, N] and ``w.bias`` [C] under the reference's names
+    (models.py:95).  The weight is stored column-major - ``weight.t()`` is a
+    contiguous [N, C] table - so the adjacency branch gathers whole rows; its
+    shape, ``state_dict`` key and initial values (same RNG stream as
+    ``nn.Linear(num_nodes, C).reset_parameters()``) are the reference's."""
+
+    def __init__(self, num_nodes: int, out_channels: int):
+        super().__init__()
+        self.in_features, self.out_features = num_nodes, out_channels
+        self.weight = Parameter(torch.empty(num_nodes, out_channels).t())
+        self.bias = Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        w = torch.empty(self.out_features, self.in_features, device=self.weight.device)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # nn.Linear.reset_parameters
+        with torch.no_grad():
+            self.weight.copy_(w)
+        bound = 1 / math.sqrt(self.in_features) if self.in_features > 0 else 0
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def _apply(self, fn, recurse=True):
+        # .to()/.cuda() would re-materialise the weight row-major; restore the layout
+        super()._apply(fn, recurse)
+        w = self.weight
+        if w.dim() == 2 and not w.t().is_contiguous():
+            with torch.no_grad():
+                fixed = w.data.t().contiguous().t()
+            self.weight = Parameter(fixed, requires_grad=w.requires_grad)
+        return self
+
+
+class SNConv_plus_plus(nn.Module):
+    """models.py:89-158: SNConv_plus blended with ``Linear(num_nodes, C)`` applied to
+    the sparse adjacency, ``out = beta * out_0 + (1 - beta) * out_1``."""
+
+    def __init__(self, in_channels, out_channels, num_nodes, top_k=2, thr=0.0, init_beta=0.5,
+                 is_remove_self_loops=True, bias: bool = False, aggr='mean'):
+        super().__init__()
+        if aggr != 'mean':
+            raise ValueError("only aggr='mean' is implemented (the reference never uses another)")
+        self.top_k = top_k
+        self.thr = thr
+        self.w = _AdjLinearParams(num_nodes, out_channels)
+        self.num_nodes = num_nodes
+        self.is_remove_self_loops = is_remove_self_loops
+        self.lin = nn.Linear(in_channels, out_channels)
+        self.beta = Parameter(torch.empty(1))
+        self.init_beta = init_beta
+        if bias:
+            self.bias = Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+        if self.bias is not None:
+            self.bias.data.fill_(0)
+        self.w.reset_parameters()
+        self.beta.data.fill_(self.init_beta)
+
+    def forward(self, x, edge_index):
+        if x.size(0) != self.num_nodes:
+            raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
+                             "(the adjacency branch is Linear(num_nodes, C))")
+        graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
+        h = self.lin(x)
+        out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
+        out_1 = ops.aggregate(h, graph, int(self.top_k), float(self.thr))
+        out = self.beta * out_0 + (1 - self.beta) * out_1
+        if self.bias is not None:
+            out = out + self.bias
+        return out

@@ -1,0 +1,60 @@
+// C-ABI entries of the SNGNN++ adjacency-linear branch (kernels: adj_linear_impl.h).
+#include "adj_linear_impl.h"
+#include "agg_fwd_impl.h"   // SNGNN_DISPATCH_GR
+
+using namespace sngnn;
+
+namespace sngnn {
+static int dispatch_adj(const RowCfg &cfg, const AdjArgs &a, hipStream_t st)
+{
+    switch (cfg.vec) {
+    case 1: SNGNN_DISPATCH_GR(launch_adj, 1, cfg, a, st)
+    case 2: SNGNN_DISPATCH_GR(launch_adj, 2, cfg, a, st)
+    default: SNGNN_DISPATCH_GR(launch_adj, 4, cfg, a, st)
+    }
+}
+}  // namespace sngnn
+
+extern "C" int sngnn_adj_linear_forward(const sngnn_graph_t *g, const float *wt, const float *bias,
+                                        int C, float *out0, void *workspace, void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(wt && out0, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(g->n_stasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    AdjArgs a;
+    a.table = wt; a.bias = bias; a.out = out0; a.partial = (float *)workspace;
+    a.C = C; a.N = (int)g->N;
+    a.ptr = g->cscptr; a.idx = g->csc_dst; a.perm = g->sperm;
+    a.seg_shift = (int)g->src_min;        // out row i <- CSC row i + src_min (models.py:125)
+    a.idx_shift = 0;
+    a.n_split = g->n_ssplit; a.n_med_end = g->srcs_gt(SMALL_T); a.n_tasks = g->n_stasks;
+    a.task_slot = g->stask_slot; a.task_chunk = g->stask_chunk; a.split_task0 = g->ssplit_task0;
+    a.nbA = a.nbB = 0;
+    return dispatch_adj(cfg, a, (hipStream_t)stream);
+}
+
+extern "C" int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0, int C, float *dwt,
+                                         void *workspace, void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(g0 && dwt, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(g->n_tasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    AdjArgs a;
+    a.table = g0; a.bias = nullptr; a.out = dwt; a.partial = (float *)workspace;
+    a.C = C; a.N = (int)g->N;
+    a.ptr = g->rowptr; a.idx = g->col; a.perm = g->rperm;
+    a.seg_shift = 0;
+    a.idx_shift = -(int)g->src_min;       // g0 row of source s is s - src_min
+    a.n_split = g->n_split; a.n_med_end = g->rows_gt(SMALL_T); a.n_tasks = g->n_tasks;
+    a.task_slot = g->task_slot; a.task_chunk = g->task_chunk; a.split_task0 = g->split_task0;
+    a.nbA = a.nbB = 0;
+    return dispatch_adj(cfg, a, (hipStream_t)stream);
+}

@@ -1,0 +1,45 @@
+// C-ABI entry of the aggregation backward (kernels: agg_bwd_impl.h).
+#include "agg_bwd_impl.h"
+
+using namespace sngnn;
+
+extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
+                                  const float *grad_out, const float *wsel,
+                                  const float *inv_norm, float *grad_h, void *workspace,
+                                  void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(h && grad_out && inv_norm && grad_h && workspace, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(wsel != nullptr || g->Ep == 0, SNGNN_EINVAL, "wsel is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    const uintptr_t al = (uintptr_t)cfg.vec * 4;
+    SN_REQUIRE((uintptr_t)h % al == 0 && (uintptr_t)grad_out % al == 0 && (uintptr_t)grad_h % al == 0,
+               SNGNN_EINVAL, "h/grad_out/grad_h must be aligned to the row vector width");
+    BwdArgs a;
+    a.h = h; a.gout = grad_out; a.wsel = wsel; a.inv = inv_norm;
+    a.C = C; a.N = (int)g->N;
+    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
+    a.cscptr = g->cscptr; a.csc_eid = g->csc_eid; a.csc_dst = g->csc_dst; a.sperm = g->sperm;
+    // workspace layout (sngnn_graph_workspace_bytes): ds | dnT | partT | partS
+    float *ws = (float *)workspace;
+    a.ds = ws;
+    const size_t ds_len = ((size_t)g->Ep + 3) / 4 * 4;      // keep rows 16-byte aligned
+    a.dnT = ws + ds_len;
+    a.partT = a.dnT + (size_t)g->N * C;
+    a.partS = a.partT + (size_t)g->n_tasks * C;
+    a.grad_h = grad_h;
+    a.n_split = g->n_split; a.n_med_end = g->rows_gt(SMALL_T); a.n_tasks = g->n_tasks;
+    a.task_slot = g->task_slot; a.task_chunk = g->task_chunk; a.split_task0 = g->split_task0;
+    a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
+    a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
+    a.nbA = a.nbB = 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (cfg.vec) {
+    case 1: return launch_agg_bwd_v1(cfg, a, st);
+    case 2: return launch_agg_bwd_v2(cfg, a, st);
+    default: return launch_agg_bwd_v4(cfg, a, st);
+    }
+}

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 }
 
 // split targets: dnT_i = sum of the tasks' partial rows, in task order
-__global__ void k_bwd_t_fin(const BwdArgs a)
+static __global__ void k_bwd_t_fin(const BwdArgs a)
 {
     const int p = blockIdx.x;
     const int i = a.rperm[p];

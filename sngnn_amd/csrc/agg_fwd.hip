@@ -40,7 +40,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk;
     a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
     a.scores = (float *)workspace;
-    a.partial = a.scores ? a.scores + g->split_edges : nullptr;
+    a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
     a.nbA = ceil_div(g->n_tasks, WAVES);
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
     const int max_split = g->n_split ? g->rdeg[0] : 0;

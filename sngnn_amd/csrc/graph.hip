@@ -329,12 +329,12 @@ int64_t sngnn_graph_src_min(const sngnn_graph_t *g) { return g ? g->src_min : -1
 int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {
     if (!g || C < 1) return -1;
-    // forward: scores of split rows + one partial row per split task
-    int64_t fwd = g->split_edges * 4 + (int64_t)g->n_tasks * C * 4;
-    // backward: d(cosine) per edge + target-side d(normalised row) per node
-    //           + one partial row per split-source task
-    int64_t bwd = g->Ep * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_stasks * C * 4 * 2 +
-                  (int64_t)g->n_tasks * C * 4;
+    // forward: scores of split rows | one partial row per split task
+    int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + (int64_t)g->n_tasks * C * 4;
+    // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
+    //           split-source task
+    int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_tasks * C * 4 +
+                  (int64_t)g->n_stasks * C * 4 * 2;
     int64_t b = std::max(fwd, bwd);
     return (b + 255) / 256 * 256;
 }

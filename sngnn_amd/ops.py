@@ -84,7 +84,7 @@ class _Aggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, graph, top_k, thr):
-        need_grad = h.requires_grad and torch.is_grad_enabled()
+        need_grad = ctx.needs_input_grad[0]
         out, wsel, inv, _, _ = aggregate_forward(graph, h, top_k, thr,
                                                  save_for_backward=need_grad)
         if need_grad:
@@ -112,7 +112,8 @@ def adj_linear_forward(graph: Graph, wt: torch.Tensor, bias: Optional[torch.Tens
     b = None if bias is None else bias.contiguous()
     with torch.cuda.device(wt.device):
         rc = lib.sngnn_adj_linear_forward(graph.handle, wt.data_ptr(), _lib.ptr(b), c,
-                                          out0.data_ptr(), _stream(wt.device))
+                                          out0.data_ptr(), graph.workspace(c).data_ptr(),
+                                          _stream(wt.device))
     _lib.check(rc, "sngnn_adj_linear_forward")
     return out0
 
@@ -123,7 +124,8 @@ def adj_linear_backward(graph: Graph, g0: torch.Tensor) -> torch.Tensor:
     dwt = torch.empty_like(g0)
     with torch.cuda.device(g0.device):
         rc = lib.sngnn_adj_linear_backward(graph.handle, g0.data_ptr(), g0.size(1),
-                                           dwt.data_ptr(), _stream(g0.device))
+                                           dwt.data_ptr(), graph.workspace(g0.size(1)).data_ptr(),
+                                           _stream(g0.device))
     _lib.check(rc, "sngnn_adj_linear_backward")
     return dwt
 

@@ -1,0 +1,116 @@
+"""GPU parity of the aggregation backward and of the SNGNN++ adjacency branch."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sngnn_oracle as O
+from tests.helpers import assert_close, random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+# gradients are sums with cancellation (the F.normalize projection): compare
+# against the magnitude of the gradient, not element by element
+def assert_grad_close(got, want, what, rel=2e-5):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    scale = want.abs().max().clamp_min(1e-30)
+    err = (got - want).abs().max()
+    assert err <= rel * scale, f"{what}: max err {err.item():.3e} vs scale {scale.item():.3e}"
+
+
+CASES = [
+    (64, 300, 5, (), True, 1, 0.0),
+    (64, 300, 7, (), False, None, 0.0),
+    (200, 1500, 40, (), True, 16, 0.0),
+    (200, 1500, 47, ((3, 90), (7, 150)), True, 6, 0.1),
+    (500, 4000, 64, ((0, 499), (9, 300)), True, 3, -0.2),
+    (500, 4000, 6, ((0, 499),), False, None, 0.0),
+    (400, 3000, 128, ((2, 350),), True, 8, 0.0),
+    (300, 2000, 129, (), False, 20, -1.5),
+    (300, 2000, 300, ((4, 200),), True, 5, 0.0),
+    (1500, 20000, 40, ((0, 1499), (1, 900)), True, 16, 0.0),
+]
+
+
+@pytest.mark.parametrize("n,e,C,hubs,rem,k,thr", CASES)
+def test_backward_matches_autograd_of_oracle(cuda, n, e, C, hubs, rem, k, thr):
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    ei = random_graph(n, e, seed=n + e + C, hubs=hubs)
+    # hub SOURCES as well (out-degree skew exercises the split-source path)
+    ei = torch.cat([ei, torch.stack([torch.full((n // 2,), 3), torch.arange(n // 2) * 2 + 1])], 1)
+    ei = torch.unique(ei, dim=1)
+    gen = torch.Generator().manual_seed(C + n)
+    h = torch.randn(n, C, generator=gen)
+    h[5] = h[6]
+    gout = torch.randn(n, C, generator=gen)
+
+    h_ref = h.clone().requires_grad_(True)
+    ref = O.aggregate_reference(h_ref, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+    (ref["out"] * gout).sum().backward()
+
+    g = Graph(ei.to(cuda), n, True, rem)
+    h_gpu = h.to(cuda).requires_grad_(True)
+    out = ops.aggregate(h_gpu, g, k, thr)
+    (out * gout.to(cuda)).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(out, ref["out"])
+    assert_grad_close(h_gpu.grad, h_ref.grad, "grad_h")
+    # deterministic: a second run gives the same bits
+    h2 = h.to(cuda).requires_grad_(True)
+    (ops.aggregate(h2, g, k, thr) * gout.to(cuda)).sum().backward()
+    assert torch.equal(h2.grad, h_gpu.grad)
+
+
+def test_eps_clamped_rows(cuda):
+    """Rows below F.normalize's eps: n = h / eps, no projection in the Jacobian."""
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    n, C = 40, 8
+    ei = random_graph(n, 200, seed=5)
+    h = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    h[3] = 0.0
+    h[4] = 1e-14
+    gout = torch.randn(n, C, generator=torch.Generator().manual_seed(3))
+    h_ref = h.clone().requires_grad_(True)
+    ref = O.aggregate_reference(h_ref, ei, add_loops=True, remove_loops=False, top_k=None)
+    (ref["out"] * gout).sum().backward()
+    g = Graph(ei.to(cuda), n, True, False)
+    h_gpu = h.to(cuda).requires_grad_(True)
+    (ops.aggregate(h_gpu, g, None, 0.0) * gout.to(cuda)).sum().backward()
+    assert_grad_close(h_gpu.grad, h_ref.grad, "grad_h (eps rows)", rel=1e-4)
+
+
+@pytest.mark.parametrize("n,e,C,hubs,src_min", [(120, 900, 5, ((1, 100),), 0),
+                                                 (300, 3000, 47, ((0, 299), (2, 150)), 0),
+                                                 (300, 3000, 40, ((5, 200),), 3),
+                                                 (200, 1500, 130, (), 0)])
+def test_adj_linear_branch(cuda, n, e, C, hubs, src_min):
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    ei = random_graph(n, e, seed=n + C, hubs=hubs)
+    ei = torch.cat([ei, torch.stack([torch.full((n // 2,), 7), torch.arange(n // 2)])], 1)
+    ei = torch.unique(ei, dim=1)
+    if src_min:
+        ei = ei[:, ei[0] >= src_min]          # no edge leaves nodes < src_min
+    gen = torch.Generator().manual_seed(n)
+    W = torch.randn(C, n, generator=gen)
+    b = torch.randn(C, generator=gen)
+    gout = torch.randn(n, C, generator=gen)
+    ei_p = O.sn_edge_list(ei, n, True, True)
+    assert int(ei_p[0].min()) == src_min
+
+    W_ref, b_ref = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out_ref = O.adj_linear_reference(W_ref, b_ref, ei_p, n)
+    (out_ref * gout).sum().backward()
+
+    g = Graph(ei.to(cuda), n, True, True)
+    assert g.src_min == src_min
+    Wg = torch.nn.Parameter(W.t().contiguous().to(cuda).t())     # column-major [C, n]
+    bg = b.to(cuda).requires_grad_(True)
+    out = ops.adj_linear(Wg, bg, g)
+    (out * gout.to(cuda)).sum().backward()
+    assert_close(out, out_ref, what="out_0", rtol=1e-5, atol=1e-5)
+    assert_grad_close(Wg.grad, W_ref.grad.to_dense() if W_ref.grad.is_sparse else W_ref.grad,
+                      "dW")
+    assert_grad_close(bg.grad, b_ref.grad, "db")
