@@ -73,9 +73,24 @@ typedef struct sngnn_graph sngnn_graph_t;
 int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N,
                        int add_loops, int remove_loops, void *stream,
                        sngnn_graph_t **out_graph);
+/*
+ * Node-range partition of a larger graph (one process per GPU): this graph owns
+ * the target rows [row_begin, row_end) of an N_total-node graph.  edge_index
+ * holds GLOBAL node ids; edges whose target lies outside the owned range are
+ * dropped, self-loops are appended for the owned nodes only.  Feature tables
+ * handed to forward/backward then have N_total rows (the all-gathered h), the
+ * outputs row_end - row_begin rows.  The reference has no counterpart (it is
+ * single-device); with row range [0, N) this is sngnn_graph_create.
+ */
+int sngnn_graph_create_partition(const int64_t *edge_index_dev, int64_t E,
+                                 int64_t N_total, int64_t row_begin,
+                                 int64_t row_end, int add_loops, int remove_loops,
+                                 void *stream, sngnn_graph_t **out_graph);
 void sngnn_graph_destroy(sngnn_graph_t *g);
 
-int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g);
+int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g);       /* owned target rows */
+int64_t sngnn_graph_num_total_nodes(const sngnn_graph_t *g); /* N_total            */
+int64_t sngnn_graph_row_offset(const sngnn_graph_t *g);      /* row_begin          */
 int64_t sngnn_graph_num_edges(const sngnn_graph_t *g);      /* E' */
 int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g);
 int64_t sngnn_graph_src_min(const sngnn_graph_t *g);         /* models.py:125 */
@@ -86,7 +101,7 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C);
  *   which: 0 rowptr   int32 [N+1]   CSR by target
  *          1 col      int32 [E']    source id of each CSR edge
  *          2 eid      int32 [E']    position of the CSR edge in the E' edge list
- *          3 cscptr   int32 [N+1]   CSC by source
+ *          3 cscptr   int32 [N_total+1]  CSC by source
  *          4 csc_eid  int32 [E']    CSR edge index of each CSC entry
  *          5 rperm    int32 [N]     rows sorted by in-degree, descending (stable)
  */
@@ -104,7 +119,8 @@ const void *sngnn_graph_array_dev(const sngnn_graph_t *g, int which);
  * PyG propagate's four index_select gathers, torch_scatter.scatter_max (x top_k
  * rounds) and torch_scatter.scatter(reduce='mean').
  *
- *   h        dev f32 [N, C]   output of self.lin (NOT normalised)
+ *   h        dev f32 [N_total, C]  output of self.lin (NOT normalised); N_total == N
+ *                             unless the graph is a partition
  *   top_k    < 0: SNConv - every edge weighted by its cosine, no selection
  *            >= 0: keep, per target, the top_k in-edges by (cosine descending,
  *            edge position ascending) and of those only the ones with
@@ -129,15 +145,25 @@ int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
  * Replaces: autograd through the op list above (triggered at train.py:86).
  * Deterministic: no floating-point atomics; every sum has a fixed order.
  *
- *   grad_out dev f32 [N, C]   dL/d out
- *   wsel, inv_norm            as written by sngnn_agg_forward on the same h
- *   grad_h   dev f32 [N, C]   dL/d h through all three routes (message value,
- *                             norm_i, norm_j) and F.normalize's Jacobian
+ *   grad_out dev f32 [N, C]        dL/d out
+ *   wsel                           as written by sngnn_agg_forward on the same h
+ *   grad_h   dev f32 [N_total, C]  dL/d h through all three routes (message
+ *                             value, norm_i, norm_j) and F.normalize's Jacobian.
+ *                             For a partition this is the rank's PARTIAL gradient
+ *                             (sum over ranks = reduce-scatter gives the total).
  */
 int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
-                       const float *grad_out, const float *wsel,
-                       const float *inv_norm, float *grad_h, void *workspace,
-                       void *stream);
+                       const float *grad_out, const float *wsel, float *grad_h,
+                       void *workspace, void *stream);
+
+/*
+ * Measurement aid (no reference counterpart): while enabled, sngnn_agg_forward
+ * records HIP events on the caller's stream around its launches;
+ * sngnn_profile_last_forward waits for the last call and returns the device
+ * time of the main kernel and of the split-row finalize kernel (ms).
+ */
+int sngnn_profile_enable(int on);
+int sngnn_profile_last_forward(float *main_ms, float *fin_ms);
 
 /* ------------------------------------------------------------------------
  * SNGNN++ adjacency-linear branch and blend.

@@ -23,8 +23,12 @@ SIGNATURES = {
     "sngnn_last_error": (C.c_char_p, []),
     "sngnn_build_info": (C.c_char_p, []),
     "sngnn_graph_create": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(_vp)]),
+    "sngnn_graph_create_partition": (_i32, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp,
+                                            C.POINTER(_vp)]),
     "sngnn_graph_destroy": (None, [_vp]),
     "sngnn_graph_num_nodes": (_i64, [_vp]),
+    "sngnn_graph_num_total_nodes": (_i64, [_vp]),
+    "sngnn_graph_row_offset": (_i64, [_vp]),
     "sngnn_graph_num_edges": (_i64, [_vp]),
     "sngnn_graph_max_in_degree": (_i64, [_vp]),
     "sngnn_graph_src_min": (_i64, [_vp]),
@@ -32,7 +36,9 @@ SIGNATURES = {
     "sngnn_graph_copy_array": (_i32, [_vp, _i32, _vp]),
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
     "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_profile_enable": (_i32, [_i32]),
+    "sngnn_profile_last_forward": (_i32, [C.POINTER(_f32), C.POINTER(_f32)]),
     "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_cosine_dense": (_i32, [_vp, _i64, _i64, _vp, _vp]),

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 from torch.nn.parameter import Parameter
 
+from . import dist as sn_dist
 from . import ops
 from .graph import GLOBAL_CACHE
 
@@ -22,7 +23,20 @@ from .graph import GLOBAL_CACHE
 def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remove_loops: bool):
     if edge_index.device != x.device:
         raise ValueError("x and edge_index must be on the same device")
-    return GLOBAL_CACHE.get(edge_index, x.size(0), add_loops, remove_loops)
+    part = sn_dist.current_partition()
+    if part is None:
+        return GLOBAL_CACHE.get(edge_index, x.size(0), add_loops, remove_loops)
+    return GLOBAL_CACHE.get(edge_index, part.n_total, add_loops, remove_loops,
+                            row_range=(part.row_begin, part.row_end))
+
+
+def _aggregate(h: torch.Tensor, graph, top_k, thr: float) -> torch.Tensor:
+    """Fused aggregation of the local rows; under a node-range partition the
+    feature shards are all-gathered first (RCCL), see sngnn_amd/dist.py."""
+    part = sn_dist.current_partition()
+    if part is not None:
+        h = sn_dist.all_gather_rows(h, part)
+    return ops.aggregate(h, graph, top_k, thr)
 
 
 class SNConv(nn.Module):
@@ -48,7 +62,7 @@ class SNConv(nn.Module):
     def forward(self, x, edge_index):
         graph = _graph_for(x, edge_index, True, False)
         h = self.lin(x)
-        out = ops.aggregate(h, graph, None, 0.0)
+        out = _aggregate(h, graph, None, 0.0)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -82,7 +96,7 @@ class SNConv_plus(nn.Module):
     def forward(self, x, edge_index):
         graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h = self.lin(x)
-        out = ops.aggregate(h, graph, int(self.top_k), float(self.thr))
+        out = _aggregate(h, graph, int(self.top_k), float(self.thr))
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -155,6 +169,9 @@ class SNConv_plus_plus(nn.Module):
         if x.size(0) != self.num_nodes:
             raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
                              "(the adjacency branch is Linear(num_nodes, C))")
+        if sn_dist.current_partition() is not None:
+            raise NotImplementedError("SNConv_plus_plus is single-GPU for now: the adjacency "
+                                      "branch needs the edges partitioned by source as well")
         graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h = self.lin(x)
         out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)

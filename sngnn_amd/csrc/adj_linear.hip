@@ -19,6 +19,7 @@ extern "C" int sngnn_adj_linear_forward(const sngnn_graph_t *g, const float *wt,
                                         int C, float *out0, void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    SN_REQUIRE(g->N == g->Ntot, SNGNN_EINVAL, "the adjacency branch needs an unpartitioned graph");
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(wt && out0, SNGNN_EINVAL, "NULL argument");
     SN_REQUIRE(g->n_stasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");
@@ -41,6 +42,7 @@ extern "C" int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0
                                          void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    SN_REQUIRE(g->N == g->Ntot, SNGNN_EINVAL, "the adjacency branch needs an unpartitioned graph");
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(g0 && dwt, SNGNN_EINVAL, "NULL argument");
     SN_REQUIRE(g->n_tasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");

@@ -4,13 +4,12 @@
 using namespace sngnn;
 
 extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
-                                  const float *grad_out, const float *wsel,
-                                  const float *inv_norm, float *grad_h, void *workspace,
-                                  void *stream)
+                                  const float *grad_out, const float *wsel, float *grad_h,
+                                  void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
-    if (g->N == 0) return SNGNN_OK;
-    SN_REQUIRE(h && grad_out && inv_norm && grad_h && workspace, SNGNN_EINVAL, "NULL argument");
+    if (g->Ntot == 0) return SNGNN_OK;
+    SN_REQUIRE(h && grad_h && workspace && (grad_out || g->N == 0), SNGNN_EINVAL, "NULL argument");
     SN_REQUIRE(wsel != nullptr || g->Ep == 0, SNGNN_EINVAL, "wsel is NULL");
     RowCfg cfg;
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
@@ -19,8 +18,8 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     SN_REQUIRE((uintptr_t)h % al == 0 && (uintptr_t)grad_out % al == 0 && (uintptr_t)grad_h % al == 0,
                SNGNN_EINVAL, "h/grad_out/grad_h must be aligned to the row vector width");
     BwdArgs a;
-    a.h = h; a.gout = grad_out; a.wsel = wsel; a.inv = inv_norm;
-    a.C = C; a.N = (int)g->N;
+    a.h = h; a.gout = grad_out; a.wsel = wsel;
+    a.C = C; a.N = (int)g->N; a.Ntot = (int)g->Ntot; a.row_off = (int)g->row_off;
     a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
     a.cscptr = g->cscptr; a.csc_eid = g->csc_eid; a.csc_dst = g->csc_dst; a.sperm = g->sperm;
     // workspace layout (sngnn_graph_workspace_bytes): ds | dnT | partT | partS

@@ -23,8 +23,8 @@
 namespace sngnn {
 
 struct BwdArgs {
-    const float *h, *gout, *wsel, *inv;
-    int C, N;
+    const float *h, *gout, *wsel;
+    int C, N, Ntot, row_off;      // N owned target rows; Ntot sources / rows of h, grad_h
     const int32_t *rowptr, *col, *rperm;
     const int32_t *cscptr, *csc_eid, *csc_dst, *sperm;
     float *ds, *dnT, *grad_h;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void t_edge(const BwdArgs &a, int e, const Row<VEC, G
     Row<VEC, G, R> x;
     const int j = a.col[e];
     x.load(a.h + (size_t)j * a.C, a.C, lg);
-    const float invj = a.inv[j];
+    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
     const float d = group_sum<G>(gp.dot_partial(x));
     if (lg == 0) a.ds[e] = d;
     fma_row<VEC, G, R>(acc, d * invj, x);
@@ -171,14 +171,15 @@ __device__ __forceinline__ void s_edge(const BwdArgs &a, int q, float w, int lg,
                                        Row<VEC, G, R> &msg, Row<VEC, G, R> &dns)
 {
     Row<VEC, G, R> x, gi;
-    const int i = a.csc_dst[q];
+    const int i = a.csc_dst[q];               // local target row
     const int e = a.csc_eid[q];
     const int deg = a.rowptr[i + 1] - a.rowptr[i];
-    x.load(a.h + (size_t)i * a.C, a.C, lg);
+    x.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     gi.load(a.gout + (size_t)i * a.C, a.C, lg);
     gi.div((float)deg);
+    const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
     fma_row<VEC, G, R>(msg, w, gi);
-    fma_row<VEC, G, R>(dns, a.ds[e] * a.inv[i], x);
+    fma_row<VEC, G, R>(dns, a.ds[e] * invi, x);
 }
 
 // dh_v from msg_v and dn_v = dnT_v + dnS_v
@@ -187,10 +188,13 @@ __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VE
                                          Row<VEC, G, R> &dn)
 {
     Row<VEC, G, R> t, hv;
-    t.load(a.dnT + (size_t)v * a.C, a.C, lg);
-    dn.add(t);
+    const int vl = v - a.row_off;                 // owned nodes also carry a target part
+    if (vl >= 0 && vl < a.N) {
+        t.load(a.dnT + (size_t)vl * a.C, a.C, lg);
+        dn.add(t);
+    }
     hv.load(a.h + (size_t)v * a.C, a.C, lg);
-    const float invv = a.inv[v];
+    const float invv = inv_norm_of(group_sum<G>(hv.dot_partial(hv)));
     hv.scale(invv);                               // n_v
     float proj = group_sum<G>(hv.dot_partial(dn));
     if (invv == 1.0f / EPS_NORM) proj = 0.f;      // eps clamp active: n = h / eps
@@ -210,7 +214,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int gid = lane / G, lg = lane % G;
     const int slot = a.n_smed_end + (blk * WAVES + wave) * RPW + gid;
-    if (slot >= a.N) return;
+    if (slot >= a.Ntot) return;
     const int v = a.sperm[slot];
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
@@ -324,7 +328,7 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
     // pass S (sources)
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
-    nbC = ceil_div(a.N - a.n_smed_end, (int64_t)WAVES * RPW);
+    nbC = ceil_div(a.Ntot - a.n_smed_end, (int64_t)WAVES * RPW);
     if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
     if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
     SN_HIP(hipGetLastError());

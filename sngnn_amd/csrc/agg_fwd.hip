@@ -3,6 +3,28 @@
 
 using namespace sngnn;
 
+// Optional in-library timing of the forward's launches (bench.py's roofline leg):
+// HIP events recorded on the caller's stream around each launch.
+static bool g_prof_on = false;
+static hipEvent_t g_prof_ev[3] = {nullptr, nullptr, nullptr};
+
+extern "C" int sngnn_profile_enable(int on)
+{
+    if (on && !g_prof_ev[0])
+        for (auto &e : g_prof_ev) SN_HIP(hipEventCreate(&e));
+    g_prof_on = on != 0;
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_profile_last_forward(float *main_ms, float *fin_ms)
+{
+    SN_REQUIRE(g_prof_ev[0] != nullptr && main_ms && fin_ms, SNGNN_EINVAL, "profiling is not enabled");
+    SN_HIP(hipEventSynchronize(g_prof_ev[2]));
+    SN_HIP(hipEventElapsedTime(main_ms, g_prof_ev[0], g_prof_ev[1]));
+    SN_HIP(hipEventElapsedTime(fin_ms, g_prof_ev[1], g_prof_ev[2]));
+    return SNGNN_OK;
+}
+
 extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
                                  float thr, float *out, float *wsel, float *inv_norm,
                                  int32_t *sel_src, float *sel_w, void *workspace, void *stream)
@@ -29,7 +51,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     }
 
     FwdArgs a;
-    a.h = h; a.C = C; a.N = (int)g->N;
+    a.h = h; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
     a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
@@ -41,12 +63,17 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
     a.scores = (float *)workspace;
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
+    a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)
+                           : nullptr;
+    a.lowbits = 1;
+    while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     a.nbA = ceil_div(g->n_tasks, WAVES);
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
     const int max_split = g->n_split ? g->rdeg[0] : 0;
+    hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
     switch (cfg.vec) {
-    case 1: return launch_agg_fwd_v1(cfg, a, max_split, st);
-    case 2: return launch_agg_fwd_v2(cfg, a, max_split, st);
-    default: return launch_agg_fwd_v4(cfg, a, max_split, st);
+    case 1: return launch_agg_fwd_v1(cfg, a, max_split, ev, st);
+    case 2: return launch_agg_fwd_v2(cfg, a, max_split, ev, st);
+    default: return launch_agg_fwd_v4(cfg, a, max_split, ev, st);
     }
 }

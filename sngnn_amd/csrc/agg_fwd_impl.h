@@ -28,7 +28,8 @@ namespace sngnn {
 
 struct FwdArgs {
     const float *h;
-    int C, N;
+    int C, N;         // N = owned target rows
+    int row_off;      // row i's own feature row is h[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
     int k;            // < 0: no selection
     float thr;
@@ -39,6 +40,8 @@ struct FwdArgs {
     int n_tasks;
     const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
     float *scores, *partial;    // workspace
+    unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
+    int lowbits;                    // bits needed for a row-local edge index
     int nbA, nbB;               // blocks of class A and B; the rest are class C
 };
 
@@ -57,47 +60,64 @@ __device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i
 }
 
 // ---------------------------------------------------------------------------
-// Wave-level top-k over up to 128 scores held in LDS (2 per lane).
-// Returns the number of kept edges; list[] receives their row-local indices in
-// ascending order; sc[idx] keeps the score, flag via return of `kept` per lane.
+// Wave-level top-k of up to 128 selection keys, two per lane (0 = no key).
+// Keys are unique, so "the k largest" is well defined: bitwise search for the
+// k-th largest key T, then keep key >= T.  lowbits = bits of the largest
+// row-local edge index (the low word of a key is 0xFFFFFFFF - index, so its
+// upper 32 - lowbits bits are all ones and need no search).
 // ---------------------------------------------------------------------------
-struct WaveSel {
-    bool kept0, kept1;
-    unsigned long long key0, key1;
-    int nsel;
-};
+constexpr int CAND_MAX_K = 32;   // split rows: chunk-local candidates are kept for k <= this
 
-__device__ __forceinline__ WaveSel wave_select(const float *sc, int deg, int k, float thr)
+__device__ __forceinline__ void wave_topk_keys(unsigned long long key0, unsigned long long key1,
+                                               int k, int lowbits, bool &kept0, bool &kept1)
 {
-    const int lane = lane_id();
-    const int i0 = lane, i1 = lane + 64;
-    const bool v0 = i0 < deg, v1 = i1 < deg;
-    const float s0 = v0 ? sc[i0] : 0.f, s1 = v1 ? sc[i1] : 0.f;
-    WaveSel r;
-    r.key0 = v0 ? sel_key(s0, i0) : 0ull;
-    r.key1 = v1 ? sel_key(s1, i1) : 0ull;
-    const bool p0 = v0 && s0 >= thr, p1 = v1 && s1 >= thr;
-    const int cnt_thr = __popcll(__ballot(p0)) + __popcll(__ballot(p1));
-    if (cnt_thr <= k) {            // the threshold alone decides
-        r.kept0 = p0; r.kept1 = p1; r.nsel = cnt_thr;
-        return r;
-    }
-    // k-th largest key by bitwise search (keys are unique)
+    const bool v0 = key0 != 0ull, v1 = key1 != 0ull;
+    const int cnt = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+    if (cnt <= k) { kept0 = v0; kept1 = v1; return; }     // everything that passed thr fits
     unsigned long long T = 0;
     for (int b = 63; b >= 32; --b) {
         const unsigned long long cand = T | (1ull << b);
-        const int c = __popcll(__ballot(r.key0 >= cand)) + __popcll(__ballot(r.key1 >= cand));
+        const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
         if (c >= k) T = cand;
     }
-    T |= 0xFFFFFF80ull;            // positions < 128: the upper 25 low-word bits are all ones
-    for (int b = 6; b >= 0; --b) {
+    T |= 0xFFFFFFFFull & ~((1ull << lowbits) - 1ull);
+    for (int b = lowbits - 1; b >= 0; --b) {
         const unsigned long long cand = T | (1ull << b);
-        const int c = __popcll(__ballot(r.key0 >= cand)) + __popcll(__ballot(r.key1 >= cand));
+        const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
         if (c >= k) T = cand;
     }
-    r.kept0 = v0 && r.key0 >= T;
-    r.kept1 = v1 && r.key1 >= T;
-    r.nsel = k;
+    kept0 = key0 >= T;      // T > 0 here, so empty slots (key 0) stay out
+    kept1 = key1 >= T;
+}
+
+__device__ __forceinline__ float key_score(unsigned long long key)
+{
+    const unsigned u = (unsigned)(key >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ int key_index(unsigned long long key)
+{
+    return (int)(0xFFFFFFFFu - (unsigned)key);
+}
+
+// Top-k (and >= thr) of the scores sc[0, n) of one wave's edges; edge t of the
+// wave has row-local index base + t.  An edge below thr gets no key at all:
+// "top-k, then drop < thr" == "drop < thr, then top-k" because the order is by score.
+struct WaveSel {
+    bool kept0, kept1;
+    unsigned long long key0, key1;
+};
+
+__device__ __forceinline__ WaveSel wave_select(const float *sc, int n, int base, int k, float thr,
+                                               int lowbits)
+{
+    const int lane = lane_id();
+    const int i0 = lane, i1 = lane + 64;
+    const float s0 = i0 < n ? sc[i0] : 0.f, s1 = i1 < n ? sc[i1] : 0.f;
+    WaveSel r;
+    r.key0 = (i0 < n && s0 >= thr) ? sel_key(s0, base + i0) : 0ull;
+    r.key1 = (i1 < n && s1 >= thr) ? sel_key(s1, base + i1) : 0ull;
+    wave_topk_keys(r.key0, r.key1, k, lowbits, r.kept0, r.kept1);
     return r;
 }
 
@@ -130,7 +150,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
     wave_lds_sync();
 
     RowT hi;
-    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
     if (valid && lg == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
 
@@ -144,7 +164,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             act[u] = (t0 + u) < deg;
-            j[u] = act[u] ? s_col[t0 + u] : i;
+            j[u] = act[u] ? s_col[t0 + u] : i + a.row_off;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
@@ -205,12 +225,14 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
 // Scoring pass shared by classes A and B: the wave's 64/G groups stride over
 // the edges [e0, e1) of row i (row-local indices).
 //   STREAM: accumulate kept rows into acc (threshold only) and write wsel
-//   sc_out: where to put the scores (LDS or HBM scratch), or nullptr
+//   sc_out: where to put the scores (LDS or HBM scratch), or nullptr; edge t goes to
+//           sc_out[t - sc_off]  (never form an out-of-range LDS pointer: LDS pointer
+//           arithmetic is 32-bit and does not survive the cast to a flat address)
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
 __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int e0, int e1,
                                             const Row<VEC, G, R> &hi, float inv_i, bool stream,
-                                            float *sc_out, Row<VEC, G, R> &acc)
+                                            float *sc_out, int sc_off, Row<VEC, G, R> &acc)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
@@ -225,7 +247,7 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
         for (int u = 0; u < U; ++u) {
             t[u] = base + u * NG + gid;
             act[u] = t[u] < e1;
-            j[u] = act[u] ? a.col[rs + t[u]] : i;
+            j[u] = act[u] ? a.col[rs + t[u]] : i + a.row_off;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
@@ -233,7 +255,7 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
         for (int u = 0; u < U; ++u) {
             const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
             if (act[u]) {
-                if (sc_out && lg == 0) sc_out[t[u]] = s;
+                if (sc_out && lg == 0) sc_out[t[u] - sc_off] = s;
                 if (stream) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
                     if (sel) acc.axpy(s, x[u]);
@@ -267,17 +289,17 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int blk, int *lds_wa
     int *s_list = lds_wave + WAVE_T;                         // [WAVE_T]
 
     RowT hi;
-    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
     if (lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
 
     RowT acc;
     acc.zero();
-    score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, acc);
+    score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc);
 
     if (need_sc) {
         wave_lds_sync();
-        const WaveSel ws = wave_select(s_sc, deg, a.k, a.thr);
+        const WaveSel ws = wave_select(s_sc, deg, 0, a.k, a.thr, 7);
         const int i0 = lane, i1 = lane + 64;
         // kept list in ascending position order
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
@@ -325,7 +347,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int blk, int *lds_wa
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_task(const FwdArgs &a, int blk)
+__device__ __forceinline__ void role_task(const FwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -339,17 +361,32 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int blk)
     const int e0 = c * CHUNK, e1 = min(deg, e0 + CHUNK);
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
+    const bool cand = rank && a.k <= CAND_MAX_K;        // chunk-local top-k -> candidates
 
     RowT hi;
-    hi.load(a.h + (size_t)i * a.C, a.C, lg);
+    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
     if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
 
     RowT acc;
     acc.zero();
-    float *sc = (rank || emit) ? a.scores + a.split_soff[p] : nullptr;
-    score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, acc);
-    if (!rank) {
+    float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
+    float *sc = cand ? s_sc : ((rank || emit) ? a.scores + a.split_soff[p] : nullptr);
+    score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, cand ? e0 : 0, acc);
+    if (cand) {
+        wave_lds_sync();
+        const WaveSel ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
+        unsigned long long *ck = a.cand_key + (size_t)tq * a.k;
+        const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
+        const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
+        if (ws.kept0) ck[prefix_popc(m0)] = ws.key0;
+        if (ws.kept1) ck[n0 + prefix_popc(m1)] = ws.key1;
+        if (lane >= nsel && lane < a.k) ck[lane] = 0ull;        // empty slots (k <= 32 < 64)
+        if (a.wsel) {     // the finalize overwrites the kept edges of the row
+            if (e0 + lane < e1) a.wsel[rs + e0 + lane] = SNGNN_UNSELECTED;
+            if (e0 + 64 + lane < e1) a.wsel[rs + e0 + 64 + lane] = SNGNN_UNSELECTED;
+        }
+    } else if (!rank) {
         acc.reduce_across_groups();
         if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
     }
@@ -361,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fwd(const FwdArgs a)
     __shared__ int lds[WAVES][LDS_PER_WAVE];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
-    if (b < a.nbA) role_task<VEC, G, R>(a, b);
+    if (b < a.nbA) role_task<VEC, G, R>(a, b, lw);
     else if (b < a.nbA + a.nbB) role_wave<VEC, G, R>(a, b - a.nbA, lw);
     else role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
 }
@@ -519,14 +556,146 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
     (void)kk;
 }
 
-template <int VEC, int G, int R> int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipStream_t st)
+// ---------------------------------------------------------------------------
+// Finalize of split rows from chunk-local candidates (top_k <= CAND_MAX_K):
+// one 256-thread workgroup per row merges the tasks' candidate keys 128 at a
+// time (tournament of wave-level top-k) and gathers the <= k winners.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int p = blockIdx.x;
+    const int i = a.rperm[p];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const bool emit = a.sel_src != nullptr && a.k >= 0;
+    const bool rank = a.k >= 0 && deg > a.k;
+
+    // dynamic LDS: [WAVES * C] partial rows | keysA [max_slots] | keysB [max_slots]
+    float *s_part = reinterpret_cast<float *>(dyn);
+    unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)WAVES * a.C + ((WAVES * a.C) & 1));
+    unsigned long long *kB = kA + max_slots;
+    int &s_n = *reinterpret_cast<int *>(kB + max_slots);
+
+    if (!rank) {
+        // streaming row (deg <= top_k or no selection): add the tasks' partial rows
+        for (int c = tid; c < a.C; c += BLOCK) {
+            float s = 0.f;
+            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+            a.out[(size_t)i * a.C + c] = s / (float)deg;
+        }
+        if (emit) {
+            // selection of a streaming split row: every edge >= thr, ranked.  Rare
+            // (needs top_k >= deg > WAVE_T); done by plain counting from the scratch scores.
+            const float *sc = a.scores + a.split_soff[p];
+            for (int e = tid; e < deg; e += BLOCK) {
+                const float se = sc[e];
+                if (!(se >= a.thr)) continue;
+                int rk = 0;
+                for (int b = 0; b < deg; ++b) rk += (sc[b] > se) || (sc[b] == se && b < e);
+                a.sel_src[(size_t)i * a.k + rk] = a.col[rs + e];
+                a.sel_w[(size_t)i * a.k + rk] = se;
+            }
+        }
+        return;
+    }
+
+    int n = (t1 - t0) * a.k;
+    for (int q = tid; q < n; q += BLOCK) kA[q] = a.cand_key[(size_t)t0 * a.k + q];
+    __syncthreads();
+    while (n > 128) {
+        const int groups = (n + 127) / 128;
+        for (int g = wave; g < groups; g += WAVES) {
+            const int q0 = g * 128 + lane, q1 = q0 + 64;
+            const unsigned long long key0 = q0 < n ? kA[q0] : 0ull, key1 = q1 < n ? kA[q1] : 0ull;
+            bool k0, k1;
+            wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+            const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+            if (k0) kB[g * a.k + prefix_popc(m0)] = key0;
+            if (k1) kB[g * a.k + n0 + prefix_popc(m1)] = key1;
+            if (lane >= ns && lane < a.k) kB[g * a.k + lane] = 0ull;
+        }
+        __syncthreads();
+        n = groups * a.k;
+        unsigned long long *t = kA; kA = kB; kB = t;
+    }
+    if (wave == 0) {
+        const unsigned long long key0 = lane < n ? kA[lane] : 0ull;
+        const unsigned long long key1 = lane + 64 < n ? kA[lane + 64] : 0ull;
+        bool k0, k1;
+        wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const int n0 = __popcll(m0);
+        if (k0) kB[prefix_popc(m0)] = key0;
+        if (k1) kB[n0 + prefix_popc(m1)] = key1;
+        if (lane == 0) s_n = n0 + __popcll(m1);
+    }
+    __syncthreads();
+    const int nsel = s_n;
+    const unsigned long long *win = kB;
+
+    for (int q = tid; q < nsel; q += BLOCK) {
+        const unsigned long long kq = win[q];
+        const int idx = key_index(kq);
+        const float sq = key_score(kq);
+        if (a.wsel) a.wsel[rs + idx] = sq;
+        if (emit) {
+            int rk = 0;
+            for (int r = 0; r < nsel; ++r) rk += win[r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
+            a.sel_w[(size_t)i * a.k + rk] = sq;
+        }
+    }
+
+    RowT acc;
+    acc.zero();
+    for (int q0 = 0; q0 < nsel; q0 += WAVES * NG) {
+        const int q = q0 + wave * NG + gid;
+        if (q < nsel) {
+            const unsigned long long kq = win[q];
+            RowT x;
+            x.load(a.h + (size_t)a.col[rs + key_index(kq)] * a.C, a.C, lg);
+            acc.axpy(key_score(kq), x);
+        }
+    }
+    acc.reduce_across_groups();
+    if (gid == 0) acc.store(s_part + (size_t)wave * a.C, a.C, lg);
+    __syncthreads();
+    for (int ch = tid; ch < a.C; ch += BLOCK) {
+        float s = 0.f;
+        for (int w = 0; w < WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
+        a.out[(size_t)i * a.C + ch] = s / (float)deg;
+    }
+}
+
+template <int VEC, int G, int R>
+int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
     constexpr int RPW = 64 / G;
     const int n_small = a.N - a.n_med_end;
     const int nbC = ceil_div(n_small, (int64_t)WAVES * RPW);
     const int grid = a.nbA + a.nbB + nbC;
+    if (ev) SN_HIP(hipEventRecord(ev[0], st));
     if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
-    if (a.n_split > 0) {
+    if (ev) SN_HIP(hipEventRecord(ev[1], st));
+    if (a.n_split > 0 && (a.k < 0 || a.k <= CAND_MAX_K)) {
+        // streaming rows and candidate tournament
+        const int max_tasks = ceil_div(max_split_deg, CHUNK);
+        const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
+        const size_t dyn = ((size_t)WAVES * a.C + 1) * 4 + (size_t)max_slots * 16 + 16;
+        if (dyn > 150 * 1024) { set_error("in-degree too large for the split-row finalize"); return SNGNN_EINVAL; }
+        if (dyn > 48 * 1024)
+            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        k_agg_fin_cand<VEC, G, R><<<a.n_split, BLOCK, dyn, st>>>(a, max_slots);
+    } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)(a.k < 0 ? 0 : a.k) * 4;
         const size_t budget = 120 * 1024;
         int lds_scores = 0;
@@ -538,14 +707,18 @@ template <int VEC, int G, int R> int launch_agg_fwd(const FwdArgs &a, int max_sp
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         k_agg_fin<VEC, G, R><<<a.n_split, FIN_BLOCK, dyn, st>>>(a, lds_scores);
     }
+    if (ev) SN_HIP(hipEventRecord(ev[2], st));
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
 
 // one translation unit per VEC instantiates these
-int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
-int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
-int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st);
+int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
+                      hipStream_t st);
+int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
+                      hipStream_t st);
+int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
+                      hipStream_t st);
 
 #define SNGNN_DISPATCH_GR(FN, VEC, cfg, ...)                                   \
     switch ((cfg).g * 100 + (cfg).r) {                                         \

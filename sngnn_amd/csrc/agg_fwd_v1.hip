@@ -3,9 +3,10 @@
 
 namespace sngnn {
 
-int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipStream_t st)
+int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
+                      hipStream_t st)
 {
-    SNGNN_DISPATCH_GR(launch_agg_fwd, 1, cfg, a, max_split_deg, st)
+    SNGNN_DISPATCH_GR(launch_agg_fwd, 1, cfg, a, max_split_deg, ev, st)
 }
 
 }  // namespace sngnn

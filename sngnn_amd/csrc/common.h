@@ -56,7 +56,8 @@ inline bool row_cfg(int C, RowCfg &cfg)
 
 // The graph object behind the opaque handle.
 struct sngnn_graph {
-    int64_t N = 0, E_in = 0, Ep = 0;
+    int64_t N = 0, E_in = 0, Ep = 0;   // N = target rows owned by this graph
+    int64_t Ntot = 0, row_off = 0;       // sources / feature-table rows; first owned node id
     int add_loops = 0, remove_loops = 0;
     // device arrays
     int32_t *rowptr = nullptr, *col = nullptr, *eid = nullptr;

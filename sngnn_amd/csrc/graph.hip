@@ -31,27 +31,29 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 }
 
 // candidate t in [0, E + n_loops): original edge or appended self-loop
-__global__ void k_mark(const int64_t *__restrict__ ei, int64_t E, int64_t T, int64_t N,
-                       int remove_loops, int32_t *__restrict__ keep, int32_t *__restrict__ bad)
+__global__ void k_mark(const int64_t *__restrict__ ei, int64_t E, int64_t T, int64_t Ntot,
+                       int64_t row0, int64_t row1, int remove_loops, int32_t *__restrict__ keep,
+                       int32_t *__restrict__ bad)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     int64_t s, d;
-    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = t - E; }
-    if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(bad, 1); keep[t] = 0; return; }
-    keep[t] = (remove_loops && s == d) ? 0 : 1;
+    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = row0 + (t - E); }
+    if (s < 0 || s >= Ntot || d < 0 || d >= Ntot) { atomicOr(bad, 1); keep[t] = 0; return; }
+    // a partition keeps only the edges that point into its own node range
+    keep[t] = ((remove_loops && s == d) || d < row0 || d >= row1) ? 0 : 1;
 }
 
-__global__ void k_compact(const int64_t *__restrict__ ei, int64_t E, int64_t T,
+__global__ void k_compact(const int64_t *__restrict__ ei, int64_t E, int64_t T, int64_t row0,
                           const int32_t *__restrict__ keep, const int32_t *__restrict__ pos,
                           int32_t *__restrict__ src32, int32_t *__restrict__ dst32)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T || !keep[t]) return;
     int64_t s, d;
-    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = t - E; }
-    src32[pos[t]] = (int32_t)s;
-    dst32[pos[t]] = (int32_t)d;
+    if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = row0 + (t - E); }
+    src32[pos[t]] = (int32_t)s;              // global source id
+    dst32[pos[t]] = (int32_t)(d - row0);     // local target row
 }
 
 __global__ void k_iota(int32_t *a, int64_t n)
@@ -168,15 +170,17 @@ static int build_tasks(const std::vector<int32_t> &deg_desc, int n_split, int32_
     return 0;
 }
 
-static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t N, int add_loops,
-                 int remove_loops, hipStream_t st)
+static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int64_t row0,
+                 int64_t row1, int add_loops, int remove_loops, hipStream_t st)
 {
+    const int64_t N = row1 - row0;                                   // owned target rows
     const int64_t n_loops = (add_loops && !remove_loops) ? N : 0;   // add+remove == remove
     const int64_t T = E + n_loops;
-    SN_REQUIRE(T < ((int64_t)1 << 31) - 1 && N < ((int64_t)1 << 31) - 1, SNGNN_EINVAL,
+    SN_REQUIRE(T < ((int64_t)1 << 31) - 1 && Ntot < ((int64_t)1 << 31) - 1, SNGNN_EINVAL,
                "graph too large for 32-bit indices");
     SN_HIP(hipGetDevice(&g->device));
-    g->N = N; g->E_in = E; g->add_loops = add_loops; g->remove_loops = remove_loops;
+    g->N = N; g->Ntot = Ntot; g->row_off = row0;
+    g->E_in = E; g->add_loops = add_loops; g->remove_loops = remove_loops;
     int rc;
 
     // 1. mark + validate, 2. scan, 3. compact to int32 (src, dst) in list order
@@ -188,8 +192,8 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t N, int ad
     SN_HIP(hipMemsetAsync(bad.p, 0, 4, st));
     int64_t Ep = 0;
     if (T > 0) {
-        k_mark<<<grid1(T), 256, 0, st>>>(ei, E, T, N, remove_loops, keep.as<int32_t>(),
-                                         bad.as<int32_t>());
+        k_mark<<<grid1(T), 256, 0, st>>>(ei, E, T, Ntot, row0, row1, remove_loops,
+                                         keep.as<int32_t>(), bad.as<int32_t>());
         size_t tmp_bytes = 0;
         SN_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep.as<int32_t>(),
                                                 pos.as<int32_t>(), (int)T, st));
@@ -211,24 +215,24 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t N, int ad
         return SNGNN_ENOMEM;
     }
     if (T > 0)
-        k_compact<<<grid1(T), 256, 0, st>>>(ei, E, T, keep.as<int32_t>(), pos.as<int32_t>(),
+        k_compact<<<grid1(T), 256, 0, st>>>(ei, E, T, row0, keep.as<int32_t>(), pos.as<int32_t>(),
                                             src32.as<int32_t>(), dst32.as<int32_t>());
 
     if ((rc = dev_alloc(&g->rowptr, N + 1)) || (rc = dev_alloc(&g->col, Ep)) ||
-        (rc = dev_alloc(&g->eid, Ep)) || (rc = dev_alloc(&g->cscptr, N + 1)) ||
+        (rc = dev_alloc(&g->eid, Ep)) || (rc = dev_alloc(&g->cscptr, Ntot + 1)) ||
         (rc = dev_alloc(&g->csc_eid, Ep)) || (rc = dev_alloc(&g->csc_dst, Ep)) ||
-        (rc = dev_alloc(&g->rperm, N)) || (rc = dev_alloc(&g->sperm, N)))
+        (rc = dev_alloc(&g->rperm, N)) || (rc = dev_alloc(&g->sperm, Ntot)))
         return rc;
 
-    const int nbits = bits_for(std::max<int64_t>(N, 2));
+    const int nbits = bits_for(std::max<int64_t>(Ntot, 2));
     DevBuf iota, keys_sorted, deg, deg_sorted;
-    if (iota.alloc((size_t)std::max(Ep, N) * 4) || keys_sorted.alloc((size_t)std::max(Ep, N) * 4) ||
-        deg.alloc((size_t)N * 4) || deg_sorted.alloc((size_t)N * 4)) {
+    if (iota.alloc((size_t)std::max(Ep, Ntot) * 4) || keys_sorted.alloc((size_t)std::max(Ep, Ntot) * 4) ||
+        deg.alloc((size_t)Ntot * 4) || deg_sorted.alloc((size_t)Ntot * 4)) {
         set_error("out of device memory (graph build)");
         return SNGNN_ENOMEM;
     }
     int32_t *d_iota = iota.as<int32_t>(), *d_keys = keys_sorted.as<int32_t>();
-    if (std::max(Ep, N) > 0) k_iota<<<grid1(std::max(Ep, N)), 256, 0, st>>>(d_iota, std::max(Ep, N));
+    if (std::max(Ep, Ntot) > 0) k_iota<<<grid1(std::max(Ep, Ntot)), 256, 0, st>>>(d_iota, std::max(Ep, Ntot));
 
     // 4. CSR by target: stable sort of list positions by dst
     if (Ep > 0) {
@@ -258,15 +262,15 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t N, int ad
         SN_HIP(hipMemcpy(&mn, d_keys, 4, hipMemcpyDeviceToHost));
         g->src_min = mn;
     }
-    k_lower_bound<<<grid1(N + 1), 256, 0, st>>>(d_keys, Ep, N, g->cscptr);
-    g->sdeg.assign((size_t)N, 0);
-    if (N > 0) {
-        k_degree<<<grid1(N), 256, 0, st>>>(g->cscptr, N, deg.as<int32_t>());
-        if ((rc = sort_pairs(deg.as<int32_t>(), deg_sorted.as<int32_t>(), d_iota, g->sperm, N, 31, true, st)))
+    k_lower_bound<<<grid1(Ntot + 1), 256, 0, st>>>(d_keys, Ep, Ntot, g->cscptr);
+    g->sdeg.assign((size_t)Ntot, 0);
+    if (Ntot > 0) {
+        k_degree<<<grid1(Ntot), 256, 0, st>>>(g->cscptr, Ntot, deg.as<int32_t>());
+        if ((rc = sort_pairs(deg.as<int32_t>(), deg_sorted.as<int32_t>(), d_iota, g->sperm, Ntot, 31, true, st)))
             return rc;
-        SN_HIP(hipMemcpy(g->sdeg.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        SN_HIP(hipMemcpy(g->sdeg.data(), deg_sorted.p, (size_t)Ntot * 4, hipMemcpyDeviceToHost));
     }
-    g->max_out_deg = N ? g->sdeg[0] : 0;
+    g->max_out_deg = Ntot ? g->sdeg[0] : 0;
 
     // 7. split-row / split-source task lists
     g->n_split = g->rows_gt(WAVE_T);
@@ -296,19 +300,30 @@ const char *sngnn_build_info(void)
     return "libsngnn_hip;arch=gfx950;hip=" SN_STR(HIP_VERSION_MAJOR) "." SN_STR(HIP_VERSION_MINOR);
 }
 
-int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int add_loops,
-                       int remove_loops, void *stream, sngnn_graph_t **out_graph)
+int sngnn_graph_create_partition(const int64_t *edge_index_dev, int64_t E, int64_t N_total,
+                                 int64_t row_begin, int64_t row_end, int add_loops,
+                                 int remove_loops, void *stream, sngnn_graph_t **out_graph)
 {
     SN_REQUIRE(out_graph != nullptr, SNGNN_EINVAL, "out_graph is NULL");
     *out_graph = nullptr;
-    SN_REQUIRE(E >= 0 && N >= 0, SNGNN_EINVAL, "negative size");
+    SN_REQUIRE(E >= 0 && N_total >= 0, SNGNN_EINVAL, "negative size");
+    SN_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= N_total, SNGNN_EINVAL,
+               "row range must satisfy 0 <= row_begin <= row_end <= N_total");
     SN_REQUIRE(E == 0 || edge_index_dev != nullptr, SNGNN_EINVAL, "edge_index is NULL");
     sngnn_graph *g = new (std::nothrow) sngnn_graph();
     SN_REQUIRE(g != nullptr, SNGNN_ENOMEM, "out of host memory");
-    int rc = build(g, edge_index_dev, E, N, add_loops != 0, remove_loops != 0, (hipStream_t)stream);
+    int rc = build(g, edge_index_dev, E, N_total, row_begin, row_end, add_loops != 0,
+                   remove_loops != 0, (hipStream_t)stream);
     if (rc != 0) { sngnn_graph_destroy(g); return rc; }
     *out_graph = g;
     return SNGNN_OK;
+}
+
+int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int add_loops,
+                       int remove_loops, void *stream, sngnn_graph_t **out_graph)
+{
+    return sngnn_graph_create_partition(edge_index_dev, E, N, 0, N, add_loops, remove_loops,
+                                        stream, out_graph);
 }
 
 void sngnn_graph_destroy(sngnn_graph_t *g)
@@ -322,6 +337,8 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 }
 
 int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g) { return g ? g->N : -1; }
+int64_t sngnn_graph_num_total_nodes(const sngnn_graph_t *g) { return g ? g->Ntot : -1; }
+int64_t sngnn_graph_row_offset(const sngnn_graph_t *g) { return g ? g->row_off : -1; }
 int64_t sngnn_graph_num_edges(const sngnn_graph_t *g) { return g ? g->Ep : -1; }
 int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g) { return g ? g->max_in_deg : -1; }
 int64_t sngnn_graph_src_min(const sngnn_graph_t *g) { return g ? g->src_min : -1; }
@@ -330,7 +347,8 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {
     if (!g || C < 1) return -1;
     // forward: scores of split rows | one partial row per split task
-    int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + (int64_t)g->n_tasks * C * 4;
+    int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
+                  (int64_t)g->n_tasks * 32 * 8;     // + CAND_MAX_K candidate keys per task
     // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_tasks * C * 4 +
@@ -345,7 +363,7 @@ static const void *graph_array(const sngnn_graph_t *g, int which, int64_t *n)
     case 0: *n = g->N + 1; return g->rowptr;
     case 1: *n = g->Ep; return g->col;
     case 2: *n = g->Ep; return g->eid;
-    case 3: *n = g->N + 1; return g->cscptr;
+    case 3: *n = g->Ntot + 1; return g->cscptr;
     case 4: *n = g->Ep; return g->csc_eid;
     case 5: *n = g->N; return g->rperm;
     default: *n = 0; return nullptr;

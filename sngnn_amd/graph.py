@@ -22,7 +22,10 @@ class Graph:
     """Owns a ``sngnn_graph_t`` handle."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
-                 remove_loops: bool):
+                 remove_loops: bool, row_range=None):
+        """``row_range=(begin, end)`` builds the node-range partition that owns the
+        targets [begin, end) of a ``num_nodes``-node graph (global ids in
+        ``edge_index``); ``None`` is the whole graph."""
         if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
             raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
         if not edge_index.is_cuda:
@@ -34,12 +37,15 @@ class Graph:
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            rc = lib.sngnn_graph_create(ei.data_ptr(), ei.size(1), int(num_nodes),
-                                        int(add_loops), int(remove_loops), stream,
-                                        C.byref(handle))
-        _lib.check(rc, "sngnn_graph_create")
+            r0, r1 = (0, int(num_nodes)) if row_range is None else map(int, row_range)
+            rc = lib.sngnn_graph_create_partition(ei.data_ptr(), ei.size(1), int(num_nodes),
+                                                  r0, r1, int(add_loops), int(remove_loops),
+                                                  stream, C.byref(handle))
+        _lib.check(rc, "sngnn_graph_create_partition")
         self._h = handle
-        self.num_nodes = int(lib.sngnn_graph_num_nodes(handle))
+        self.num_nodes = int(lib.sngnn_graph_num_nodes(handle))            # owned rows
+        self.num_total_nodes = int(lib.sngnn_graph_num_total_nodes(handle))
+        self.row_offset = int(lib.sngnn_graph_row_offset(handle))
         self.num_edges = int(lib.sngnn_graph_num_edges(handle))
         self.max_in_degree = int(lib.sngnn_graph_max_in_degree(handle))
         self.src_min = int(lib.sngnn_graph_src_min(handle))
@@ -62,8 +68,8 @@ class Graph:
     def array(self, name: str) -> np.ndarray:
         """Host copy of one of the structure arrays (tests / inspection)."""
         which = _ARRAYS[name]
-        n = {0: self.num_nodes + 1, 3: self.num_nodes + 1, 5: self.num_nodes}.get(which,
-                                                                                  self.num_edges)
+        n = {0: self.num_nodes + 1, 3: self.num_total_nodes + 1,
+             5: self.num_nodes}.get(which, self.num_edges)
         out = np.empty(n, dtype=np.int32)
         _lib.check(_lib.load().sngnn_graph_copy_array(self._h, which, out.ctypes.data),
                    "sngnn_graph_copy_array")
@@ -87,16 +93,17 @@ class GraphCache:
         self._max = max_entries
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
-            remove_loops: bool) -> Graph:
+            remove_loops: bool, row_range=None) -> Graph:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               int(num_nodes), bool(add_loops), bool(remove_loops), str(edge_index.device))
+               int(num_nodes), bool(add_loops), bool(remove_loops), str(edge_index.device),
+               None if row_range is None else tuple(map(int, row_range)))
         hit = self._entries.get(key)
         if hit is None:
             if len(self._entries) >= self._max:
                 self._entries.pop(next(iter(self._entries)))
             # the entry keeps edge_index alive, so its address cannot be recycled
             # for a different tensor while the key is cached
-            hit = (Graph(edge_index, num_nodes, add_loops, remove_loops), edge_index)
+            hit = (Graph(edge_index, num_nodes, add_loops, remove_loops, row_range), edge_index)
             self._entries[key] = hit
         return hit[0]
 

@@ -37,12 +37,12 @@ def aggregate_forward(graph: Graph, h: torch.Tensor, top_k: Optional[int], thr: 
     unless requested.  ``top_k=None`` is SNConv (no selection)."""
     lib = _lib.load()
     n = graph.num_nodes
-    h = _check_rows(h, n, "h")
+    h = _check_rows(h, graph.num_total_nodes, "h")
     c = h.size(1)
     k = -1 if top_k is None else int(top_k)
     if top_k is not None and k < 0:
         raise ValueError("top_k must be >= 0")
-    out = torch.empty_like(h)
+    out = torch.empty((n, c), dtype=torch.float32, device=h.device)
     wsel = inv = sel_src = sel_w = None
     if save_for_backward:
         wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=h.device)
@@ -62,18 +62,17 @@ def aggregate_forward(graph: Graph, h: torch.Tensor, top_k: Optional[int], thr: 
 
 
 def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
-                       wsel: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+                       wsel: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
-    n = graph.num_nodes
-    h = _check_rows(h, n, "h")
-    grad_out = _check_rows(grad_out, n, "grad_out")
+    h = _check_rows(h, graph.num_total_nodes, "h")
+    grad_out = _check_rows(grad_out, graph.num_nodes, "grad_out")
     c = h.size(1)
     grad_h = torch.empty_like(h)
     ws = graph.workspace(c)
     with torch.cuda.device(h.device):
         rc = lib.sngnn_agg_backward(graph.handle, h.data_ptr(), c, grad_out.data_ptr(),
-                                    wsel.data_ptr(), inv.data_ptr(), grad_h.data_ptr(),
-                                    ws.data_ptr(), _stream(h.device))
+                                    wsel.data_ptr(), grad_h.data_ptr(), ws.data_ptr(),
+                                    _stream(h.device))
     _lib.check(rc, "sngnn_agg_backward")
     return grad_h
 
@@ -85,22 +84,23 @@ class _Aggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, graph, top_k, thr):
         need_grad = ctx.needs_input_grad[0]
-        out, wsel, inv, _, _ = aggregate_forward(graph, h, top_k, thr,
-                                                 save_for_backward=need_grad)
+        out, wsel, _, _, _ = aggregate_forward(graph, h, top_k, thr,
+                                               save_for_backward=need_grad)
         if need_grad:
             ctx.graph = graph
-            ctx.save_for_backward(h, wsel, inv)
+            ctx.save_for_backward(h, wsel)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        h, wsel, inv = ctx.saved_tensors
-        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, inv)
+        h, wsel = ctx.saved_tensors
+        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel)
         return grad_h, None, None, None
 
 
 def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float) -> torch.Tensor:
-    """Differentiable fused aggregation: [N, C] -> [N, C]."""
+    """Differentiable fused aggregation: [N_total, C] -> [N, C] (N_total == N unless
+    ``graph`` is a node-range partition)."""
     return _Aggregate.apply(h, graph, top_k, thr)
 
 
