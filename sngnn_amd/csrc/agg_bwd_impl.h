@@ -194,10 +194,11 @@ __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VE
         dn.add(t);
     }
     hv.load(a.h + (size_t)v * a.C, a.C, lg);
-    const float invv = inv_norm_of(group_sum<G>(hv.dot_partial(hv)));
+    const float qv = group_sum<G>(hv.dot_partial(hv));
+    const float invv = inv_norm_of(qv);
     hv.scale(invv);                               // n_v
     float proj = group_sum<G>(hv.dot_partial(dn));
-    if (invv == 1.0f / EPS_NORM) proj = 0.f;      // eps clamp active: n = h / eps
+    if (norm_clamped(qv)) proj = 0.f;             // eps clamp active: n = h / eps
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -52,7 +52,8 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
 
     FwdArgs a;
     a.h = h; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
-    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
+    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm; a.rdesc = g->rdesc;
+    a.nbC = 0;
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
     a.sel_src = top_k > 0 ? sel_src : nullptr; a.sel_w = top_k > 0 ? sel_w : nullptr;

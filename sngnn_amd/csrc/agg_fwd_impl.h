@@ -31,6 +31,7 @@ struct FwdArgs {
     int C, N;         // N = owned target rows
     int row_off;      // row i's own feature row is h[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
+    const int4 *rdesc;     // per degree-sorted slot: {row, first edge, in-degree, 0}
     int k;            // < 0: no selection
     float thr;
     float *out, *wsel, *inv_norm;
@@ -42,10 +43,11 @@ struct FwdArgs {
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int lowbits;                    // bits needed for a row-local edge index
-    int nbA, nbB;               // blocks of class A and B; the rest are class C
+    int nbA, nbB, nbC;          // blocks of class A, B and C (C: persistent, grid-stride)
 };
 
 constexpr int LDS_PER_WAVE = 512;   // 32-bit words
+constexpr int FWD_WAVES_PER_SIMD = 6;   // register budget of the main kernel (<= 80 VGPRs)
 
 template <int R> struct Unroll { static constexpr int U = (R >= 4) ? 1 : (R == 2 ? 2 : 4); };
 
@@ -124,54 +126,44 @@ __device__ __forceinline__ WaveSel wave_select(const float *sc, int n, int base,
 // ---------------------------------------------------------------------------
 // Class C: deg <= SMALL_T, one group per row.
 // ---------------------------------------------------------------------------
+// One set of 64/G small rows (one per lane group) whose column ids are already in
+// LDS (s_col[gid][t]).  d = this group's row descriptor (deg 0 for a padding slot).
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_wave)
+__device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, bool valid,
+                                               int *lds_wave, const int *s_col_set)
 {
     using RowT = Row<VEC, G, R>;
-    constexpr int RPW = 64 / G;
     constexpr int U = Unroll<R>::U;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
-    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
-    const bool valid = slot < a.N;
-    const int i = valid ? a.rperm[slot] : 0;
-    const int rs = valid ? a.rowptr[i] : 0;
-    const int deg = valid ? a.rowptr[i + 1] - rs : 0;
+    const int i = d.x, rs = d.y, deg = d.z;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
     const bool need_sc = rank || emit;
 
-    int *s_col = lds_wave + gid * SMALL_T;                       // [RPW][SMALL_T]
-    float *s_sc = reinterpret_cast<float *>(lds_wave + 128) + gid * SMALL_T;
-    float *s_w = reinterpret_cast<float *>(lds_wave + 256) + gid * SMALL_T;
-    int *s_rank = lds_wave + 384 + gid * SMALL_T;
-
-    for (int t = lg; t < deg; t += G) s_col[t] = a.col[rs + t];
-    wave_lds_sync();
+    const int *s_col = s_col_set + gid * SMALL_T;
+    float *s_sc = reinterpret_cast<float *>(lds_wave + 256) + gid * SMALL_T;
+    float *s_w = reinterpret_cast<float *>(lds_wave + 384) + gid * SMALL_T;
 
     RowT hi;
     hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
-    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
-    if (valid && lg == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+    const int dmax = wave_max_i(deg);
 
     RowT acc;
     acc.zero();
-    const int dmax = wave_max_i(deg);
+    float inv_i = 0.f;
     for (int t0 = 0; t0 < dmax; t0 += U) {
-        int j[U];
-        bool act[U];
         RowT x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            act[u] = (t0 + u) < deg;
-            j[u] = act[u] ? s_col[t0 + u] : i + a.row_off;
+            const int j = (t0 + u) < deg ? s_col[t0 + u] : i + a.row_off;
+            x[u].load(a.h + (size_t)j * a.C, a.C, lg);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
+        if (t0 == 0) inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
-            if (act[u]) {
+            if (t0 + u < deg) {
                 if (need_sc && lg == 0) s_sc[t0 + u] = s;
                 if (!rank) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
@@ -180,6 +172,10 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
                 }
             }
         }
+    }
+    if (a.inv_norm) {      // isolated rows never enter the loop
+        if (dmax == 0) inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+        if (valid && lg == 0) a.inv_norm[i] = inv_i;
     }
 
     if (need_sc) {
@@ -194,7 +190,6 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
             }
             const bool sel = rk < a.k && se >= a.thr;
             s_w[e] = sel ? se : SNGNN_UNSELECTED;
-            s_rank[e] = rk;
             if (rank && a.wsel) a.wsel[rs + e] = sel ? se : SNGNN_UNSELECTED;
             if (emit && sel) {
                 a.sel_src[(size_t)i * a.k + rk] = s_col[e];
@@ -208,16 +203,78 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int blk, int *lds_w
             for (int t = 0; t < deg; ++t) {
                 const float w = s_w[t];
                 if (w != SNGNN_UNSELECTED) {
-                    RowT x;
-                    x.load(a.h + (size_t)s_col[t] * a.C, a.C, lg);
-                    acc.axpy(w, x);
+                    RowT xr;
+                    xr.load(a.h + (size_t)s_col[t] * a.C, a.C, lg);
+                    acc.axpy(w, xr);
                 }
             }
         }
+        wave_lds_sync();       // s_sc / s_w are reused by the next set
     }
     if (valid) {
         acc.div((float)max(deg, 1));
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Class C: deg <= SMALL_T, one G-lane group per row, 64/G rows per set.  Waves
+// are persistent: each walks sets wave_id, wave_id + n_waves, ... and keeps the
+// NEXT set's descriptors and column ids in flight while it works on the current
+// one, so a set costs one memory round trip (its feature rows) instead of a
+// chain of three (descriptor -> columns -> rows).
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void role_small(const FwdArgs &a, int set, int stride, int *lds_wave)
+{
+    constexpr int RPW = 64 / G;
+    constexpr int CPL = (RPW * SMALL_T + 63) / 64;      // column ids per lane per set
+    const int lane = lane_id();
+    const int gid = lane / G;
+    const int n_small = a.N - a.n_med_end;
+    const int nsets = (n_small + RPW - 1) / RPW;
+    if (set >= nsets) return;
+
+    auto load_desc = [&](int st) -> int4 {
+        const int slot = a.n_med_end + st * RPW + gid;
+        return (st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
+    };
+    // lane l fetches column ids q = l + 64 m of the set: row q / SMALL_T, edge q % SMALL_T
+    auto load_cols = [&](const int4 d, int (&c)[CPL]) {
+#pragma unroll
+        for (int m = 0; m < CPL; ++m) {
+            const int q = lane + 64 * m;
+            const int r = q / SMALL_T, t = q % SMALL_T;
+            // descriptor of row r of the set lives in the lanes of group r
+            const int rs = __shfl(d.y, r * G, 64), dg = __shfl(d.z, r * G, 64);
+            c[m] = (r < RPW && t < dg) ? a.col[rs + t] : 0;
+        }
+    };
+    auto store_cols = [&](const int (&c)[CPL], int *dst) {
+#pragma unroll
+        for (int m = 0; m < CPL; ++m) {
+            const int q = lane + 64 * m;
+            if (q < RPW * SMALL_T) dst[q] = c[m];
+        }
+    };
+
+    int *s_colbuf[2] = {lds_wave, lds_wave + 128};      // [RPW][SMALL_T] each
+    int4 d_cur = load_desc(set);
+    int4 d_nxt = load_desc(set + stride);
+    int cols[CPL];
+    load_cols(d_cur, cols);
+    store_cols(cols, s_colbuf[0]);
+    int buf = 0;
+    while (set < nsets) {
+        const int4 d_n2 = load_desc(set + 2 * stride);
+        load_cols(d_nxt, cols);                 // in flight during this set's work
+        wave_lds_sync();
+        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, s_colbuf[buf]);
+        store_cols(cols, s_colbuf[buf ^ 1]);
+        d_cur = d_nxt;
+        d_nxt = d_n2;
+        buf ^= 1;
+        set += stride;
     }
 }
 
@@ -239,6 +296,14 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
     constexpr int U = Unroll<R>::U;
     const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
+    // column ids one iteration ahead: the col -> row dependency of iteration n+1
+    // overlaps the row loads of iteration n
+    int jn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int t = e0 + u * NG + gid;
+        jn[u] = t < e1 ? a.col[rs + t] : i + a.row_off;
+    }
     for (int base = e0; base < e1; base += NG * U) {
         int t[U], j[U];
         bool act[U];
@@ -247,10 +312,15 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
         for (int u = 0; u < U; ++u) {
             t[u] = base + u * NG + gid;
             act[u] = t[u] < e1;
-            j[u] = act[u] ? a.col[rs + t[u]] : i + a.row_off;
+            j[u] = jn[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tn = t[u] + NG * U;
+            jn[u] = tn < e1 ? a.col[rs + tn] : i + a.row_off;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
@@ -270,17 +340,15 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_wave(const FwdArgs &a, int blk, int *lds_wave)
+__device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
-    const int slot = a.n_split + blk * WAVES + wave;
-    if (slot >= a.n_med_end) return;            // wave-uniform
-    const int i = a.rperm[slot];
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
+    const int slot = a.n_split + item;
+    const int4 d = a.rdesc[slot];
+    const int i = d.x, rs = d.y, deg = d.z;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
     const bool need_sc = rank || emit;
@@ -341,23 +409,21 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int blk, int *lds_wa
         acc.div((float)deg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
+    wave_lds_sync();            // the wave's LDS scratch is reused by its next item
 }
 
 // ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_task(const FwdArgs &a, int blk, int *lds_wave)
+__device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
-    const int tq = blk * WAVES + wave;
-    if (tq >= a.n_tasks) return;                // wave-uniform
     const int p = a.task_slot[tq], c = a.task_chunk[tq];
-    const int i = a.rperm[p];
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
     const int e0 = c * CHUNK, e1 = min(deg, e0 + CHUNK);
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
@@ -390,17 +456,26 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int blk, int *lds_wa
         acc.reduce_across_groups();
         if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
     }
+    wave_lds_sync();            // the wave's LDS scratch is reused by its next item
 }
 
+// Persistent waves: wave w of the grid takes work items w, w + n_waves, ... of the
+// list [split-row tasks | wave rows | small-row sets], each class in order of
+// descending degree, so every wave gets a similar mix and the grid drains evenly.
 template <int VEC, int G, int R>
-__global__ __launch_bounds__(BLOCK) void k_agg_fwd(const FwdArgs a)
+__global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
     __shared__ int lds[WAVES][LDS_PER_WAVE];
-    const int b = blockIdx.x;
-    int *lw = lds[threadIdx.x >> 6];
-    if (b < a.nbA) role_task<VEC, G, R>(a, b, lw);
-    else if (b < a.nbA + a.nbB) role_wave<VEC, G, R>(a, b - a.nbA, lw);
-    else role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+    const int wave = threadIdx.x >> 6;
+    int *lw = lds[wave];
+    const int nw = gridDim.x * WAVES;
+    const int n_wave_rows = a.n_med_end - a.n_split;
+    int it = blockIdx.x * WAVES + wave;
+    for (; it < a.n_tasks; it += nw) role_task<VEC, G, R>(a, it, lw);
+    it -= a.n_tasks;
+    for (; it < n_wave_rows; it += nw) role_wave<VEC, G, R>(a, it, lw);
+    it -= n_wave_rows;
+    role_small<VEC, G, R>(a, it, nw, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -676,12 +751,14 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
 }
 
 template <int VEC, int G, int R>
-int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
     constexpr int RPW = 64 / G;
+    FwdArgs a = a0;
     const int n_small = a.N - a.n_med_end;
-    const int nbC = ceil_div(n_small, (int64_t)WAVES * RPW);
-    const int grid = a.nbA + a.nbB + nbC;
+    const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
+    // persistent grid: what the chip holds at the kernel's occupancy, or less
+    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
     if (ev) SN_HIP(hipEventRecord(ev[1], st));

@@ -63,6 +63,7 @@ struct sngnn_graph {
     int32_t *rowptr = nullptr, *col = nullptr, *eid = nullptr;
     int32_t *cscptr = nullptr, *csc_eid = nullptr, *csc_dst = nullptr;
     int32_t *rperm = nullptr, *sperm = nullptr;
+    int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, 0}
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch

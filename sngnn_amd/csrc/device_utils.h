@@ -6,11 +6,28 @@ namespace sngnn {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// Butterfly sum over the G lanes of a group; every lane ends with the same bits.
+// v + (v of the lane selected by a DPP control): one VALU instruction, no LDS.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+    return v + __int_as_float(moved);
+}
+
+// Sum over the G lanes of a group; every lane of the group ends with the same
+// bits (each step adds a pair (a, b) as a + b in one lane and b + a in the other).
+// Within a 16-lane row the partner lanes come from DPP: quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror (i <-> 7-i: the other quad, whose lanes
+// already agree), row_mirror (i <-> 15-i: the other half).  Wider groups finish
+// with ds_swizzle / bpermute.  The order is fixed and identical in every kernel.
 template <int G> __device__ __forceinline__ float group_sum(float v)
 {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group width");
+    v = dpp_add<0xB1>(v);      // xor 1
+    v = dpp_add<0x4E>(v);      // xor 2
+    v = dpp_add<0x141>(v);     // other quad of the 8
+    if constexpr (G >= 16) v = dpp_add<0x140>(v);     // other half of the 16
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -173,10 +190,17 @@ template <int VEC, int G, int R> struct Row {
     }
 };
 
-// 1 / max(||row||_2, eps) from the group-summed sum of squares
+// 1 / max(||row||_2, eps) from the group-summed sum of squares: hardware
+// reciprocal square root of max(sumsq, eps^2) plus one Newton step (about half an
+// ulp; the same bits wherever a row's norm is needed, forward and backward).
 __device__ __forceinline__ float inv_norm_of(float sumsq)
 {
-    return 1.0f / fmaxf(sqrtf(sumsq), EPS_NORM);
+    const float q = fmaxf(sumsq, EPS_NORM * EPS_NORM);
+    const float r = __builtin_amdgcn_rsqf(q);
+    return r * fmaf(-0.5f * q * r, r, 1.5f);
 }
+
+// F.normalize clamps the norm at eps; below it the normalisation is a plain scale
+__device__ __forceinline__ bool norm_clamped(float sumsq) { return sumsq < EPS_NORM * EPS_NORM; }
 
 }  // namespace sngnn

@@ -83,6 +83,16 @@ __global__ void k_lower_bound(const int32_t *__restrict__ keys, int64_t n, int64
     ptr[i] = (int32_t)lo;
 }
 
+__global__ void k_row_desc(const int32_t *__restrict__ rperm, const int32_t *__restrict__ rowptr,
+                           int64_t N, int4 *__restrict__ desc)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int i = rperm[p];
+    const int rs = rowptr[i];
+    desc[p] = make_int4(i, rs, rowptr[i + 1] - rs, 0);
+}
+
 __global__ void k_degree(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ deg)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,6 +263,8 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
         SN_HIP(hipMemcpy(g->rdeg.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     }
     g->max_in_deg = N ? g->rdeg[0] : 0;
+    if ((rc = dev_alloc(&g->rdesc, N))) return rc;
+    if (N > 0) k_row_desc<<<grid1(N), 256, 0, st>>>(g->rperm, g->rowptr, N, g->rdesc);
 
     // 6. CSC by source: stable sort of CSR positions by col
     if (Ep > 0) {
@@ -330,7 +342,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
-                    g->sperm, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
+                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
