@@ -1,4 +1,6 @@
 // C-ABI entry of the fused aggregation forward (see agg_fwd_impl.h for the kernels).
+#include <cstdlib>
+
 #include "agg_fwd_impl.h"
 
 using namespace sngnn;
@@ -54,6 +56,14 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.h = h; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
     a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm; a.rdesc = g->rdesc;
     a.nbC = 0;
+    {   // tuning aids (unset in production)
+        static const char *e_cls = getenv("SNGNN_DEBUG_CLASSES");
+        static const char *e_bpc = getenv("SNGNN_DEBUG_BLOCKS_PER_CU");
+        const char *c1 = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_DEBUG_CLASSES") : e_cls;
+        const char *c2 = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_DEBUG_BLOCKS_PER_CU") : e_bpc;
+        a.dbg_classes = c1 ? atoi(c1) : 7;
+        a.dbg_blocks_per_cu = c2 ? atoi(c2) : 0;
+    }
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
     a.sel_src = top_k > 0 ? sel_src : nullptr; a.sel_w = top_k > 0 ? sel_w : nullptr;

@@ -43,7 +43,9 @@ struct FwdArgs {
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int lowbits;                    // bits needed for a row-local edge index
-    int nbA, nbB, nbC;          // blocks of class A, B and C (C: persistent, grid-stride)
+    int nbA, nbB, nbC;          // (unused by the persistent kernel)
+    int dbg_classes;            // tuning aid: bit 0 tasks, bit 1 wave rows, bit 2 small rows
+    int dbg_blocks_per_cu;      // tuning aid: persistent grid size override (0 = default)
 };
 
 constexpr int LDS_PER_WAVE = 512;   // 32-bit words
@@ -471,11 +473,13 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     const int nw = gridDim.x * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
-    for (; it < a.n_tasks; it += nw) role_task<VEC, G, R>(a, it, lw);
+    for (; it < a.n_tasks; it += nw)
+        if (a.dbg_classes & 1) role_task<VEC, G, R>(a, it, lw);
     it -= a.n_tasks;
-    for (; it < n_wave_rows; it += nw) role_wave<VEC, G, R>(a, it, lw);
+    for (; it < n_wave_rows; it += nw)
+        if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, it, lw);
     it -= n_wave_rows;
-    role_small<VEC, G, R>(a, it, nw, lw);
+    if (a.dbg_classes & 4) role_small<VEC, G, R>(a, it, nw, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -758,7 +762,8 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
     const int n_small = a.N - a.n_med_end;
     const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
     // persistent grid: what the chip holds at the kernel's occupancy, or less
-    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
+    const int bpc = a.dbg_blocks_per_cu > 0 ? a.dbg_blocks_per_cu : FWD_WAVES_PER_SIMD;
+    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * bpc);
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
     if (ev) SN_HIP(hipEventRecord(ev[1], st));

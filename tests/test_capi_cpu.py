@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sngnn_hip.h declares;
+argument validation that needs no GPU; the product has no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sngnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sngnn_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from sngnn_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in sngnn_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signatures out of sync with the header"
+    assert b"gfx950" in lib.sngnn_build_info()
+
+
+def test_constants_match_header():
+    from sngnn_amd import _lib
+    text = open(os.path.join(ROOT, "include", "sngnn_hip.h")).read()
+    assert f"#define SNGNN_MAX_CHANNELS  {_lib.MAX_CHANNELS}" in text
+    assert "#define SNGNN_UNSELECTED   (-4.0f)" in text and _lib.UNSELECTED == -4.0
+
+
+def test_null_and_bad_arguments_are_rejected_without_a_gpu():
+    from sngnn_amd import _lib
+    lib = _lib.load()
+    assert lib.sngnn_graph_create(None, 0, 0, 1, 0, None, None) == _lib.EINVAL
+    assert b"NULL" in lib.sngnn_last_error()
+    h = C.c_void_p()
+    assert lib.sngnn_graph_create(None, 5, 10, 1, 0, None, C.byref(h)) == _lib.EINVAL
+    assert lib.sngnn_graph_create_partition(None, 0, 10, 4, 2, 1, 0, None, C.byref(h)) == _lib.EINVAL
+    assert lib.sngnn_agg_forward(None, None, 8, 1, 0.0, None, None, None, None, None, None,
+                                 None) == _lib.EINVAL
+    assert lib.sngnn_graph_num_nodes(None) == -1
+    lib.sngnn_graph_destroy(None)          # no-op
+
+
+def test_no_cpu_fallback():
+    from sngnn_amd import SNConv_plus, ops
+    from sngnn_amd.graph import Graph
+    conv = SNConv_plus(4, 3, 10)
+    x = torch.randn(10, 4)
+    ei = torch.randint(0, 10, (2, 20))
+    with pytest.raises(ValueError, match="GPU"):
+        conv(x, ei)
+    with pytest.raises(ValueError, match="GPU"):
+        Graph(ei, 10, True, False)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "sngnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "sngnn_oracle" not in src, f

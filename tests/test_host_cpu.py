@@ -1,0 +1,115 @@
+"""CPU: host-side logic - module surface (names, signatures, state_dict keys, init
+streams), synthetic generators, trainer loop semantics."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+import sngnn_amd
+from oracle import sngnn_oracle as O
+from sngnn_amd import synth
+
+
+def test_constructor_signatures_match_the_reference():
+    # models.py:266, :162-163, :36-37 and :306, :215-216, :90-91
+    sig = lambda f: list(inspect.signature(f).parameters)[1:]
+    assert sig(sngnn_amd.SNGNN.__init__) == ["in_channels", "hidden_channels", "out_channels",
+                                             "num_layers", "bn"]
+    assert sig(sngnn_amd.SNGNN_Plus.__init__) == [
+        "in_channels", "hidden_channels", "out_channels", "num_nodes", "num_layers", "top_k",
+        "thr", "is_remove_self_loops", "droput_rate", "bn"]
+    assert sig(sngnn_amd.SNGNN_Plus_Plus.__init__) == [
+        "in_channels", "hidden_channels", "out_channels", "num_nodes", "num_layers", "top_k",
+        "thr", "init_beta", "is_remove_self_loops", "droput_rate", "bn"]
+    assert sig(sngnn_amd.SNConv.__init__) == ["in_channels", "out_channels", "aggr", "bias"]
+    assert sig(sngnn_amd.SNConv_plus.__init__) == [
+        "in_channels", "out_channels", "num_nodes", "top_k", "thr", "is_remove_self_loops",
+        "bias", "aggr"]
+    assert sig(sngnn_amd.SNConv_plus_plus.__init__) == [
+        "in_channels", "out_channels", "num_nodes", "top_k", "thr", "init_beta",
+        "is_remove_self_loops", "bias", "aggr"]
+    d = inspect.signature(sngnn_amd.SNGNN_Plus.__init__).parameters
+    assert (d["top_k"].default, d["thr"].default, d["is_remove_self_loops"].default,
+            d["droput_rate"].default) == (2, 0.0, 1, 0.5)
+
+
+@pytest.mark.parametrize("kind,args", [
+    ("SNGNN", (10, 8, 3, 1)), ("SNGNN", (10, 8, 3, 3, True)),
+    ("SNGNN_Plus", (10, 8, 3, 40, 2, 4, 0.1, 1, 0.5, True)),
+    ("SNGNN_Plus", (10, 8, 3, 40, 1)),
+    ("SNGNN_Plus_Plus", (10, 8, 3, 40, 2, 4, 0.1, 0.3, 0, 0.5, True)),
+    ("SNGNN_Plus_Plus", (10, 8, 3, 40, 1, 2, 0.0, 0.0)),
+])
+def test_state_dict_keys_shapes_and_seeded_init_equal_the_restated_reference(kind, args):
+    torch.manual_seed(7)
+    ours = getattr(sngnn_amd, kind)(*args)
+    torch.manual_seed(7)
+    ref = getattr(O, kind)(*args)
+    a, b = ours.state_dict(), ref.state_dict()
+    assert list(a) == list(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    # bn flag lands in the conv's bias slot (models.py:52-53,177-178)
+    has_bias = any(k.endswith("lins.0.bias") for k in a)
+    assert has_bias == (kind == "SNGNN" or bool(ours.bn))
+
+
+def test_adjacency_table_layout():
+    m = sngnn_amd.SNConv_plus_plus(6, 4, 30)
+    assert m.w.weight.shape == (4, 30) and m.w.weight.t().is_contiguous()
+    assert float(m.beta) == 0.5
+    m2 = sngnn_amd.SNConv_plus_plus(6, 4, 30, init_beta=0.0)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2.load_state_dict(sd)
+    assert torch.equal(m2.w.weight, m.w.weight) and m2.w.weight.t().is_contiguous()
+
+
+@pytest.mark.parametrize("name", ["cora", "chameleon", "actor"])
+def test_synthetic_datasets_have_the_published_shapes(name):
+    n, e, f, c, max_deg, kind, dens = synth.SHAPES[name]
+    d = synth.make_dataset(name)
+    ei = d.edge_index.numpy()
+    assert d.x.shape == (n, f) and ei.shape == (2, e)
+    key = ei[0].astype(np.int64) * (n + 1) + ei[1]
+    assert (np.diff(key) > 0).all(), "sorted by (src, dst) and de-duplicated (coalesce)"
+    deg = np.bincount(ei[1], minlength=n)
+    assert deg.max() <= max_deg and (deg == 0).mean() >= 0.01
+    assert (ei[0] == ei[1]).sum() > 0
+    assert int(d.train_mask.sum() + d.val_mask.sum() + d.test_mask.sum()) == n
+    d2 = synth.make_dataset(name)
+    assert torch.equal(d.edge_index, d2.edge_index) and torch.equal(d.x, d2.x)
+
+
+def test_partition_edge_generation():
+    rng = np.random.default_rng(0)
+    ei = synth.make_edges(rng, 100, 600, 50, n_src=400, dst_offset=200)
+    assert ei[1].min() >= 200 and ei[1].max() < 300 and ei[0].max() < 400
+
+
+def test_trainer_loop_early_stopping_semantics():
+    """train.py:150-158: strict '<' on the validation loss, patience counter, test
+    accuracy taken at the best validation loss."""
+    from sngnn_amd import train as T
+
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.calls = 0
+
+        def forward(self, data):
+            self.calls += 1
+            return torch.log_softmax(self.p * 0 + data.x, dim=1)
+
+    n = 12
+    data = synth.Data(x=torch.randn(n, 3), edge_index=torch.zeros(2, 0, dtype=torch.long),
+                      y=torch.randint(0, 3, (n,)), train_mask=torch.arange(n) < 6,
+                      val_mask=(torch.arange(n) >= 6) & (torch.arange(n) < 9),
+                      test_mask=torch.arange(n) >= 9)
+    model = Fake()
+    opt = torch.optim.Adam(model.parameters(), lr=0.1)
+    res = T.train(model, data, opt, epochs=50, patience=3)
+    # the output never changes -> val loss never improves after epoch 0 -> stop at epoch 3
+    assert len(res["history"]) == 4 and model.calls == 12
+    assert res["final_test_acc"] == res["history"][0]["test_acc"]

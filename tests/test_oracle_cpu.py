@@ -1,0 +1,155 @@
+"""CPU: the oracle against its pins - the hand-derived KATs,
+the committed golden vectors, the literal-loop forms, and the independent C
+restatement."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+from oracle import c_oracle as CO
+from oracle import sngnn_oracle as O
+from tests.helpers import random_graph
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_kat_appendix_b_both_oracles():
+    kat = json.load(open(os.path.join(GOLDEN, "kat_appendix_b.json")))
+    h = torch.tensor(kat["h"], dtype=torch.float32)
+    ei = torch.tensor(kat["edge_index"], dtype=torch.int64)
+    s = O.edge_cosine(torch.nn.functional.normalize(h, dim=-1), ei)
+    np.testing.assert_allclose(s.numpy(), kat["edge_cosine"], atol=1e-7)
+    for case in kat["cases"]:
+        for use_loop in (False, True):
+            r = O.aggregate_reference(h, ei, add_loops=True, remove_loops=case["remove_loops"],
+                                      top_k=case["top_k"], thr=case["thr"], use_loop=use_loop)
+            np.testing.assert_allclose(r["out"].numpy(), case["out"], atol=1e-6)
+            if case["top_k"] is not None:
+                assert r["sel_src"].tolist() == case["sel_src"]
+        c = CO.aggregate(h.numpy(), ei.numpy(), add_loops=True, remove_loops=case["remove_loops"],
+                         top_k=case["top_k"], thr=case["thr"])
+        np.testing.assert_allclose(c["out"], case["out"], atol=1e-6)
+        if case["top_k"] is not None:
+            assert c["sel_src"].tolist() == case["sel_src"]
+
+
+def test_tie_break_first_occurrence_and_self_loop_last():
+    """Appendix B tie case: identical neighbours -> lower edge position first; with
+    loops kept, a neighbour identical to the target beats the appended self-loop."""
+    h = torch.tensor([[1., 2.], [3., 1.], [3., 1.], [1., 2.]])
+    ei = torch.tensor([[1, 2, 3], [0, 0, 0]])          # 1->0, 2->0 tie; 3 identical to 0
+    r = O.aggregate_reference(h, ei, add_loops=True, remove_loops=False, top_k=2, thr=-1.0)
+    assert r["sel_src"][0].tolist() == [3, 0]           # cos 1.0: node 3 (pos 2) before loop (pos 3)
+    r = O.aggregate_reference(h, ei, add_loops=True, remove_loops=True, top_k=2, thr=-1.0)
+    assert r["sel_src"][0].tolist() == [3, 1]           # then the tie 1 vs 2 -> node 1
+
+
+def test_threshold_compare_is_fp32():
+    # models.py:152,257 compare an fp32 tensor with the Python float thr
+    t = torch.tensor([0.9], dtype=torch.float32)
+    assert bool((t >= 0.9).item()) and not (float(t.item()) >= 0.9 + 1e-8)
+    s = torch.tensor([0.9, 0.5], dtype=torch.float32)
+    w, _ = O.topk_threshold_weights(s, torch.tensor([0, 0]), 2, 0.9)
+    assert w.tolist() == [pytest.approx(0.9), 0.0]
+
+
+def test_mean_divides_by_full_in_degree_and_isolated_rows_are_zero():
+    h = torch.tensor([[1., 0.], [1., 0.], [0., 1.], [5., 5.]])
+    ei = torch.tensor([[1, 2], [0, 0]])
+    r = O.aggregate_reference(h, ei, add_loops=True, remove_loops=True, top_k=1, thr=0.5)
+    assert r["out"][0].tolist() == [0.5, 0.0]           # one kept edge, divided by 2
+    assert r["out"][3].tolist() == [0.0, 0.0]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "agg_*.npz"))))
+def test_golden_vectors_reproduce(path):
+    z = np.load(path)
+    add, rem, k = (int(v) for v in z["params"])
+    k = None if k < 0 else k
+    thr = float(z["thr"][0])
+    h = torch.from_numpy(z["h"]).requires_grad_(True)
+    ei = torch.from_numpy(z["edge_index"])
+    r = O.aggregate_reference(h, ei, add_loops=bool(add), remove_loops=bool(rem), top_k=k, thr=thr)
+    assert torch.equal(r["ei"], torch.from_numpy(z["ei_prime"]))
+    np.testing.assert_array_equal(r["out"].detach().numpy(), z["out"])
+    (r["out"] * torch.from_numpy(z["gout"])).sum().backward()
+    np.testing.assert_allclose(h.grad.numpy(), z["grad_h"], rtol=1e-6, atol=1e-7)
+    c = CO.aggregate(z["h"], z["edge_index"], add_loops=bool(add), remove_loops=bool(rem),
+                     top_k=k, thr=thr)
+    np.testing.assert_array_equal(c["ei"], z["ei_prime"])
+    np.testing.assert_allclose(c["out"], z["out"], rtol=1e-5, atol=2e-6)
+    if k is not None:
+        np.testing.assert_array_equal(r["sel_src"].numpy(), z["sel_src"])
+        np.testing.assert_array_equal(c["sel_src"], z["sel_src"])
+
+
+@settings(max_examples=25, deadline=None)
+@given(n=st.integers(2, 40), e=st.integers(1, 200), c=st.integers(1, 9), k=st.integers(0, 6),
+       thr=st.sampled_from([-1.5, -0.2, 0.0, 0.3, 0.9]), rem=st.booleans(),
+       seed=st.integers(0, 10_000))
+def test_vectorised_scatter_max_equals_literal_loop(n, e, c, k, thr, rem, seed):
+    ei = random_graph(n, e, seed)
+    h = torch.randn(n, c, generator=torch.Generator().manual_seed(seed))
+    h[0] = h[1]
+    a = O.aggregate_reference(h, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+    b = O.aggregate_reference(h, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr,
+                              use_loop=True)
+    assert torch.equal(a["out"], b["out"]) and torch.equal(a["sel_src"], b["sel_src"])
+    # properties of the operator itself
+    deg = torch.bincount(a["ei"][1], minlength=n)
+    assert torch.equal((a["sel_src"] >= 0).sum(1) <= torch.minimum(deg, torch.tensor(k)),
+                       torch.ones(n, dtype=torch.bool))
+    kept = a["weight"] != 0
+    assert bool((a["s"][kept] >= torch.tensor(thr, dtype=torch.float32)).all())
+    assert bool((a["out"][deg == 0] == 0).all())
+
+
+def test_c_oracle_agrees_with_torch_oracle_on_selection_and_sums():
+    ei = random_graph(500, 6000, 3, hubs=((0, 400),))
+    h = torch.randn(500, 12, generator=torch.Generator().manual_seed(0))
+    h[3] = h[4]
+    for k, thr, rem in ((None, 0.0, False), (1, 0.0, True), (8, 0.2, True), (16, -1.5, False)):
+        a = O.aggregate_reference(h, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+        b = CO.aggregate(h.numpy(), ei.numpy(), add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+        np.testing.assert_allclose(b["out"], a["out"].numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(b["s"], a["s"].numpy(), atol=1e-6)
+        if k is not None:
+            np.testing.assert_array_equal(b["sel_src"], a["sel_src"].numpy())
+
+
+def test_adjacency_branch_and_row_min_quirk():
+    n = 30
+    ei = random_graph(n, 150, 1)
+    ei = ei[:, ei[0] >= 2]                               # row.min() == 2 (models.py:125)
+    eip = O.sn_edge_list(ei, n, True, True)
+    W = torch.randn(4, n, generator=torch.Generator().manual_seed(1))
+    b = torch.randn(4, generator=torch.Generator().manual_seed(2))
+    out = O.adj_linear_reference(W, b, eip, n)
+    want = b.repeat(n, 1)
+    m = int(eip[0].min())
+    for s_, d_ in eip.t().tolist():
+        want[s_ - m] += W[:, d_]
+    np.testing.assert_allclose(out.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(CO.adj_linear(W.numpy(), b.numpy(), eip.numpy(), n), out.numpy(),
+                               rtol=1e-5, atol=1e-5)
+
+
+def test_toolbox_small_variants():
+    x = torch.randn(50, 9, generator=torch.Generator().manual_seed(4))
+    y = torch.randint(0, 3, (50,), generator=torch.Generator().manual_seed(5))
+    ei = random_graph(50, 300, 6)
+    S = O.cosine_similarity_dense_small(x)
+    np.testing.assert_allclose(S.numpy(), CO.cosine_dense(x.numpy()), atol=1e-6)
+    sim, mean = O.node_similarity_dense_small(x)
+    assert sim.numel() == 50 * 49
+    np.testing.assert_allclose(float(mean), float((S.sum() - S.diag().sum()) / (50 * 49)), rtol=1e-5)
+    lsim, lmean = O.linked_node_similarity_dense_small(x, ei)
+    np.testing.assert_allclose(lsim.flatten().numpy(), S[ei[0], ei[1]].numpy())
+    w, wm = O.neighborhood_similarity_dense_small(x, ei)
+    assert w.numel() == int(ei[0].max()) + 1
+    cm, _ = O.class_similarity_dense_small(x, y)
+    np.testing.assert_allclose(cm.numpy(), O.class_similarity_dense_large(x, y).numpy(), atol=1e-6)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Tuning aid: time the forward's main kernel per row class and per grid size
+(HIP events inside the library).  Run on the GPU box."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SNGNN_DEBUG_LIVE"] = "1"
+import bench  # noqa: E402
+from sngnn_amd import _lib, ops  # noqa: E402
+from sngnn_amd.graph import Graph  # noqa: E402
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+n, c, ei, x, h, lin = bench.make_rank_inputs("arxiv", 0, 1, 1234, dev)
+g = Graph(ei, n, True, True)
+k, thr = int(os.environ.get("K", 16)), float(os.environ.get("THR", 0.0))
+
+
+def timeit(reps=60):
+    lib.sngnn_profile_enable(1)
+    m, f = C.c_float(), C.c_float()
+    ms = []
+    for _ in range(reps):
+        ops.aggregate_forward(g, h, k, thr)
+        lib.sngnn_profile_last_forward(C.byref(m), C.byref(f))
+        ms.append(m.value)
+    lib.sngnn_profile_enable(0)
+    return float(np.median(ms[10:])) * 1e3, float(np.min(ms[10:])) * 1e3
+
+
+for cls in (7, 1, 2, 4):
+    os.environ["SNGNN_DEBUG_CLASSES"] = str(cls)
+    for bpc in (2, 3, 4, 5, 6, 8):
+        os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
+        med, mn = timeit()
+        print(f"classes={cls} blocks/CU={bpc}: median {med:7.1f} us  min {mn:7.1f} us", flush=True)
