@@ -143,7 +143,7 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][CHUNK];
+    __shared__ int lds[WAVES][WAVE_T];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
@@ -251,8 +251,8 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
     const int e1 = task ? min(od, e0 + CHUNK) : od;
-    int *s_q = lds_wave;                                         // [CHUNK] CSC positions
-    float *s_w = reinterpret_cast<float *>(lds_wave + CHUNK);   // [CHUNK] their cosines
+    int *s_q = lds_wave;                                         // [WAVE_T] CSC positions
+    float *s_w = reinterpret_cast<float *>(lds_wave + WAVE_T);  // their cosines
     int nsel = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][2 * CHUNK];
+    __shared__ int lds[WAVES][2 * WAVE_T];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) s_role_wave<VEC, G, R>(a, b, lw, true);

@@ -63,6 +63,8 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
         const char *c2 = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_DEBUG_BLOCKS_PER_CU") : e_bpc;
         a.dbg_classes = c1 ? atoi(c1) : 7;
         a.dbg_blocks_per_cu = c2 ? atoi(c2) : 0;
+        static const char *e_fin = getenv("SNGNN_INKERNEL_FIN");
+        a.inkernel_fin = e_fin ? atoi(e_fin) : 0;
     }
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
@@ -76,6 +78,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
     a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)
                            : nullptr;
+    a.split_cnt = g->split_cnt;
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     a.nbA = ceil_div(g->n_tasks, WAVES);

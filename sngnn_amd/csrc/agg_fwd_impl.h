@@ -43,9 +43,11 @@ struct FwdArgs {
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int lowbits;                    // bits needed for a row-local edge index
+    int32_t *split_cnt;             // [n_split] arrival counters of the in-kernel finalize
     int nbA, nbB, nbC;          // (unused by the persistent kernel)
     int dbg_classes;            // tuning aid: bit 0 tasks, bit 1 wave rows, bit 2 small rows
     int dbg_blocks_per_cu;      // tuning aid: persistent grid size override (0 = default)
+    int inkernel_fin;           // split rows finalized by their last-arriving task (experimental)
 };
 
 constexpr int LDS_PER_WAVE = 512;   // 32-bit words
@@ -415,6 +417,77 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 }
 
 // ---------------------------------------------------------------------------
+// In-kernel finalize of a split row (top_k <= CAND_MAX_K): executed by the wave
+// whose task was the last of the row to arrive.  Streams the tasks' candidate keys
+// through a wave-level top-k, 96 new keys per step beside the <= 32 champions, then
+// gathers the <= k winners.  Hand-off (guide G16): producers store the keys
+// write-through (sc1) and drain vmcnt before their relaxed agent-scope counter add;
+// the last arriver takes an agent-scope acquire and reads the keys with sc1 loads.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void finalize_split_row(const FwdArgs &a, int p, const int4 d,
+                                                   int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int i = d.x, rs = d.y, deg = d.z;
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const bool emit = a.sel_src != nullptr;
+    unsigned long long *champ = reinterpret_cast<unsigned long long *>(lds_wave);   // [32]
+    const unsigned long long *ck = a.cand_key + (size_t)t0 * a.k;
+    const int n = (t1 - t0) * a.k;
+    int nchamp = 0;
+    for (int base = 0; base < n; base += 96) {
+        // lanes 0..31 of slot 0: champions; the other 96 slots: new candidate keys
+        const int q0 = base + lane - 32, q1 = base + 32 + lane;
+        unsigned long long key0, key1;
+        if (lane < 32) key0 = lane < nchamp ? champ[lane] : 0ull;
+        else key0 = q0 < n ? __hip_atomic_load(ck + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        key1 = q1 < n ? __hip_atomic_load(ck + q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bool k0, k1;
+        wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const int n0 = __popcll(m0);
+        wave_lds_sync();                    // every lane has read its champion
+        if (k0) champ[prefix_popc(m0)] = key0;
+        if (k1) champ[n0 + prefix_popc(m1)] = key1;
+        nchamp = n0 + __popcll(m1);
+        wave_lds_sync();
+    }
+    // kept edges: weights for backward, rank-ordered selection, weighted sum
+    if (lane < nchamp) {
+        const unsigned long long kq = champ[lane];
+        const int idx = key_index(kq);
+        const float sq = key_score(kq);
+        if (a.wsel) a.wsel[rs + idx] = sq;
+        if (emit) {
+            int rk = 0;
+            for (int r = 0; r < nchamp; ++r) rk += champ[r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
+            a.sel_w[(size_t)i * a.k + rk] = sq;
+        }
+    }
+    RowT acc;
+    acc.zero();
+    for (int q0 = 0; q0 < nchamp; q0 += NG) {
+        const int q = q0 + gid;
+        if (q < nchamp) {
+            const unsigned long long kq = champ[q];
+            RowT x;
+            x.load(a.h + (size_t)a.col[rs + key_index(kq)] * a.C, a.C, lg);
+            acc.axpy(key_score(kq), x);
+        }
+    }
+    acc.reduce_across_groups();
+    if (gid == 0) {
+        acc.div((float)deg);
+        acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
@@ -447,12 +520,31 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
         unsigned long long *ck = a.cand_key + (size_t)tq * a.k;
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
         const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-        if (ws.kept0) ck[prefix_popc(m0)] = ws.key0;
-        if (ws.kept1) ck[n0 + prefix_popc(m1)] = ws.key1;
-        if (lane >= nsel && lane < a.k) ck[lane] = 0ull;        // empty slots (k <= 32 < 64)
+        // write-through (sc1) stores: the row's last-arriving wave reads these keys
+        if (ws.kept0) __hip_atomic_store(ck + prefix_popc(m0), ws.key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ws.kept1) __hip_atomic_store(ck + n0 + prefix_popc(m1), ws.key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane >= nsel && lane < a.k)           // empty slots (k <= 32 < 64)
+            __hip_atomic_store(ck + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.wsel) {     // the finalize overwrites the kept edges of the row
-            if (e0 + lane < e1) a.wsel[rs + e0 + lane] = SNGNN_UNSELECTED;
-            if (e0 + 64 + lane < e1) a.wsel[rs + e0 + 64 + lane] = SNGNN_UNSELECTED;
+            float *w = a.wsel + rs + e0;
+            if (lane < e1 - e0) __hip_atomic_store(w + lane, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane + 64 < e1 - e0) __hip_atomic_store(w + lane + 64, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int arrived = -1, ntasks = 0;
+        if (a.inkernel_fin) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are out
+            if (lane == 0)
+                arrived = __hip_atomic_fetch_add(a.split_cnt + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            ntasks = a.split_task0[p + 1] - a.split_task0[p];
+        }
+        if (a.inkernel_fin && arrived == ntasks - 1) {         // wave-uniform: last task of the row
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)                                      // ready for the next launch
+                __hip_atomic_store(a.split_cnt + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_lds_sync();
+            finalize_split_row<VEC, G, R>(a, p, d, lds_wave);
         }
     } else if (!rank) {
         acc.reduce_across_groups();
@@ -767,7 +859,10 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
-    if (a.n_split > 0 && (a.k < 0 || a.k <= CAND_MAX_K)) {
+    const bool any_streaming_split = a.k < 0 || a.k > WAVE_T;   // split rows have deg > WAVE_T
+    if (a.n_split > 0 && a.k <= CAND_MAX_K && !any_streaming_split && a.inkernel_fin) {
+        // every split row is finalized inside k_agg_fwd by its last-arriving task
+    } else if (a.n_split > 0 && (a.k < 0 || a.k <= CAND_MAX_K)) {
         // streaming rows and candidate tournament
         const int max_tasks = ceil_div(max_split_deg, CHUNK);
         const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));

@@ -68,6 +68,7 @@ struct sngnn_graph {
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
+    int32_t *split_cnt = nullptr;     // [n_split] tasks arrived (in-kernel finalize); 0 between launches
     // split sources (out-degree > WAVE_T) = the first n_ssplit slots of sperm
     int32_t *stask_slot = nullptr, *stask_chunk = nullptr;  // [n_stasks]
     int32_t *ssplit_task0 = nullptr;  // [n_ssplit+1]

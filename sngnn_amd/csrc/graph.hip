@@ -289,6 +289,8 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if ((rc = build_tasks(g->rdeg, g->n_split, &g->task_slot, &g->task_chunk, &g->split_task0,
                           &g->split_soff, &g->n_tasks, &g->split_edges)))
         return rc;
+    if ((rc = dev_alloc(&g->split_cnt, g->n_split))) return rc;
+    SN_HIP(hipMemsetAsync(g->split_cnt, 0, (size_t)std::max(g->n_split, 1) * 4, st));
     g->n_ssplit = g->srcs_gt(WAVE_T);
     if ((rc = build_tasks(g->sdeg, g->n_ssplit, &g->stask_slot, &g->stask_chunk, &g->ssplit_task0,
                           nullptr, &g->n_stasks, nullptr)))
@@ -342,7 +344,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
-                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
+                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;

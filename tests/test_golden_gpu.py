@@ -95,3 +95,30 @@ def test_linearity_in_the_message_values(cuda):
     a = ops.aggregate_forward(g, h, 10, 0.2)[0]
     b = ops.aggregate_forward(g, 2.0 * h, 10, 0.2)[0]
     assert torch.equal(b, 2.0 * a)        # power-of-two scaling is exact in fp32
+
+
+def test_alternating_inputs_on_one_graph_never_see_stale_candidates(cuda):
+    """The split-row finalize runs inside the main kernel on keys handed over
+    between waves (possibly on different XCDs).  Stale keys from the previous launch
+    would be invisible with identical inputs, so alternate two inputs on the same
+    graph, L1/L2-warm, and check every launch."""
+    from oracle import c_oracle as CO
+    from sngnn_amd import ops
+    from sngnn_amd.graph import Graph
+    from tests.helpers import random_graph
+    n, C, k = 6000, 40, 16
+    hubs = tuple((i, 129 + 371 * i) for i in range(12)) + ((20, 5999),)
+    ei = random_graph(n, 60000, seed=77, hubs=hubs)
+    gen = torch.Generator().manual_seed(5)
+    hs = [torch.randn(n, C, generator=gen) for _ in range(2)]
+    refs = [CO.aggregate(h.numpy(), ei.numpy(), add_loops=True, remove_loops=True, top_k=k,
+                         thr=0.0) for h in hs]
+    g = Graph(ei.to(cuda), n, True, True)
+    hd = [h.to(cuda) for h in hs]
+    for it in range(40):
+        w = it % 2
+        out, wsel, _, sel_src, _ = ops.aggregate_forward(g, hd[w], k, 0.0, save_for_backward=True,
+                                                         want_selection=True)
+        assert np.array_equal(sel_src.cpu().numpy().astype(np.int64), refs[w]["sel_src"]), it
+        assert_close(out, torch.from_numpy(refs[w]["out"]), what=f"launch {it}")
+        assert int((wsel > -3).sum()) == int((sel_src >= 0).sum())

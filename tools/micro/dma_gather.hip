@@ -1,0 +1,140 @@
+// Micro-benchmark (tuning aid, not product code): gather 160-byte rows (C = 40 fp32)
+// by index from a 27 MB table, (a) straight into registers, (b) with LDS-DMA
+// (global_load_lds_dwordx4) into a per-wave double buffer.  Prints GB/s of useful
+// bytes and a checksum per variant.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr int C = 40, CH = C / 4, RPI = 64 / CH;   // 10 chunks per row, 6 rows per DMA instruction
+
+template <int U>
+__global__ __launch_bounds__(256) void k_reg(const float *__restrict__ h, const int *__restrict__ ids,
+                                             int E, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, gid = lane >> 4, lg = lane & 15;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * 4 * U; base < E; base += nw * 4 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 4 + gid;
+            const int j = e < E ? ids[e] : 0;
+            x[u] = lg < CH ? *reinterpret_cast<const float4 *>(h + (size_t)j * C + lg * 4) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+// NI DMA instructions (RPI rows each) per batch, two LDS buffers per wave
+template <int NI>
+__global__ __launch_bounds__(256) void k_dma(const float *__restrict__ h, const int *__restrict__ ids,
+                                             int E, float *__restrict__ out)
+{
+    constexpr int BR = NI * RPI;                  // rows per batch
+    __shared__ __attribute__((aligned(16))) float lds[4][2][NI * 256];   // 1 KiB per DMA instruction
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gid = lane >> 4, lg = lane & 15;
+    const int wave = blockIdx.x * 4 + wv, nw = gridDim.x * 4;
+    const int r_in = lane / CH, c_in = lane % CH;     // this lane's row / chunk inside one DMA instruction
+    const bool dma_lane = lane < RPI * CH;
+    float4 acc = make_float4(0, 0, 0, 0);
+    int base = wave * BR;
+    auto issue = [&](int b0, int buf) {
+        // ids through SCALAR loads (lgkmcnt): a VGPR-destination load next to LDS-DMA makes
+        // hipcc wait vmcnt(0) before every use and drains the DMA queue
+        const int *idp = ids + __builtin_amdgcn_readfirstlane(b0);
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            int j = 0;
+#pragma unroll
+            for (int r = 0; r < RPI; ++r) {
+                const int e = q * RPI + r;
+                const int jr = idp[min(e, E - 1 - b0)];
+                j = (r_in == r) ? jr : j;
+            }
+            const int e = b0 + q * RPI + r_in;
+            if (dma_lane && e < E)
+                __builtin_amdgcn_global_load_lds(h + (size_t)j * C + c_in * 4,
+                                                 (__attribute__((address_space(3))) void *)&lds[wv][buf][q * 256],
+                                                 16, 0, 0);
+        }
+    };
+    int buf = 0;
+    if (base < E) issue(base, 0);
+    for (; base < E; base += nw * BR) {
+        const int nxt = base + nw * BR;
+        if (nxt < E) issue(nxt, buf ^ 1);
+        // wait for the CURRENT batch only: the NI instructions of the next batch stay in flight
+        if (nxt < E) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nrow = min(BR, E - base);
+        for (int r = gid; r < nrow; r += 4) {
+            if (lg < CH) {
+                const float4 x = *reinterpret_cast<const float4 *>(&lds[wv][buf][(r / RPI) * 256 + ((r % RPI) * CH + lg) * 4]);
+                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // reads done before the buffer is refilled
+        buf ^= 1;
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+int main()
+{
+    const int N = 169343, E = 1163820;
+    std::vector<float> hh((size_t)N * C);
+    std::vector<int> hi(E);
+    srand(1);
+    for (auto &v : hh) v = (rand() % 1000) * 0.001f;
+    for (auto &v : hi) v = (int)(((long long)rand() * 32768 + rand()) % N);
+    float *dh, *dout;
+    int *di;
+    CK(hipMalloc(&dh, hh.size() * 4));
+    CK(hipMalloc(&di, hi.size() * 4));
+    CK(hipMalloc(&dout, 4 * 65536));
+    CK(hipMemcpy(dh, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(di, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto run = [&](const char *name, auto launch) {
+        float best = 1e9f, sum = 0;
+        for (int it = 0; it < 30; ++it) {
+            CK(hipMemset(dout, 0, 4 * 65536));
+            CK(hipEventRecord(e0));
+            launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 5 && ms < best) best = ms;
+            { std::vector<float> ho(65536); CK(hipMemcpy(ho.data(), dout, 4 * 65536, hipMemcpyDeviceToHost)); double t = 0; for (float v : ho) t += v; sum = (float)t; }
+        }
+        printf("%-28s best %7.1f us  %7.1f GB/s useful   checksum %.3f\n", name, best * 1e3,
+               (double)E * C * 4 / (best * 1e-3) / 1e9, sum);
+        fflush(stdout);
+    };
+    for (int bpc : {4, 6, 8}) {
+        const int grid = 256 * bpc;
+        printf("-- %d blocks/CU\n", bpc);
+        run("reg U=4", [&] { k_reg<4><<<grid, 256>>>(dh, di, E, dout); });
+        run("reg U=8", [&] { k_reg<8><<<grid, 256>>>(dh, di, E, dout); });
+        run("reg U=16", [&] { k_reg<16><<<grid, 256>>>(dh, di, E, dout); });
+        run("dma NI=2 (12 rows/batch)", [&] { k_dma<2><<<grid, 256>>>(dh, di, E, dout); });
+        run("dma NI=4 (24 rows/batch)", [&] { k_dma<4><<<grid, 256>>>(dh, di, E, dout); });
+        if (bpc <= 6) run("dma NI=6 (36 rows/batch)", [&] { k_dma<6><<<grid, 256>>>(dh, di, E, dout); });
+    }
+    return 0;
+}
