@@ -1,0 +1,152 @@
+"""Sim-GFA toolbox on the GPU: the dense-feature statistics of SimGFAToolbox/dense.py
+under the reference's function names and return conventions, computed by
+libsngnn_hip (no Python row / block loops, no N x N temporaries unless the function's
+contract is to return them).  Inputs are GPU tensors; there is no CPU path.
+
+Not covered: SimGFAToolbox/sparse.py (scipy CSC on the host - stays the comparison
+baseline) and plot.py.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _x(x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise ValueError("x must live on the GPU (there is no CPU path)")
+    if x.dim() != 2:
+        raise ValueError("x must be [N, F]")
+    return x.to(torch.float32).contiguous()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def cosine_similarity_dense_small(x: torch.Tensor) -> torch.Tensor:
+    """dense.py:138-141: S = normalize(x) @ normalize(x).T, [N, N] (fp32 MFMA)."""
+    x = _x(x)
+    n, f = x.shape
+    s = torch.empty((n, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sngnn_cosine_dense(x.data_ptr(), n, f, s.data_ptr(), _stream(x))
+    _lib.check(rc, "sngnn_cosine_dense")
+    return s
+
+
+def edge_cosine(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+    """Per-edge cosine <n[ei[0]], n[ei[1]]> of raw feature rows, [E]."""
+    x = _x(x)
+    ei = edge_index.to(torch.int64).contiguous()
+    if ei.device != x.device:
+        raise ValueError("x and edge_index must be on the same device")
+    e = ei.size(1)
+    sim = torch.empty(e, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sngnn_edge_cosine(x.data_ptr(), x.size(0), x.size(1), ei.data_ptr(), e,
+                                           sim.data_ptr(), _stream(x))
+    _lib.check(rc, "sngnn_edge_cosine")
+    return sim
+
+
+def class_block_sums(x: torch.Tensor, y: torch.Tensor, n_classes: int):
+    """(sums [c, c] f64 of S over every class pair, diagonal sum f64) without forming S:
+    sum_{i in A, j in B} <n_i, n_j> = <sum_A n, sum_B n>."""
+    x = _x(x)
+    y32 = y.to(device=x.device, dtype=torch.int32).contiguous()
+    sums = torch.zeros((n_classes, n_classes), dtype=torch.float64, device=x.device)
+    diag = torch.zeros(1, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().sngnn_cosine_class_sums(x.data_ptr(), x.size(0), x.size(1),
+                                                 y32.data_ptr(), n_classes, sums.data_ptr(),
+                                                 diag.data_ptr(), _stream(x))
+    _lib.check(rc, "sngnn_cosine_class_sums")
+    return sums, diag
+
+
+def node_similarity_dense_small(x):
+    """dense.py:144-149: every off-diagonal entry of S (row-major) and their mean."""
+    s = cosine_similarity_dense_small(x)
+    n = s.size(0)
+    mask = ~torch.eye(n, dtype=torch.bool, device=s.device)
+    sim = s[mask]
+    return sim, torch.mean(sim)
+
+
+def node_similarity_dense_large_parted(x, corrected: bool = False):
+    """dense.py:9-30 without the 1000-row block loops.  The reference's last line
+    has an operator-precedence slip, ``(sum - N) / (N - 1) * N`` (dense.py:28); that
+    value is returned by default, ``corrected=True`` gives the mean over the
+    N (N - 1) off-diagonal pairs."""
+    x = _x(x)
+    n = x.size(0)
+    sums, diag = class_block_sums(x, torch.zeros(n, dtype=torch.int32, device=x.device), 1)
+    total = sums[0, 0]
+    if corrected:      # the true diagonal: all-zero rows contribute 0, not 1
+        return None, ((total - diag[0]) / (n * (n - 1))).to(torch.float32)
+    return None, ((total - n) / (n - 1) * n).to(torch.float32)
+
+
+def linked_node_similarity_dense_small(x, edge_index):
+    """dense.py:152-155: S[ei[0], ei[1]] - computed per edge, S is never formed."""
+    sim = edge_cosine(x, edge_index)
+    return sim.reshape(-1, 1), torch.mean(sim)
+
+
+def linked_node_similarity_dense_large(x, edge_index):
+    """dense.py:33-62: the same values listed by source node (edges sorted by
+    (src, dst) as PyG's sort_edge_index does)."""
+    ei = _sort_edge_index(edge_index)
+    sim = edge_cosine(x, ei)
+    return sim.reshape(-1, 1), torch.mean(sim.reshape(-1, 1))
+
+
+def _sort_edge_index(edge_index):
+    n = int(edge_index.max()) + 1 if edge_index.numel() else 1
+    key = edge_index[0] * n + edge_index[1]
+    return edge_index[:, torch.argsort(key, stable=True)]
+
+
+def _mean_by_source(sim, src, length):
+    tot = torch.zeros(length, dtype=torch.float64, device=sim.device)
+    tot.index_add_(0, src, sim.double())
+    cnt = torch.bincount(src, minlength=length)
+    return tot, cnt
+
+
+def neighborhood_similarity_dense_small(x, edge_index):
+    """dense.py:158-164: per-edge cosine, mean grouped by SOURCE (edge_index[0]);
+    output length max(src) + 1 like torch_scatter.scatter_mean without dim_size."""
+    sim = edge_cosine(x, edge_index)
+    src = edge_index[0].to(sim.device)
+    length = int(src.max()) + 1 if src.numel() else 0
+    tot, cnt = _mean_by_source(sim, src, length)
+    weight = (tot / cnt.clamp(min=1)).to(torch.float32)
+    return weight, torch.mean(weight)
+
+
+def neighborhood_similarity_dense_large(x, edge_index):
+    """dense.py:65-101: one value per node (0 for a node without out-edges) and the
+    mean over ALL nodes."""
+    n = x.size(0)
+    sim = edge_cosine(x, edge_index)
+    tot, cnt = _mean_by_source(sim, edge_index[0].to(sim.device), n)
+    per_node = torch.where(cnt > 0, tot / cnt.clamp(min=1), torch.zeros_like(tot)).to(torch.float32)
+    return per_node.reshape(-1, 1), per_node.sum() / n
+
+
+def class_similarity_dense_small(x, y):
+    """dense.py:167-179: mean of S over every ordered class pair and the mean of that
+    matrix (classes are ``0 .. len(unique(y)) - 1`` as in the reference)."""
+    n_classes = len(torch.unique(y))
+    sums, _ = class_block_sums(x, y, n_classes)
+    cnt = torch.bincount(y.to(sums.device).long(), minlength=n_classes).double()
+    mat = (sums / (cnt[:, None] * cnt[None, :])).to(torch.float32)
+    return mat, torch.mean(mat)
+
+
+def class_similarity_dense_large(x, y):
+    """dense.py:104-130: block sums / block sizes (== the small variant's matrix)."""
+    return class_similarity_dense_small(x, y)[0]

@@ -1,0 +1,97 @@
+"""GPU parity of the Sim-GFA toolbox kernels against the oracle's restatement of
+SimGFAToolbox/dense.py (small variants are the semantic spec)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sngnn_oracle as O
+from tests.helpers import random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def bow(n, f, seed, density=0.05):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, f, generator=g) < density).float()
+    x[3] = x[4]
+    x[7] = 0.0                     # an all-zero row normalises to 0
+    return x
+
+
+@pytest.mark.parametrize("n,f", [(50, 9), (300, 257), (515, 1000), (129, 16)])
+def test_cosine_dense_mfma(cuda, n, f):
+    from sngnn_amd import toolbox as T
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(n))
+    x[2] = 0.0
+    S = T.cosine_similarity_dense_small(x.to(cuda)).cpu()
+    ref = O.cosine_similarity_dense_small(x)
+    assert S.shape == ref.shape
+    assert (S - ref).abs().max() < 2e-6
+    # asymmetric data check of the tile/epilogue indexing: S[i, j] really is rows i, j
+    i, j = 1, n - 2
+    want = torch.dot(x[i], x[j]) / (x[i].norm() * x[j].norm())
+    assert abs(S[i, j] - want) < 2e-6 and abs(S[j, i] - want) < 2e-6
+
+
+def test_node_and_linked_similarity(cuda):
+    from sngnn_amd import toolbox as T
+    n, f = 200, 120
+    x = bow(n, f, 1)
+    ei = random_graph(n, 1500, 2)
+    sim, mean = T.node_similarity_dense_small(x.to(cuda))
+    rsim, rmean = O.node_similarity_dense_small(x)
+    assert sim.shape == rsim.shape and (sim.cpu() - rsim).abs().max() < 2e-6
+    assert abs(float(mean) - float(rmean)) < 1e-6
+    lsim, lmean = T.linked_node_similarity_dense_small(x.to(cuda), ei.to(cuda))
+    rl, rlm = O.linked_node_similarity_dense_small(x, ei)
+    assert lsim.shape == rl.shape and (lsim.cpu() - rl).abs().max() < 2e-6
+    assert abs(float(lmean) - float(rlm)) < 1e-6
+    # the "large" mean: documented precedence quirk and the corrected value
+    _, q = T.node_similarity_dense_large_parted(x.to(cuda))
+    _, qr = O.node_similarity_dense_large_parted(x)
+    assert abs(float(q) - float(qr)) <= 1e-4 * abs(float(qr))
+    _, c = T.node_similarity_dense_large_parted(x.to(cuda), corrected=True)
+    assert abs(float(c) - float(rmean)) < 1e-5
+
+
+def test_neighborhood_similarity(cuda):
+    from sngnn_amd import toolbox as T
+    n, f = 150, 64
+    x = bow(n, f, 3, 0.1)
+    ei = random_graph(n, 900, 4)
+    ei = ei[:, ei[0] < n - 5]                  # the last nodes have no out-edge
+    w, wm = T.neighborhood_similarity_dense_small(x.to(cuda), ei.to(cuda))
+    rw, rwm = O.neighborhood_similarity_dense_small(x, ei)
+    assert w.shape == rw.shape and (w.cpu() - rw).abs().max() < 2e-6
+    assert abs(float(wm) - float(rwm)) < 1e-6
+    per_node, mean_all = T.neighborhood_similarity_dense_large(x.to(cuda), ei.to(cuda))
+    assert per_node.shape == (n, 1)
+    full = torch.zeros(n)
+    full[: rw.numel()] = rw
+    assert (per_node.cpu().flatten() - full).abs().max() < 2e-6
+    assert abs(float(mean_all) - float(full.sum() / n)) < 1e-6
+
+
+@pytest.mark.parametrize("n,f,c", [(120, 33, 3), (700, 300, 5), (257, 1000, 7)])
+def test_class_similarity_without_forming_S(cuda, n, f, c):
+    from sngnn_amd import toolbox as T
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(c))
+    y = torch.randint(0, c, (n,), generator=torch.Generator().manual_seed(n))
+    y[:c] = torch.arange(c)                        # every class present
+    mat, mean = T.class_similarity_dense_small(x.to(cuda), y.to(cuda))
+    rmat, rmean = O.class_similarity_dense_small(x, y)
+    assert mat.shape == rmat.shape
+    # block means are O(1/sqrt(F |A||B|)) small: compare on the scale of the largest entry
+    tol = 2e-5 * float(rmat.abs().max())
+    assert (mat.cpu() - rmat).abs().max() < tol
+    assert (T.class_similarity_dense_large(x.to(cuda), y.to(cuda)).cpu() - rmat).abs().max() < tol
+
+
+def test_toolbox_argument_errors(cuda):
+    from sngnn_amd import toolbox as T
+    x = torch.randn(10, 4)
+    with pytest.raises(ValueError, match="GPU"):
+        T.cosine_similarity_dense_small(x)
+    bad = torch.tensor([[0, 1], [2, 99]])
+    with pytest.raises(ValueError, match="outside"):
+        T.edge_cosine(x.to(cuda), bad.to(cuda))
