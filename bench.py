@@ -209,8 +209,12 @@ def main():
         result["fwd_bwd_ms"] = (time.perf_counter() - t0) / reps * 1e3
         if not args.no_epoch:
             from sngnn_amd.train import epoch_time_ms
+            # reference-style eager loop (train.py:73-143) and the same epoch replayed
+            # from a HIP graph (sngnn_amd/train.py:GraphedEpoch)
+            result["epoch_ms_eager"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k,
+                                                     args.thr, seed=args.seed)
             result["epoch_ms"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
-                                               seed=args.seed)
+                                               seed=args.seed, graphed=True)
         if not args.no_cpu_baseline:
             h_cpu, ei_cpu = h_local.cpu(), ei.cpu()
             res, cpu_dt = cpu_baseline(h_cpu, ei_cpu, args.top_k, args.thr, reps=3)

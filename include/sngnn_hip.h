@@ -188,6 +188,34 @@ int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0, int C,
                               float *dwt, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
+ * The callers on either side of the aggregation inside one training epoch
+ * (SURVEY.md 8f rank 1): classification head and self.lin's weight gradient.
+ * ------------------------------------------------------------------------ */
+/*
+ * Replaces: F.log_softmax (models.py:86,211,303) + F.nll_loss on the masked rows +
+ * the accuracy count (train.py:81-84, 98-102, 112-116) by one pass over the logits.
+ *   logits   dev f32 [N, C]     the last conv's output (before log_softmax)
+ *   y        dev i64 [N]        labels
+ *   row_mask dev u8  [N]        1 for the rows of the split (train/val/test mask)
+ *   n_masked                    number of ones in row_mask (the mean's denominator)
+ *   grad_logits dev f32 [N, C] or NULL: d loss / d logits (zero rows outside the mask)
+ *   loss_and_correct dev f32 [2]: mean NLL over the masked rows, number of correct rows
+ *   workspace: sngnn_head_workspace_bytes(N) bytes.  Deterministic (fixed-order sums).
+ */
+int64_t sngnn_head_workspace_bytes(int64_t N);
+int sngnn_head_nll(const float *logits, const int64_t *y, const unsigned char *row_mask,
+                   int64_t N, int C, int64_t n_masked, float *grad_logits,
+                   float *loss_and_correct, void *workspace, void *stream);
+/*
+ * Replaces: autograd of self.lin w.r.t. its parameters (models.py:121,237,324):
+ *   grad_weight [C, F] = grad_out^T [C, N] . x [N, F],  grad_bias [C] = sum_i grad_out[i]
+ * (grad_bias may be NULL).  workspace: sngnn_linear_wgrad_workspace_bytes(N, C, F).
+ */
+int64_t sngnn_linear_wgrad_workspace_bytes(int64_t N, int C, int F);
+int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t N, int C, int F,
+                       float *grad_weight, float *grad_bias, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------
  * Sim-GFA toolbox (SimGFAToolbox/dense.py).
  * ------------------------------------------------------------------------ */
 /* dense.py:138-141: S = normalize(x) normalize(x)^T, dev f32 [N, N]. */

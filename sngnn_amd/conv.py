@@ -61,7 +61,7 @@ class SNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph = _graph_for(x, edge_index, True, False)
-        h = self.lin(x)
+        h = ops.linear(x, self.lin)
         out = _aggregate(h, graph, None, 0.0)
         if self.bias is not None:
             out = out + self.bias
@@ -95,7 +95,7 @@ class SNConv_plus(nn.Module):
 
     def forward(self, x, edge_index):
         graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h = self.lin(x)
+        h = ops.linear(x, self.lin)
         out = _aggregate(h, graph, int(self.top_k), float(self.thr))
         if self.bias is not None:
             out = out + self.bias
@@ -173,7 +173,7 @@ class SNConv_plus_plus(nn.Module):
             raise NotImplementedError("SNConv_plus_plus is single-GPU for now: the adjacency "
                                       "branch needs the edges partitioned by source as well")
         graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h = self.lin(x)
+        h = ops.linear(x, self.lin)
         out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         out_1 = ops.aggregate(h, graph, int(self.top_k), float(self.thr))
         out = self.beta * out_0 + (1 - self.beta) * out_1

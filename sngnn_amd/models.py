@@ -19,7 +19,9 @@ class _Stack(nn.Module):
             for bn in self.bns:
                 bn.reset_parameters()
 
-    def forward(self, data):
+    def forward_logits(self, data):
+        """Everything before the final ``log_softmax`` (lets a trainer fuse the
+        classification head, sngnn_amd/train.py:GraphedEpoch)."""
         x, edge_index = data.x, data.edge_index
         for i, lin in enumerate(self.lins[:-1]):
             x = lin(x, edge_index)
@@ -27,8 +29,10 @@ class _Stack(nn.Module):
             if self.bn:
                 x = self.bns[i](x)
             x = self.dropout(x)
-        x = self.lins[-1](x, edge_index)
-        return F.log_softmax(x, dim=1)
+        return self.lins[-1](x, edge_index)
+
+    def forward(self, data):
+        return F.log_softmax(self.forward_logits(data), dim=1)
 
     def _build(self, conv, in_channels, hidden_channels, out_channels, num_layers):
         self.lins = nn.ModuleList()

@@ -154,3 +154,98 @@ class _AdjLinear(torch.autograd.Function):
 
 def adj_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], graph: Graph) -> torch.Tensor:
     return _AdjLinear.apply(weight, bias, graph)
+
+
+# ---------------------------------------------------------------------------
+# Callers on either side of the aggregation
+# ---------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(key, nbytes, device):
+    ws = _ws_cache.get((key, str(device)))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[(key, str(device))] = ws
+    return ws
+
+
+class _Linear(torch.autograd.Function):
+    """``self.lin(x)`` (models.py:121,237,324): rocBLAS forward, hand-written weight
+    gradient (the [C, F] result reduces over all N rows - a shape the BLAS heuristic
+    handles poorly), grad_x through rocBLAS only when x needs it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g.mm(weight)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            lib = _lib.load()
+            xc = x.contiguous()
+            n, f = xc.shape
+            c = g.size(1)
+            gw = torch.empty((c, f), dtype=torch.float32, device=g.device)
+            gb = torch.empty(c, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            ws = _workspace("wgrad", lib.sngnn_linear_wgrad_workspace_bytes(n, c, f), g.device)
+            with torch.cuda.device(g.device):
+                rc = lib.sngnn_linear_wgrad(g.data_ptr(), xc.data_ptr(), n, c, f, gw.data_ptr(),
+                                            _lib.ptr(gb), ws.data_ptr(), _stream(g.device))
+            _lib.check(rc, "sngnn_linear_wgrad")
+        return gx, gw, gb
+
+
+def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
+    """Apply ``lin`` with the hand-written weight gradient (fp32 GPU tensors), or
+    plain ``lin(x)`` for anything else."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32:
+        return _Linear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
+class _HeadNLL(torch.autograd.Function):
+    """mean NLL of log_softmax(logits) over the masked rows; also returns the number
+    of correctly classified masked rows (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, logits, y, row_mask_u8, n_masked):
+        lib = _lib.load()
+        z = logits.contiguous()
+        n, c = z.shape
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(z) if need_grad else None
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        ws = _workspace("head", lib.sngnn_head_workspace_bytes(n), z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.sngnn_head_nll(z.data_ptr(), y.data_ptr(), row_mask_u8.data_ptr(), n, c,
+                                    int(n_masked), _lib.ptr(grad), out.data_ptr(), ws.data_ptr(),
+                                    _stream(z.device))
+        _lib.check(rc, "sngnn_head_nll")
+        if need_grad:
+            ctx.save_for_backward(grad)
+        loss, correct = out[0], out[1]
+        ctx.mark_non_differentiable(correct)
+        return loss, correct
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_correct):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss, None, None, None
+
+
+def head_nll(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int):
+    """(loss, n_correct) of the masked rows: fused log_softmax + nll_loss + accuracy
+    (models.py:86 + train.py:81-84).  ``row_mask_u8``: uint8 [N]."""
+    if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
+        raise ValueError("logits must be a float32 GPU tensor [N, C]")
+    if y.dtype != torch.int64 or row_mask_u8.dtype != torch.uint8:
+        raise ValueError("y must be int64 and row_mask uint8")
+    return _HeadNLL.apply(logits, y.contiguous(), row_mask_u8.contiguous(), n_masked)

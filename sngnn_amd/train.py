@@ -75,12 +75,127 @@ def train(model, data, optimizer, epochs: int, patience: int, log=None) -> Dict:
                 mean_epoch_s=sum(dur) / max(len(dur), 1))
 
 
+class GraphedEpoch:
+    """One full epoch (train step + validation + test passes) captured in a HIP graph.
+
+    The reference loop (train.py:134-143) spends most of an epoch on launch latency
+    and on host synchronisations: boolean-mask indexing (a ``nonzero`` each),
+    ``.item()`` after every step (train.py:83,100,114).  Here the masks become index
+    tensors once, the six metrics stay on the device, Adam runs ``capturable`` and the
+    whole epoch - 3 forwards, 1 backward, the optimizer step - replays as one graph;
+    the host reads one 6-float tensor per epoch (needed for early stopping on the
+    validation loss, train.py:150-158).  Same arithmetic as :func:`train_step` /
+    :func:`eval_step`.
+    """
+
+    def __init__(self, model, data, optimizer, warmup: int = 3):
+        self.model, self.data, self.opt = model, data, optimizer
+        dev = data.x.device
+        from . import ops
+        self._ops = ops
+        self.mask = {k: getattr(data, k + "_mask").to(torch.uint8).contiguous()
+                     for k in ("train", "val", "test")}
+        self.count = {k: max(int(m.sum()), 1) for k, m in self.mask.items()}
+        self.fused = hasattr(model, "forward_logits")
+        self.metrics = torch.zeros(6, dtype=torch.float32, device=dev)
+        for g in optimizer.param_groups:
+            g["capturable"] = True
+        self._materialise_adam_state()
+        with torch.no_grad():            # library handles / workspaces exist before the capture
+            model.eval()
+            model(data)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # allocator / lazy-init warm-up outside the capture
+                self._epoch()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._epoch()
+
+    def _materialise_adam_state(self):
+        """Adam creates its state lazily inside the first ``step()``; inside a capture
+        those zero-fills would be replayed every epoch.  Create it up front (what
+        torch.optim.Adam._init_group does for capturable groups)."""
+        if not isinstance(self.opt, (torch.optim.Adam, torch.optim.AdamW)):
+            return
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                st = self.opt.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if group.get("amsgrad", False):
+                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _loss(self, which):
+        """(mean NLL, correct count) on one mask: the fused head kernel on the model's
+        logits, or the reference expressions for a model without ``forward_logits``."""
+        if self.fused:
+            return self._ops.head_nll(self.model.forward_logits(self.data), self.data.y,
+                                      self.mask[which], self.count[which])
+        out = self.model(self.data)
+        m = self.mask[which].bool()
+        return (F.nll_loss(out[m], self.data.y[m]),
+                (out[m].max(dim=1)[1] == self.data.y[m]).sum().float())
+
+    def _epoch(self):
+        self.model.train()
+        self.opt.zero_grad(set_to_none=False)
+        loss, correct = self._loss("train")
+        loss.backward()
+        self.opt.step()
+        with torch.no_grad():
+            self.metrics[0] = loss.detach()
+            self.metrics[1] = correct
+            self.model.eval()
+            for slot, which in ((2, "val"), (4, "test")):
+                l, c = self._loss(which)
+                self.metrics[slot] = l
+                self.metrics[slot + 1] = c
+
+    def run(self) -> Dict[str, float]:
+        """Replay one epoch; returns the metrics (one host read)."""
+        self.graph.replay()
+        m = self.metrics.tolist()
+        return dict(train_loss=m[0], train_acc=m[1] / self.count["train"], val_loss=m[2],
+                    val_acc=m[3] / self.count["val"], test_loss=m[4],
+                    test_acc=m[5] / self.count["test"])
+
+
+def train_graphed(model, data, optimizer, epochs: int, patience: int) -> Dict:
+    """:func:`train` with the epoch replayed from a HIP graph (same early stopping).
+    The capture warm-up runs real optimizer steps, so pass a freshly initialised
+    model when the trajectory must match :func:`train` epoch for epoch."""
+    ge = GraphedEpoch(model, data, optimizer, warmup=0)
+    dur, history = [], []
+    final_test_acc, bad_counter, smallest_val_loss = 0.0, 0, float("inf")
+    for epoch in range(epochs):
+        t0 = time.time()
+        rec = ge.run()
+        dur.append(time.time() - t0)
+        rec.update(epoch=epoch, time_s=sum(dur) / len(dur))
+        history.append(rec)
+        if rec["val_loss"] < smallest_val_loss:
+            smallest_val_loss, final_test_acc, bad_counter = rec["val_loss"], rec["test_acc"], 0
+        else:
+            bad_counter += 1
+        if bad_counter == patience:
+            break
+    return dict(final_test_acc=final_test_acc, history=history,
+                mean_epoch_s=sum(dur) / max(len(dur), 1))
+
+
 def epoch_time_ms(workload: str, x: torch.Tensor, edge_index: torch.Tensor, n: int,
                   classes: int, top_k: int, thr: float, *, seed: int = 1234, lr: float = 0.01,
-                  weight_decay: float = 5e-4, epochs: int = 30, warmup: int = 5) -> float:
+                  weight_decay: float = 5e-4, epochs: int = 30, warmup: int = 5,
+                  graphed: bool = False) -> float:
     """Mean wall time of train + validation + test steps (3 forwards, 1 backward,
     Adam) of a 1-layer SNGNN_Plus, device-synchronised - the quantity train.py:135-143
-    logs as ``Time(s)``."""
+    logs as ``Time(s)``.  ``graphed`` replays the epoch from a HIP graph."""
     from .models import SNGNN_Plus
     gen = torch.Generator().manual_seed(seed)
     y = torch.randint(0, classes, (n,), generator=gen).to(x.device)
@@ -92,10 +207,14 @@ def epoch_time_ms(workload: str, x: torch.Tensor, edge_index: torch.Tensor, n: i
     model = SNGNN_Plus(x.size(1), 32, classes, n, 1, top_k, thr, 1, 0.0).to(x.device)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
 
-    def one_epoch():
-        train_step(model, data, opt)
-        eval_step(model, data, data.val_mask)
-        eval_step(model, data, data.test_mask)
+    if graphed:
+        ge = GraphedEpoch(model, data, opt)
+        one_epoch = ge.run
+    else:
+        def one_epoch():
+            train_step(model, data, opt)
+            eval_step(model, data, data.val_mask)
+            eval_step(model, data, data.test_mask)
 
     for _ in range(warmup):
         one_epoch()

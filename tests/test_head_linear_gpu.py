@@ -1,0 +1,56 @@
+"""GPU: the fused classification head and the Linear weight-gradient kernel against
+plain PyTorch fp32 (floating-point kernels: a torch reference is the checker here)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,c", [(1000, 5), (5000, 40), (777, 47), (300, 130)])
+def test_head_matches_log_softmax_nll_and_accuracy(cuda, n, c):
+    from sngnn_amd import ops
+    g = torch.Generator().manual_seed(n)
+    z = (torch.randn(n, c, generator=g) * 3).to(cuda).requires_grad_(True)
+    y = torch.randint(0, c, (n,), generator=g).to(cuda)
+    mask = (torch.rand(n, generator=g) < 0.6).to(cuda)
+    z_ref = z.detach().clone().requires_grad_(True)
+    logp = F.log_softmax(z_ref, dim=1)
+    loss_ref = F.nll_loss(logp[mask], y[mask])
+    loss_ref.backward()
+    corr_ref = int((logp[mask].max(dim=1)[1] == y[mask]).sum())
+    loss, corr = ops.head_nll(z, y, mask.to(torch.uint8), int(mask.sum()))
+    (loss * 1.0).backward()
+    assert abs(float(loss) - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref)))
+    assert int(corr) == corr_ref
+    assert (z.grad - z_ref.grad).abs().max() <= 1e-6 * max(1e-3, float(z_ref.grad.abs().max())) + 1e-9
+    assert bool((z.grad[~mask] == 0).all())
+    # no-grad evaluation path gives the same numbers
+    with torch.no_grad():
+        l2, c2 = ops.head_nll(z.detach(), y, mask.to(torch.uint8), int(mask.sum()))
+    assert float(l2) == float(loss) and int(c2) == corr_ref
+
+
+@pytest.mark.parametrize("n,f,c", [(3000, 128, 40), (2277, 2325, 5), (1000, 33, 47), (513, 200, 70)])
+def test_linear_wgrad_matches_autograd(cuda, n, f, c):
+    from sngnn_amd import ops
+    g = torch.Generator().manual_seed(f)
+    x = torch.randn(n, f, generator=g).to(cuda)
+    lin = torch.nn.Linear(f, c).to(cuda)
+    gout = torch.randn(n, c, generator=g).to(cuda)
+    (lin(x) * gout).sum().backward()
+    gw_ref, gb_ref = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    out = ops.linear(x, lin)
+    assert torch.equal(out, lin(x))
+    (out * gout).sum().backward()
+    tol_w = 2e-5 * float(gw_ref.abs().max())
+    assert (lin.weight.grad - gw_ref).abs().max() <= tol_w
+    assert (lin.bias.grad - gb_ref).abs().max() <= 2e-5 * float(gb_ref.abs().max())
+    # x that needs a gradient (hidden layers)
+    xr = x.clone().requires_grad_(True)
+    lin.zero_grad()
+    (ops.linear(xr, lin) * gout).sum().backward()
+    xr2 = x.clone().requires_grad_(True)
+    (lin(xr2) * gout).sum().backward()
+    assert (xr.grad - xr2.grad).abs().max() <= 1e-4 * float(xr2.grad.abs().max())
