@@ -34,11 +34,11 @@ __device__ __forceinline__ int wmin_i(int v)
     return v;
 }
 
-constexpr int HEAD_ROWS_PER_BLOCK = 64;    // 4 waves x 16 rows
+constexpr int HEAD_ROWS_PER_BLOCK = 16;    // 4 waves x 4 rows
 
-// One wave per row (lanes stride the C logits).  sel[i] != 0 marks the rows of the
-// mask.  Per-block partial (loss sum, correct count) go to part[]; grad (optional,
-// dense [N, C]) = (softmax - onehot) * scale on masked rows, 0 elsewhere.
+// One wave per row.  sel[i] != 0 marks the rows of the mask.  Per-block partial (loss
+// sum, correct count) go to part[]; grad (optional, dense [N, C]) = (softmax - onehot)
+// * scale on masked rows, 0 elsewhere.  C <= 64: the row lives in one register per lane.
 __global__ __launch_bounds__(256) void k_head(const float *__restrict__ z, const int64_t *__restrict__ y,
                                               const unsigned char *__restrict__ sel, int64_t N, int C,
                                               float scale, float *__restrict__ grad,
@@ -47,37 +47,64 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ z, const
     __shared__ float s_loss[4], s_corr[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss = 0.f, corr = 0.f;
-    for (int r = 0; r < HEAD_ROWS_PER_BLOCK / 4; ++r) {
-        const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS_PER_BLOCK + wave * (HEAD_ROWS_PER_BLOCK / 4) + r;
-        if (i >= N) break;
-        const bool on = sel[i] != 0;
-        if (!on) {
-            if (grad) for (int c = lane; c < C; c += 64) grad[i * C + c] = 0.f;
-            continue;
+    constexpr int RPW = HEAD_ROWS_PER_BLOCK / 4;
+    const int64_t i0 = (int64_t)blockIdx.x * HEAD_ROWS_PER_BLOCK + wave * RPW;
+    if (C <= 64) {
+        float v[RPW];
+        int yi[RPW];
+        bool on[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {             // all loads first
+            const int64_t i = i0 + r;
+            on[r] = i < N && sel[i] != 0;
+            v[r] = (on[r] && lane < C) ? z[i * C + lane] : -INFINITY;
+            yi[r] = on[r] ? (int)y[i] : 0;
         }
-        const float *zi = z + i * C;
-        float mx = -INFINITY;
-        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zi[c]);
-        mx = wmax(mx);
-        float se = 0.f;
-        int arg = C;
-        for (int c = lane; c < C; c += 64) {
-            const float v = zi[c];
-            se += expf(v - mx);
-            if (v == mx) arg = min(arg, c);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= N) break;
+            if (!on[r]) {
+                if (grad && lane < C) grad[i * C + lane] = 0.f;
+                continue;
+            }
+            const float mx = wmax(v[r]);
+            const float e = lane < C ? expf(v[r] - mx) : 0.f;
+            const float se = wsum(e);
+            const int arg = wmin_i((lane < C && v[r] == mx) ? lane : C);
+            const float zy = __shfl(v[r], yi[r], 64);
+            loss += -(zy - mx - logf(se));
+            corr += (arg == yi[r]) ? 1.f : 0.f;
+            if (grad && lane < C) grad[i * C + lane] = e * (scale / se) - (lane == yi[r] ? scale : 0.f);
         }
-        se = wsum(se);
-        arg = wmin_i(arg);                          // first maximum, like torch.max on the CPU
-        const int yi = (int)y[i];
-        const float lse = logf(se);
-        loss += -(zi[yi] - mx - lse);
-        corr += (arg == yi) ? 1.f : 0.f;
-        if (grad) {
-            const float inv = scale / se;
+    } else {
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t i = i0 + r;
+            if (i >= N) break;
+            if (sel[i] == 0) {
+                if (grad) for (int c = lane; c < C; c += 64) grad[i * C + c] = 0.f;
+                continue;
+            }
+            const float *zi = z + i * C;
+            float mx = -INFINITY;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zi[c]);
+            mx = wmax(mx);
+            float se = 0.f;
+            int arg = C;
             for (int c = lane; c < C; c += 64) {
-                float p = expf(zi[c] - mx) * inv;
-                if (c == yi) p -= scale;
-                grad[i * C + c] = p;
+                const float t = zi[c];
+                se += expf(t - mx);
+                if (t == mx) arg = min(arg, c);
+            }
+            se = wsum(se);
+            arg = wmin_i(arg);                      // first maximum, like torch.max on the CPU
+            const int yy = (int)y[i];
+            loss += -(zi[yy] - mx - logf(se));
+            corr += (arg == yy) ? 1.f : 0.f;
+            if (grad) {
+                const float inv = scale / se;
+                for (int c = lane; c < C; c += 64)
+                    grad[i * C + c] = expf(zi[c] - mx) * inv - (c == yy ? scale : 0.f);
             }
         }
     }
@@ -107,58 +134,72 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------
-// dW partials: workgroup = (128 features) x (2 halves of a 32-channel tile) over a
-// chunk of rows; thread keeps 16 accumulators.
+// dW / db partials.  Workgroup = 128 feature lanes x 2 channel halves over a chunk of
+// WG_ROWS rows; a thread keeps KACC accumulators (channel tile = 2 KACC).  Rows are
+// taken WG_STEP at a time: x values straight to registers (coalesced over f), the
+// g tile through LDS (read back as broadcasts), so WG_STEP loads are in flight per
+// thread and WG_STEP x KACC FMAs follow.
 // ---------------------------------------------------------------------------
-constexpr int WG_ROWS = 512, WG_FT = 128, WG_CT = 32;
+constexpr int WG_ROWS = 512, WG_FT = 128, WG_STEP = 16;
 
+template <int KACC>
 __global__ __launch_bounds__(256) void k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x,
-                                                       int64_t N, int C, int F, float *__restrict__ part)
-{
-    const int f = blockIdx.x * WG_FT + (threadIdx.x & (WG_FT - 1));
-    const int c0 = blockIdx.y * WG_CT + (threadIdx.x >> 7) * (WG_CT / 2);
-    const int64_t r0 = (int64_t)blockIdx.z * WG_ROWS, r1 = min(N, r0 + WG_ROWS);
-    float acc[WG_CT / 2];
-#pragma unroll
-    for (int k = 0; k < WG_CT / 2; ++k) acc[k] = 0.f;
-    const bool fok = f < F;
-    for (int64_t i = r0; i < r1; ++i) {
-        const float xv = fok ? x[i * F + f] : 0.f;
-        const float *gi = g + i * C + c0;
-#pragma unroll
-        for (int k = 0; k < WG_CT / 2; ++k) {
-            const float gv = (c0 + k < C) ? gi[k] : 0.f;      // same address across the 128 lanes
-            acc[k] = fmaf(gv, xv, acc[k]);
-        }
-    }
-    if (fok) {
-#pragma unroll
-        for (int k = 0; k < WG_CT / 2; ++k)
-            if (c0 + k < C) part[((size_t)blockIdx.z * C + (c0 + k)) * F + f] = acc[k];
-    }
-}
-
-// db partials: part_b[chunk][c] = sum of g over the chunk's rows
-__global__ __launch_bounds__(256) void k_bgrad_partial(const float *__restrict__ g, int64_t N, int C,
+                                                       int64_t N, int C, int F, float *__restrict__ part,
                                                        float *__restrict__ part_b)
 {
-    const int64_t r0 = (int64_t)blockIdx.x * WG_ROWS, r1 = min(N, r0 + WG_ROWS);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int64_t i = r0; i < r1; ++i) s += g[i * C + c];
-        part_b[(size_t)blockIdx.x * C + c] = s;
+    constexpr int CT = 2 * KACC;
+    __shared__ float sg[WG_STEP][CT];
+    const int fl = threadIdx.x & (WG_FT - 1), half = threadIdx.x >> 7;
+    const int f = blockIdx.x * WG_FT + fl;
+    const int ct0 = blockIdx.y * CT, c0 = ct0 + half * KACC;
+    const int64_t r0 = (int64_t)blockIdx.z * WG_ROWS, r1 = min(N, r0 + WG_ROWS);
+    float acc[KACC], bacc[KACC];
+#pragma unroll
+    for (int k = 0; k < KACC; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
+    const bool fok = f < F;
+    const bool do_bias = part_b != nullptr && blockIdx.x == 0 && fl == 0;
+    for (int64_t ib = r0; ib < r1; ib += WG_STEP) {
+        float xv[WG_STEP];
+#pragma unroll
+        for (int r = 0; r < WG_STEP; ++r)
+            xv[r] = (fok && ib + r < r1) ? x[(ib + r) * F + f] : 0.f;
+        __syncthreads();                            // previous step's sg reads are done
+        for (int q = threadIdx.x; q < WG_STEP * CT; q += 256) {
+            const int r = q / CT, c = q % CT;
+            sg[r][c] = (ib + r < r1 && ct0 + c < C) ? g[(ib + r) * C + ct0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WG_STEP; ++r)
+#pragma unroll
+            for (int k = 0; k < KACC; ++k) {
+                const float gv = sg[r][half * KACC + k];
+                acc[k] = fmaf(gv, xv[r], acc[k]);
+                if (do_bias) bacc[k] += gv;
+            }
     }
+#pragma unroll
+    for (int k = 0; k < KACC; ++k)
+        if (c0 + k < C) {
+            if (fok) part[((size_t)blockIdx.z * C + (c0 + k)) * F + f] = acc[k];
+            if (do_bias) part_b[(size_t)blockIdx.z * C + c0 + k] = bacc[k];
+        }
 }
 
-// out[j] = sum over chunks (fixed order) of part[chunk][j]
+// out[j] = sum over chunks of part[chunk][j]: 4 threads per output take every 4th
+// chunk, then their sums are added in fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, int nchunks,
                                                       int64_t len, float *__restrict__ out)
 {
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= len) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * len + j];
-    out[j] = s;
+    __shared__ float s[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + o;
+    float a = 0.f;
+    if (j < len)
+        for (int k = q; k < nchunks; k += 4) a += part[(size_t)k * len + j];
+    s[q][o] = a;
+    __syncthreads();
+    if (q == 0 && j < len) out[j] = (s[0][o] + s[1][o]) + (s[2][o] + s[3][o]);
 }
 
 }  // namespace sngnn
@@ -202,13 +243,21 @@ extern "C" int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t
     float *part = (float *)workspace;
     float *part_b = part + (size_t)chunks * C * F;
     if (chunks > 0) {
-        dim3 grid((F + WG_FT - 1) / WG_FT, (C + WG_CT - 1) / WG_CT, chunks);
-        k_wgrad_partial<<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part);
-        if (grad_bias) k_bgrad_partial<<<chunks, 256, 0, st>>>(grad_out, N, C, part_b);
+        // accumulators per thread: the smallest tile that covers C (or 64 channels per pass)
+        const int kacc = C <= 16 ? 8 : C <= 32 ? 16 : C <= 40 ? 20 : C <= 48 ? 24 : 32;
+        dim3 grid((F + WG_FT - 1) / WG_FT, (C + 2 * kacc - 1) / (2 * kacc), chunks);
+        float *pb = grad_bias ? part_b : nullptr;
+        switch (kacc) {
+        case 8: k_wgrad_partial<8><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 16: k_wgrad_partial<16><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 20: k_wgrad_partial<20><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 24: k_wgrad_partial<24><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        default: k_wgrad_partial<32><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        }
     }
     const int64_t len = (int64_t)C * F;
-    k_sum_partials<<<(unsigned)((len + 255) / 256), 256, 0, st>>>(part, chunks, len, grad_weight);
-    if (grad_bias) k_sum_partials<<<(C + 255) / 256, 256, 0, st>>>(part_b, chunks, C, grad_bias);
+    k_sum_partials<<<(unsigned)((len + 63) / 64), 256, 0, st>>>(part, chunks, len, grad_weight);
+    if (grad_bias) k_sum_partials<<<(C + 63) / 64, 256, 0, st>>>(part_b, chunks, C, grad_bias);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
