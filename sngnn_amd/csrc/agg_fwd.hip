@@ -65,6 +65,11 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
         a.dbg_blocks_per_cu = c2 ? atoi(c2) : 0;
         static const char *e_fin = getenv("SNGNN_INKERNEL_FIN");
         a.inkernel_fin = e_fin ? atoi(e_fin) : 0;
+        { const char *lf = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_INKERNEL_FIN") : nullptr; if (lf) a.inkernel_fin = atoi(lf); }
+        const char *e_dma = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_FWD_DMA") : nullptr;
+        static const char *e_dma0 = getenv("SNGNN_FWD_DMA");
+        if (!e_dma) e_dma = e_dma0;
+        a.use_dma = (e_dma ? atoi(e_dma) : 1) && (C % 4 == 0) && (C <= 256);
     }
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
@@ -78,7 +83,8 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
     a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)
                            : nullptr;
-    a.split_cnt = g->split_cnt;
+    a.split_cnt = g->split_cnt; a.grp_cnt = g->grp_cnt; a.split_grp0 = g->split_grp0;
+    a.cand2 = a.cand_key ? a.cand_key + (size_t)g->n_tasks * 32 : nullptr;
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     a.nbA = ceil_div(g->n_tasks, WAVES);

@@ -43,14 +43,23 @@ struct FwdArgs {
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int lowbits;                    // bits needed for a row-local edge index
-    int32_t *split_cnt;             // [n_split] arrival counters of the in-kernel finalize
+    int32_t *split_cnt;             // [n_split] groups arrived (in-kernel finalize)
+    int32_t *grp_cnt;               // [n_groups] tasks arrived per group of FIN_GT tasks
+    const int32_t *split_grp0;      // [n_split+1] first group of each split row
+    unsigned long long *cand2;      // [n_groups, k] champions of each group
     int nbA, nbB, nbC;          // (unused by the persistent kernel)
     int dbg_classes;            // tuning aid: bit 0 tasks, bit 1 wave rows, bit 2 small rows
     int dbg_blocks_per_cu;      // tuning aid: persistent grid size override (0 = default)
     int inkernel_fin;           // split rows finalized by their last-arriving task (experimental)
+    int use_dma;                // classes A/B stream source rows through LDS-DMA (C % 4 == 0, C <= 256)
 };
 
-constexpr int LDS_PER_WAVE = 512;   // 32-bit words
+#ifndef SNGNN_ENABLE_DMA
+#define SNGNN_ENABLE_DMA 0           // LDS-DMA scoring path: measured no faster than register staging
+#endif
+constexpr int DMA_NI = 2;            // LDS-DMA instructions (1 KiB each) per batch of source rows
+constexpr int LDS_DMA_OFF = 384;     // words: [0,128) scores | [128,256) kept list | [256,384) column ids
+constexpr int LDS_PER_WAVE = SNGNN_ENABLE_DMA ? LDS_DMA_OFF + 2 * DMA_NI * 256 : 512;   // + two DMA buffers
 constexpr int FWD_WAVES_PER_SIMD = 6;   // register budget of the main kernel (<= 80 VGPRs)
 
 template <int R> struct Unroll { static constexpr int U = (R >= 4) ? 1 : (R == 2 ? 2 : 4); };
@@ -341,6 +350,85 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
 }
 
 // ---------------------------------------------------------------------------
+// Scoring pass of classes A and B with the source rows streamed through LDS-DMA
+// (global_load_lds_dwordx4: per-lane source address, wave-contiguous 1 KiB LDS
+// destination, no VGPR destination).  One DMA instruction gathers 64 / (C/4) whole
+// rows; a batch is DMA_NI instructions; two batches ping-pong, so the next batch is
+// in flight while the current one is scored and the number of rows in flight does
+// not depend on the register budget.  The column ids were put in LDS (s_ids) with
+// ordinary loads BEFORE the first DMA: beside an LDS-DMA in flight hipcc waits
+// vmcnt(0) for any VGPR-destination load, which would drain the queue.
+// Edges are [e0, e0 + n), n <= 128.  Same arithmetic and order as score_edges.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmcnt_upto(int n)      // n wave-uniform, 0..DMA_NI
+{
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+}
+static_assert(DMA_NI == 2, "wait_vmcnt_upto covers 0..2");
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void score_edges_dma(const FwdArgs &a, int rs, int e0, int n,
+                                                const Row<VEC, G, R> &hi, float inv_i, bool stream,
+                                                float *s_sc, const int *s_ids, float *dma,
+                                                Row<VEC, G, R> &acc)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int CH = a.C >> 2;                      // 16-byte chunks per row (<= G)
+    const int RPI = 64 / CH;                      // rows per DMA instruction
+    const int BR = DMA_NI * RPI;                  // rows per batch
+    const int r_in = lane / CH, c_in = lane - r_in * CH;
+    const bool dlane = r_in < RPI;
+    const int nb = (n + BR - 1) / BR;
+    auto issue = [&](int b, int buf) {
+#pragma unroll
+        for (int q = 0; q < DMA_NI; ++q) {
+            const int e = b * BR + q * RPI + r_in;
+            if (dlane && e < n) {
+                const int j = s_ids[e];
+                __builtin_amdgcn_global_load_lds(
+                    a.h + (size_t)j * a.C + c_in * 4,
+                    (__attribute__((address_space(3))) void *)(dma + (buf * DMA_NI + q) * 256), 16, 0, 0);
+            }
+        }
+    };
+    auto n_instr = [&](int b) {                   // DMA instructions of batch b with an active lane
+        const int rows = min(BR, n - b * BR);
+        return rows <= 0 ? 0 : (rows + RPI - 1) / RPI;
+    };
+    issue(0, 0);
+    if (nb > 1) issue(1, 1);
+    for (int b = 0; b < nb; ++b) {
+        wait_vmcnt_upto(b + 1 < nb ? n_instr(b + 1) : 0);     // batch b has landed
+        const float *buf = dma + (b & 1) * DMA_NI * 256;
+        const int rows = min(BR, n - b * BR);
+        for (int r0 = 0; r0 < rows; r0 += NG) {
+            const int r = r0 + gid;
+            const bool act = r < rows;
+            const int rr = act ? r : 0;
+            RowT x;
+            x.load(buf + (rr / RPI) * 256 + (rr % RPI) * CH * 4, a.C, lg);
+            const float s = edge_score<VEC, G, R>(hi, inv_i, x);
+            if (act) {
+                const int t = b * BR + r;             // chunk-local edge index
+                if (s_sc && lg == 0) s_sc[t] = s;
+                if (stream) {
+                    const bool sel = (a.k < 0) || (s >= a.thr);
+                    if (sel) acc.axpy(s, x);
+                    if (a.wsel && lg == 0) a.wsel[rs + e0 + t] = sel ? s : SNGNN_UNSELECTED;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this buffer's reads are done
+        if (b + 2 < nb) issue(b + 2, b & 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
@@ -367,7 +455,19 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 
     RowT acc;
     acc.zero();
-    score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc);
+    bool dma_done = false;
+    if constexpr (SNGNN_ENABLE_DMA && VEC == 4 && R == 1) {
+        if (a.use_dma) {
+            int *s_ids = lds_wave + 2 * WAVE_T;
+            for (int t = lane; t < deg; t += 64) s_ids[t] = a.col[rs + t];
+            wave_lds_sync();
+            score_edges_dma<VEC, G, R>(a, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, s_ids,
+                                       reinterpret_cast<float *>(lds_wave + LDS_DMA_OFF), acc);
+            dma_done = true;
+        }
+    }
+    if (!dma_done)
+        score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc);
 
     if (need_sc) {
         wave_lds_sync();
@@ -417,37 +517,34 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 }
 
 // ---------------------------------------------------------------------------
-// In-kernel finalize of a split row (top_k <= CAND_MAX_K): executed by the wave
-// whose task was the last of the row to arrive.  Streams the tasks' candidate keys
-// through a wave-level top-k, 96 new keys per step beside the <= 32 champions, then
-// gathers the <= k winners.  Hand-off (guide G16): producers store the keys
-// write-through (sc1) and drain vmcnt before their relaxed agent-scope counter add;
-// the last arriver takes an agent-scope acquire and reads the keys with sc1 loads.
+// In-kernel finalize of split rows (top_k <= CAND_MAX_K), two levels, no waiting:
+//   * the tasks of a row form groups of FIN_GT; the wave whose task is the LAST of its
+//     group to arrive merges the group's candidate keys into <= k champions;
+//   * the wave whose group is the last of the ROW to arrive merges the groups'
+//     champions, gathers the <= k winners and writes the row.
+// Nobody spins: a wave only ever waits for its own stores.  Hand-off (guide G16):
+// producers store keys write-through (sc1) and drain vmcnt before their relaxed
+// agent-scope counter add; a last arriver takes an agent-scope acquire and reads the
+// keys with sc1 loads.  Counters are reset by the last arriver (0 between launches).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R>
-__device__ __forceinline__ void finalize_split_row(const FwdArgs &a, int p, const int4 d,
-                                                   int *lds_wave)
+constexpr int FIN_GT = 6;      // tasks per group: 6 * 16 keys fill one merge step beside 32 champions
+static_assert(FIN_GT == FIN_GT_HOST, "keep graph.hip in sync");
+
+// merge n keys at ck (sc1 loads) into champ[] (LDS, <= k keys); returns their number
+__device__ __forceinline__ int merge_keys(const unsigned long long *ck, int n, int k, int lowbits,
+                                          unsigned long long *champ)
 {
-    using RowT = Row<VEC, G, R>;
-    constexpr int NG = 64 / G;
     const int lane = lane_id();
-    const int gid = lane / G, lg = lane % G;
-    const int i = d.x, rs = d.y, deg = d.z;
-    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    const bool emit = a.sel_src != nullptr;
-    unsigned long long *champ = reinterpret_cast<unsigned long long *>(lds_wave);   // [32]
-    const unsigned long long *ck = a.cand_key + (size_t)t0 * a.k;
-    const int n = (t1 - t0) * a.k;
     int nchamp = 0;
     for (int base = 0; base < n; base += 96) {
-        // lanes 0..31 of slot 0: champions; the other 96 slots: new candidate keys
+        // lanes 0..31 of slot 0: champions so far; the other 96 slots: new keys
         const int q0 = base + lane - 32, q1 = base + 32 + lane;
         unsigned long long key0, key1;
         if (lane < 32) key0 = lane < nchamp ? champ[lane] : 0ull;
         else key0 = q0 < n ? __hip_atomic_load(ck + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         key1 = q1 < n ? __hip_atomic_load(ck + q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         bool k0, k1;
-        wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+        wave_topk_keys(key0, key1, k, lowbits, k0, k1);
         const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
         const int n0 = __popcll(m0);
         wave_lds_sync();                    // every lane has read its champion
@@ -456,7 +553,21 @@ __device__ __forceinline__ void finalize_split_row(const FwdArgs &a, int p, cons
         nchamp = n0 + __popcll(m1);
         wave_lds_sync();
     }
-    // kept edges: weights for backward, rank-ordered selection, weighted sum
+    return nchamp;
+}
+
+// kept edges of a split row from its champion keys: weights for backward, rank-ordered
+// selection, weighted sum
+template <int VEC, int G, int R>
+__device__ __forceinline__ void finalize_split_row(const FwdArgs &a, const int4 d,
+                                                   const unsigned long long *champ, int nchamp)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int i = d.x, rs = d.y, deg = d.z;
+    const bool emit = a.sel_src != nullptr;
     if (lane < nchamp) {
         const unsigned long long kq = champ[lane];
         const int idx = key_index(kq);
@@ -487,6 +598,22 @@ __device__ __forceinline__ void finalize_split_row(const FwdArgs &a, int p, cons
     }
 }
 
+// my stores are out -> count me in; true for the last of `total` arrivers, which
+// then also holds an acquire and has reset the counter
+__device__ __forceinline__ bool arrive_last(int32_t *cnt, int total)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int arrived = 0;
+    if (lane_id() == 0)
+        arrived = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived != total - 1) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane_id() == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
@@ -513,7 +640,19 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
     acc.zero();
     float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
     float *sc = cand ? s_sc : ((rank || emit) ? a.scores + a.split_soff[p] : nullptr);
-    score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, cand ? e0 : 0, acc);
+    bool dma_done = false;
+    if constexpr (SNGNN_ENABLE_DMA && VEC == 4 && R == 1) {
+        if (a.use_dma && (cand || (!rank && !emit))) {      // scores (if any) go to LDS in these modes
+            int *s_ids = lds_wave + 2 * WAVE_T;
+            for (int t = lane; t < e1 - e0; t += 64) s_ids[t] = a.col[rs + e0 + t];
+            wave_lds_sync();
+            score_edges_dma<VEC, G, R>(a, rs, e0, e1 - e0, hi, inv_i, !rank, cand ? s_sc : nullptr, s_ids,
+                                       reinterpret_cast<float *>(lds_wave + LDS_DMA_OFF), acc);
+            dma_done = true;
+        }
+    }
+    if (!dma_done)
+        score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, cand ? e0 : 0, acc);
     if (cand) {
         wave_lds_sync();
         const WaveSel ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
@@ -530,21 +669,30 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             if (lane < e1 - e0) __hip_atomic_store(w + lane, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane + 64 < e1 - e0) __hip_atomic_store(w + lane + 64, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        int arrived = -1, ntasks = 0;
         if (a.inkernel_fin) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my stores are out
-            if (lane == 0)
-                arrived = __hip_atomic_fetch_add(a.split_cnt + p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrived = __builtin_amdgcn_readfirstlane(arrived);
-            ntasks = a.split_task0[p + 1] - a.split_task0[p];
-        }
-        if (a.inkernel_fin && arrived == ntasks - 1) {         // wave-uniform: last task of the row
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)                                      // ready for the next launch
-                __hip_atomic_store(a.split_cnt + p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            wave_lds_sync();
-            finalize_split_row<VEC, G, R>(a, p, d, lds_wave);
+            unsigned long long *champ = reinterpret_cast<unsigned long long *>(lds_wave);   // [32]
+            const int t0 = a.split_task0[p], nt = a.split_task0[p + 1] - t0;
+            const int gl = c / FIN_GT;                                  // my group inside the row
+            const int g0 = a.split_grp0[p], ng = a.split_grp0[p + 1] - g0;
+            const int gsize = min(FIN_GT, nt - gl * FIN_GT);
+            if (arrive_last(a.grp_cnt + g0 + gl, gsize)) {              // wave-uniform
+                wave_lds_sync();
+                int nchamp = merge_keys(a.cand_key + (size_t)(t0 + gl * FIN_GT) * a.k, gsize * a.k, a.k,
+                                        a.lowbits, champ);
+                bool mine = ng == 1;
+                if (!mine) {
+                    unsigned long long *c2 = a.cand2 + (size_t)(g0 + gl) * a.k;
+                    if (lane < a.k)
+                        __hip_atomic_store(c2 + lane, lane < nchamp ? champ[lane] : 0ull, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if (arrive_last(a.split_cnt + p, ng)) {
+                        wave_lds_sync();
+                        nchamp = merge_keys(a.cand2 + (size_t)g0 * a.k, ng * a.k, a.k, a.lowbits, champ);
+                        mine = true;
+                    }
+                }
+                if (mine) finalize_split_row<VEC, G, R>(a, d, champ, nchamp);
+            }
         }
     } else if (!rank) {
         acc.reduce_across_groups();

@@ -16,6 +16,7 @@ constexpr int CHUNK = 128;     // deg >  WAVE_T  : split into CHUNK-edge wave ta
 constexpr int BLOCK = 256;     // threads per workgroup of the main kernels
 constexpr int WAVES = BLOCK / 64;
 constexpr int FIN_BLOCK = 1024;   // threads per workgroup of the split-row finalize
+constexpr int FIN_GT_HOST = 6;    // == FIN_GT (agg_fwd_impl.h): tasks per in-kernel finalize group
 constexpr float EPS_NORM = 1e-12f;   // F.normalize eps (models.py:122,238,325)
 
 void set_error(const std::string &msg);
@@ -68,7 +69,10 @@ struct sngnn_graph {
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
-    int32_t *split_cnt = nullptr;     // [n_split] tasks arrived (in-kernel finalize); 0 between launches
+    int32_t *split_cnt = nullptr;     // [n_split] groups arrived (in-kernel finalize); 0 between launches
+    int32_t *grp_cnt = nullptr;       // [n_groups] tasks arrived per group of FIN_GT tasks
+    int32_t *split_grp0 = nullptr;    // [n_split+1] first group of each split row
+    int n_groups = 0;
     // split sources (out-degree > WAVE_T) = the first n_ssplit slots of sperm
     int32_t *stask_slot = nullptr, *stask_chunk = nullptr;  // [n_stasks]
     int32_t *ssplit_task0 = nullptr;  // [n_ssplit+1]

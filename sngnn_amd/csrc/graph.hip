@@ -289,8 +289,20 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if ((rc = build_tasks(g->rdeg, g->n_split, &g->task_slot, &g->task_chunk, &g->split_task0,
                           &g->split_soff, &g->n_tasks, &g->split_edges)))
         return rc;
-    if ((rc = dev_alloc(&g->split_cnt, g->n_split))) return rc;
-    SN_HIP(hipMemsetAsync(g->split_cnt, 0, (size_t)std::max(g->n_split, 1) * 4, st));
+    {   // groups of FIN_GT tasks for the in-kernel finalize
+        std::vector<int32_t> g0((size_t)g->n_split + 1, 0);
+        for (int p = 0; p < g->n_split; ++p) {
+            const int nt = (g->rdeg[p] + CHUNK - 1) / CHUNK;
+            g0[p + 1] = g0[p] + (nt + FIN_GT_HOST - 1) / FIN_GT_HOST;
+        }
+        g->n_groups = g0[g->n_split];
+        if ((rc = dev_alloc(&g->split_grp0, g->n_split + 1)) || (rc = dev_alloc(&g->grp_cnt, g->n_groups)) ||
+            (rc = dev_alloc(&g->split_cnt, g->n_split)))
+            return rc;
+        SN_HIP(hipMemcpy(g->split_grp0, g0.data(), g0.size() * 4, hipMemcpyHostToDevice));
+        SN_HIP(hipMemsetAsync(g->split_cnt, 0, (size_t)std::max(g->n_split, 1) * 4, st));
+        SN_HIP(hipMemsetAsync(g->grp_cnt, 0, (size_t)std::max(g->n_groups, 1) * 4, st));
+    }
     g->n_ssplit = g->srcs_gt(WAVE_T);
     if ((rc = build_tasks(g->sdeg, g->n_ssplit, &g->stask_slot, &g->stask_chunk, &g->ssplit_task0,
                           nullptr, &g->n_stasks, nullptr)))
@@ -344,7 +356,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
-                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt,
+                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt, g->grp_cnt, g->split_grp0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
@@ -362,7 +374,8 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
     if (!g || C < 1) return -1;
     // forward: scores of split rows | one partial row per split task
     int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
-                  (int64_t)g->n_tasks * 32 * 8;     // + CAND_MAX_K candidate keys per task
+                  (int64_t)g->n_tasks * 32 * 8 +     // + CAND_MAX_K candidate keys per task
+                  (int64_t)g->n_groups * 32 * 8;     // + champions per finalize group
     // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_tasks * C * 4 +

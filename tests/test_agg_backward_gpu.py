@@ -114,3 +114,43 @@ def test_adj_linear_branch(cuda, n, e, C, hubs, src_min):
     assert_grad_close(Wg.grad, W_ref.grad.to_dense() if W_ref.grad.is_sparse else W_ref.grad,
                       "dW")
     assert_grad_close(bg.grad, b_ref.grad, "db")
+
+
+@pytest.mark.parametrize("parts,k,thr", [(2, 8, 0.0), (3, None, 0.0), (4, 2, 0.1)])
+def test_node_range_partitions_reproduce_the_whole_graph(cuda, parts, k, thr):
+    """What every rank of a multi-GPU run computes: the partition graph of a node range
+    (global column ids, all-gathered h) gives exactly the owned rows of the full
+    result, and the ranks' partial grad_h sum (the reduce-scatter) to the full gradient."""
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    n, C = 1200, 40
+    n -= n % parts
+    ei = random_graph(n, 12000, seed=21, hubs=((0, n - 1), (n // 2, 300), (n - 1, 200)))
+    ei = torch.cat([ei, torch.stack([torch.full((n // 3,), 5), torch.arange(n // 3) * 3])], 1)
+    ei = torch.unique(ei, dim=1).to(cuda)
+    gen = torch.Generator().manual_seed(9)
+    h = torch.randn(n, C, generator=gen).to(cuda)
+    gout = torch.randn(n, C, generator=gen).to(cuda)
+
+    g_full = Graph(ei, n, True, True)
+    hf = h.clone().requires_grad_(True)
+    out_full = ops.aggregate(hf, g_full, k, thr)
+    (out_full * gout).sum().backward()
+
+    step = n // parts
+    outs, grad_sum, edges = [], torch.zeros_like(h), 0
+    for r in range(parts):
+        lo, hi = r * step, (r + 1) * step
+        g = Graph(ei, n, True, True, row_range=(lo, hi))
+        assert (g.num_nodes, g.num_total_nodes, g.row_offset) == (step, n, lo)
+        edges += g.num_edges
+        hp = h.clone().requires_grad_(True)
+        o = ops.aggregate(hp, g, k, thr)
+        assert o.shape == (step, C)
+        (o * gout[lo:hi]).sum().backward()
+        outs.append(o.detach())
+        grad_sum += hp.grad
+    assert edges == g_full.num_edges
+    assert torch.equal(torch.cat(outs), out_full.detach())
+    scale = hf.grad.abs().max()
+    assert (grad_sum - hf.grad).abs().max() <= 2e-6 * scale

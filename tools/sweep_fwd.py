@@ -24,18 +24,22 @@ k, thr = int(os.environ.get("K", 16)), float(os.environ.get("THR", 0.0))
 def timeit(reps=60):
     lib.sngnn_profile_enable(1)
     m, f = C.c_float(), C.c_float()
-    ms = []
+    ms, fs = [], []
     for _ in range(reps):
         ops.aggregate_forward(g, h, k, thr)
         lib.sngnn_profile_last_forward(C.byref(m), C.byref(f))
         ms.append(m.value)
+        fs.append(f.value)
     lib.sngnn_profile_enable(0)
-    return float(np.median(ms[10:])) * 1e3, float(np.min(ms[10:])) * 1e3
+    return float(np.median(ms[10:])) * 1e3, float(np.median(fs[10:])) * 1e3
 
 
-for cls in (7, 1, 2, 4):
-    os.environ["SNGNN_DEBUG_CLASSES"] = str(cls)
-    for bpc in (2, 3, 4, 5, 6, 8):
-        os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
-        med, mn = timeit()
-        print(f"classes={cls} blocks/CU={bpc}: median {med:7.1f} us  min {mn:7.1f} us", flush=True)
+for fin in (0, 1):
+    os.environ["SNGNN_INKERNEL_FIN"] = str(fin)
+    for cls in (7, 1):
+        os.environ["SNGNN_DEBUG_CLASSES"] = str(cls)
+        for bpc in (5, 6):
+            os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
+            med, fm = timeit()
+            print(f"inkernel_fin={fin} classes={cls} blocks/CU={bpc}: main {med:7.1f} us  "
+                  f"separate finalize {fm:6.1f} us  total {med + fm:7.1f}", flush=True)
