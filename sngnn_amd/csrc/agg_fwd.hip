@@ -65,6 +65,10 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
         a.dbg_blocks_per_cu = c2 ? atoi(c2) : 0;
         static const char *e_fin = getenv("SNGNN_INKERNEL_FIN");
         a.inkernel_fin = e_fin ? atoi(e_fin) : 0;
+        { const char *xa = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_XCD_AFFINITY") : nullptr;
+          static const char *xa0 = getenv("SNGNN_XCD_AFFINITY");
+          if (!xa) xa = xa0;
+          a.xcd_affinity = xa ? atoi(xa) : 0; }
         { const char *lf = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_INKERNEL_FIN") : nullptr; if (lf) a.inkernel_fin = atoi(lf); }
         const char *e_dma = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_FWD_DMA") : nullptr;
         static const char *e_dma0 = getenv("SNGNN_FWD_DMA");
@@ -79,6 +83,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.n_tasks = g->n_tasks;
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk;
     a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
+    a.xtask_list = g->xtask_list; a.xtask_ptr = g->xtask_ptr;
     a.scores = (float *)workspace;
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
     a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)

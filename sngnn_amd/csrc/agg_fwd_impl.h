@@ -40,6 +40,8 @@ struct FwdArgs {
     int n_split, n_med_end;     // slots [0,n_split) split, [n_split,n_med_end) wave, rest small
     int n_tasks;
     const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
+    const int32_t *xtask_list, *xtask_ptr;   // tasks grouped by source-range eighth (XCD affinity)
+    int xcd_affinity;
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int lowbits;                    // bits needed for a row-local edge index
@@ -713,9 +715,22 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     const int nw = gridDim.x * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
-    for (; it < a.n_tasks; it += nw)
-        if (a.dbg_classes & 1) role_task<VEC, G, R>(a, it, lw);
-    it -= a.n_tasks;
+    if (a.xcd_affinity && (gridDim.x & 7) == 0) {
+        // Workgroups b and b + 8 share an XCD (observed round-robin placement; speed
+        // only, never correctness).  XCD group x takes the tasks whose sources lie in
+        // the x-th eighth of the node range: ~1/8 of the feature table per L2.
+        const int x = blockIdx.x & 7;
+        const int j = (blockIdx.x >> 3) * WAVES + wave, nwx = (gridDim.x >> 3) * WAVES;
+        const int q1 = a.xtask_ptr[x + 1];
+        if (a.dbg_classes & 1)
+            for (int q = a.xtask_ptr[x] + j; q < q1; q += nwx) role_task<VEC, G, R>(a, a.xtask_list[q], lw);
+        // waves without a task (high j) start with the biggest wave rows
+        it = (nwx - 1 - j) * 8 + x;
+    } else {
+        for (; it < a.n_tasks; it += nw)
+            if (a.dbg_classes & 1) role_task<VEC, G, R>(a, it, lw);
+        it -= a.n_tasks;
+    }
     for (; it < n_wave_rows; it += nw)
         if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, it, lw);
     it -= n_wave_rows;

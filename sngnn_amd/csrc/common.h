@@ -68,6 +68,8 @@ struct sngnn_graph {
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
+    int32_t *xtask_list = nullptr;    // [n_tasks] task ids grouped by the eighth of the node range their
+    int32_t *xtask_ptr = nullptr;     // [9]       sources fall in (one group per XCD: L2 affinity)
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
     int32_t *split_cnt = nullptr;     // [n_split] groups arrived (in-kernel finalize); 0 between launches
     int32_t *grp_cnt = nullptr;       // [n_groups] tasks arrived per group of FIN_GT tasks

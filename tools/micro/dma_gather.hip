@@ -34,6 +34,57 @@ __global__ __launch_bounds__(256) void k_reg(const float *__restrict__ h, const 
     if (lane == 0) out[wave] = s;
 }
 
+// split layout: table A [N][32] (one 128-B line per row) + table B [N][8] (32 B per row,
+// four rows per line, 5.4 MB: mostly L2-resident)
+template <int U>
+__global__ __launch_bounds__(256) void k_split(const float *__restrict__ ha, const float *__restrict__ hb,
+                                               const int *__restrict__ ids, int E, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, gid = lane >> 4, lg = lane & 15;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * 4 * U; base < E; base += nw * 4 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 4 + gid;
+            const int j = e < E ? ids[e] : 0;
+            x[u] = lg < 8 ? *reinterpret_cast<const float4 *>(ha + (size_t)j * 32 + lg * 4)
+                 : lg < 10 ? *reinterpret_cast<const float4 *>(hb + (size_t)j * 8 + (lg - 8) * 4)
+                           : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+// 128-byte rows only (C = 32): what a one-line-per-row table can deliver
+template <int U>
+__global__ __launch_bounds__(256) void k_c32(const float *__restrict__ ha, const int *__restrict__ ids,
+                                             int E, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, gid = lane >> 3, lg = lane & 7;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * 8 * U; base < E; base += nw * 8 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 8 + gid;
+            const int j = e < E ? ids[e] : 0;
+            x[u] = *reinterpret_cast<const float4 *>(ha + (size_t)j * 32 + lg * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
 // NI DMA instructions (RPI rows each) per batch, two LDS buffers per wave
 template <int NI>
 __global__ __launch_bounds__(256) void k_dma(const float *__restrict__ h, const int *__restrict__ ids,
@@ -99,10 +150,14 @@ int main()
     srand(1);
     for (auto &v : hh) v = (rand() % 1000) * 0.001f;
     for (auto &v : hi) v = (int)(((long long)rand() * 32768 + rand()) % N);
-    float *dh, *dout;
+    float *dh, *dout, *dha, *dhb;
+    std::vector<float> ha((size_t)N * 32), hb((size_t)N * 8);
+    for (int i = 0; i < N; ++i) { for (int c = 0; c < 32; ++c) ha[(size_t)i * 32 + c] = hh[(size_t)i * C + c]; for (int c = 0; c < 8; ++c) hb[(size_t)i * 8 + c] = hh[(size_t)i * C + 32 + c]; }
     int *di;
     CK(hipMalloc(&dh, hh.size() * 4));
     CK(hipMalloc(&di, hi.size() * 4));
+    CK(hipMalloc(&dha, ha.size() * 4)); CK(hipMalloc(&dhb, hb.size() * 4));
+    CK(hipMemcpy(dha, ha.data(), ha.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dhb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dout, 4 * 65536));
     CK(hipMemcpy(dh, hh.data(), hh.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(di, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
@@ -130,6 +185,9 @@ int main()
         const int grid = 256 * bpc;
         printf("-- %d blocks/CU\n", bpc);
         run("reg U=4", [&] { k_reg<4><<<grid, 256>>>(dh, di, E, dout); });
+        run("split 128+32 U=4", [&] { k_split<4><<<grid, 256>>>(dha, dhb, di, E, dout); });
+        run("split 128+32 U=8", [&] { k_split<8><<<grid, 256>>>(dha, dhb, di, E, dout); });
+        run("C=32 only (128-B rows) U=4", [&] { k_c32<4><<<grid, 256>>>(dha, di, E, dout); });
         run("reg U=8", [&] { k_reg<8><<<grid, 256>>>(dh, di, E, dout); });
         run("reg U=16", [&] { k_reg<16><<<grid, 256>>>(dh, di, E, dout); });
         run("dma NI=2 (12 rows/batch)", [&] { k_dma<2><<<grid, 256>>>(dh, di, E, dout); });
