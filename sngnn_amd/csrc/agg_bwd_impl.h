@@ -63,6 +63,17 @@ __device__ __forceinline__ void t_edge(const BwdArgs &a, int e, const Row<VEC, G
     fma_row<VEC, G, R>(acc, d * invj, x);
 }
 
+// the same with the source row already loaded
+template <int VEC, int G, int R>
+__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, const Row<VEC, G, R> &x,
+                                           const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc)
+{
+    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));
+    const float d = group_sum<G>(gp.dot_partial(x));
+    if (lg == 0) a.ds[e] = d;
+    fma_row<VEC, G, R>(acc, d * invj, x);
+}
+
 // kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[];
 // lanes cover the range 64 at a time
 __device__ __forceinline__ int kept_list(const float *__restrict__ wsel, int rs, int e0, int e1,
@@ -80,8 +91,11 @@ __device__ __forceinline__ int kept_list(const float *__restrict__ wsel, int rs,
     return n;
 }
 
+// small targets (deg <= SMALL_T), one group per row.  The group's lanes first fetch the
+// kept flags and source ids of all its edges in parallel (one round trip), then the
+// kept source rows are gathered two at a time.
 template <int VEC, int G, int R>
-__device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk)
+__device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int RPW = 64 / G;
@@ -92,12 +106,22 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk)
     const int i = a.rperm[slot];
     const int rs = a.rowptr[i];
     const int deg = a.rowptr[i + 1] - rs;
+    int *s_j = lds_wave + gid * 2 * SMALL_T;                 // [SMALL_T] source id or -1
+    for (int t = lg; t < deg; t += G)
+        s_j[t] = is_kept(a.wsel[rs + t]) ? a.col[rs + t] : -1;
     RowT gp, acc;
     gp.load(a.gout + (size_t)i * a.C, a.C, lg);
     gp.div((float)max(deg, 1));
     acc.zero();
-    for (int t = 0; t < deg; ++t)
-        if (is_kept(a.wsel[rs + t])) t_edge<VEC, G, R>(a, rs + t, gp, lg, acc);
+    wave_lds_sync();
+    for (int t0 = 0; t0 < deg; t0 += 2) {
+        const int j0 = s_j[t0], j1 = (t0 + 1 < deg) ? s_j[t0 + 1] : -1;
+        RowT x0, x1;
+        if (j0 >= 0) x0.load(a.h + (size_t)j0 * a.C, a.C, lg);
+        if (j1 >= 0) x1.load(a.h + (size_t)j1 * a.C, a.C, lg);
+        if (j0 >= 0) t_edge_row<VEC, G, R>(a, rs + t0, x0, gp, lg, acc);
+        if (j1 >= 0) t_edge_row<VEC, G, R>(a, rs + t0 + 1, x1, gp, lg, acc);
+    }
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
 
@@ -143,24 +167,32 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][WAVE_T];
+    __shared__ int lds[WAVES][256];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
     else if (b < a.nbA + a.nbB) t_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
-    else t_role_small<VEC, G, R>(a, b - a.nbA - a.nbB);
+    else t_role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
 }
 
-// split targets: dnT_i = sum of the tasks' partial rows, in task order
-static __global__ void k_bwd_t_fin(const BwdArgs a)
+// split targets: dnT_i = sum of the tasks' partial rows.  Thread (c, q) adds every 4th
+// task, the four sums are combined in fixed order (deterministic).
+static __global__ __launch_bounds__(256) void k_bwd_t_fin(const BwdArgs a)
 {
+    __shared__ float s[4][64];
     const int p = blockIdx.x;
     const int i = a.rperm[p];
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-        float s = 0.f;
-        for (int t = t0; t < t1; ++t) s += a.partT[(size_t)t * a.C + c];
-        a.dnT[(size_t)i * a.C + c] = s;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < a.C; c0 += 64) {
+        const int c = c0 + cl;
+        float v = 0.f;
+        if (c < a.C)
+            for (int t = t0 + q; t < t1; t += 4) v += a.partT[(size_t)t * a.C + c];
+        s[q][cl] = v;
+        __syncthreads();
+        if (q == 0 && c < a.C) a.dnT[(size_t)i * a.C + c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
+        __syncthreads();
     }
 }
 
@@ -207,8 +239,23 @@ __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VE
     msg.store(a.grad_h + (size_t)v * a.C, a.C, lg);
 }
 
+// one kept out-edge with its per-edge scalars already fetched
 template <int VEC, int G, int R>
-__device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk)
+__device__ __forceinline__ void s_edge_rows(const BwdArgs &a, const Row<VEC, G, R> &x, Row<VEC, G, R> &gi,
+                                            float w, float dse, int deg, Row<VEC, G, R> &msg,
+                                            Row<VEC, G, R> &dns)
+{
+    gi.div((float)deg);
+    const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
+    fma_row<VEC, G, R>(msg, w, gi);
+    fma_row<VEC, G, R>(dns, dse * invi, x);
+}
+
+// small sources (out-degree <= SMALL_T), one group per source: per-edge scalars of all
+// out-edges are fetched by the group's lanes in parallel, then the (h_i, G_i) row pairs
+// of the kept edges are gathered two edges at a time.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int RPW = 64 / G;
@@ -219,12 +266,39 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk)
     const int v = a.sperm[slot];
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
+    int *s_i = lds_wave + gid * 4 * SMALL_T;                          // target row or -1
+    int *s_deg = s_i + SMALL_T;
+    float *s_w = reinterpret_cast<float *>(s_i + 2 * SMALL_T);
+    float *s_ds = reinterpret_cast<float *>(s_i + 3 * SMALL_T);
+    for (int t = lg; t < od; t += G) {
+        const int e = a.csc_eid[qs + t];
+        const float w = a.wsel[e];
+        const bool kept = is_kept(w);
+        const int i = kept ? a.csc_dst[qs + t] : -1;
+        s_i[t] = i;
+        if (kept) {
+            s_deg[t] = a.rowptr[i + 1] - a.rowptr[i];
+            s_w[t] = w;
+            s_ds[t] = a.ds[e];
+        }
+    }
     RowT msg, dns;
     msg.zero();
     dns.zero();
-    for (int t = 0; t < od; ++t) {
-        const float w = a.wsel[a.csc_eid[qs + t]];
-        if (is_kept(w)) s_edge<VEC, G, R>(a, qs + t, w, lg, msg, dns);
+    wave_lds_sync();
+    for (int t0 = 0; t0 < od; t0 += 2) {
+        const int i0 = s_i[t0], i1 = (t0 + 1 < od) ? s_i[t0 + 1] : -1;
+        RowT x0, g0, x1, g1;
+        if (i0 >= 0) {
+            x0.load(a.h + (size_t)(i0 + a.row_off) * a.C, a.C, lg);
+            g0.load(a.gout + (size_t)i0 * a.C, a.C, lg);
+        }
+        if (i1 >= 0) {
+            x1.load(a.h + (size_t)(i1 + a.row_off) * a.C, a.C, lg);
+            g1.load(a.gout + (size_t)i1 * a.C, a.C, lg);
+        }
+        if (i0 >= 0) s_edge_rows<VEC, G, R>(a, x0, g0, s_w[t0], s_ds[t0], s_deg[t0], msg, dns);
+        if (i1 >= 0) s_edge_rows<VEC, G, R>(a, x1, g1, s_w[t0 + 1], s_ds[t0 + 1], s_deg[t0 + 1], msg, dns);
     }
     s_finish<VEC, G, R>(a, v, lg, msg, dns);
 }
@@ -285,12 +359,12 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][2 * WAVE_T];
+    __shared__ int lds[WAVES][512];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) s_role_wave<VEC, G, R>(a, b, lw, true);
     else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
-    else s_role_small<VEC, G, R>(a, b - a.nbA - a.nbB);
+    else s_role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
 }
 
 // split sources: one wave per source sums the tasks' partial rows, then finishes
