@@ -34,7 +34,8 @@ __device__ __forceinline__ int wmin_i(int v)
     return v;
 }
 
-constexpr int HEAD_ROWS_PER_BLOCK = 16;    // 4 waves x 4 rows
+constexpr int HEAD_ROWS_PER_BLOCK = 16;    // 4 waves x 4 rows per step
+constexpr int HEAD_MAX_BLOCKS = 2048;      // persistent grid: partials stay few
 
 // One wave per row.  sel[i] != 0 marks the rows of the mask.  Per-block partial (loss
 // sum, correct count) go to part[]; grad (optional, dense [N, C]) = (softmax - onehot)
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ z, const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss = 0.f, corr = 0.f;
     constexpr int RPW = HEAD_ROWS_PER_BLOCK / 4;
-    const int64_t i0 = (int64_t)blockIdx.x * HEAD_ROWS_PER_BLOCK + wave * RPW;
+    for (int64_t blk = blockIdx.x; blk * HEAD_ROWS_PER_BLOCK < N; blk += gridDim.x) {
+    const int64_t i0 = blk * HEAD_ROWS_PER_BLOCK + wave * RPW;
     if (C <= 64) {
         float v[RPW];
         int yi[RPW];
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ z, const
             }
         }
     }
+    }   // persistent loop over row blocks
     if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -140,44 +143,65 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float *__restrict__ p
 // g tile through LDS (read back as broadcasts), so WG_STEP loads are in flight per
 // thread and WG_STEP x KACC FMAs follow.
 // ---------------------------------------------------------------------------
-constexpr int WG_ROWS = 512, WG_FT = 128, WG_STEP = 16;
+constexpr int WG_ROWS = 512, WG_FT = 128, WG_STEP = 16, WG_SUB = 4;   // 4 sub-blocks of 128 rows
 
 template <int KACC>
-__global__ __launch_bounds__(256) void k_wgrad_partial(const float *__restrict__ g, const float *__restrict__ x,
-                                                       int64_t N, int C, int F, float *__restrict__ part,
-                                                       float *__restrict__ part_b)
+__global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__restrict__ g,
+                                                                const float *__restrict__ x, int64_t N, int C,
+                                                                int F, float *__restrict__ part,
+                                                                float *__restrict__ part_b)
 {
     constexpr int CT = 2 * KACC;
-    __shared__ float sg[WG_STEP][CT];
-    const int fl = threadIdx.x & (WG_FT - 1), half = threadIdx.x >> 7;
+    __shared__ float sg[WG_SUB][WG_STEP][CT];
+    __shared__ float sred[WG_SUB - 1][256];
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int fl = tid & (WG_FT - 1), half = tid >> 7;
     const int f = blockIdx.x * WG_FT + fl;
     const int ct0 = blockIdx.y * CT, c0 = ct0 + half * KACC;
-    const int64_t r0 = (int64_t)blockIdx.z * WG_ROWS, r1 = min(N, r0 + WG_ROWS);
+    const int64_t r0 = (int64_t)blockIdx.z * WG_ROWS + sub * (WG_ROWS / WG_SUB);
+    const int64_t r1 = min(N, r0 + WG_ROWS / WG_SUB);
     float acc[KACC], bacc[KACC];
 #pragma unroll
     for (int k = 0; k < KACC; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
     const bool fok = f < F;
     const bool do_bias = part_b != nullptr && blockIdx.x == 0 && fl == 0;
-    for (int64_t ib = r0; ib < r1; ib += WG_STEP) {
+    for (int64_t ib = (int64_t)blockIdx.z * WG_ROWS + sub * (WG_ROWS / WG_SUB), it = 0;
+         it < WG_ROWS / WG_SUB / WG_STEP; ib += WG_STEP, ++it) {         // uniform trip count (barriers)
         float xv[WG_STEP];
 #pragma unroll
         for (int r = 0; r < WG_STEP; ++r)
             xv[r] = (fok && ib + r < r1) ? x[(ib + r) * F + f] : 0.f;
         __syncthreads();                            // previous step's sg reads are done
-        for (int q = threadIdx.x; q < WG_STEP * CT; q += 256) {
+        for (int q = tid; q < WG_STEP * CT; q += 256) {
             const int r = q / CT, c = q % CT;
-            sg[r][c] = (ib + r < r1 && ct0 + c < C) ? g[(ib + r) * C + ct0 + c] : 0.f;
+            sg[sub][r][c] = (ib + r < r1 && ct0 + c < C) ? g[(ib + r) * C + ct0 + c] : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < WG_STEP; ++r)
 #pragma unroll
             for (int k = 0; k < KACC; ++k) {
-                const float gv = sg[r][half * KACC + k];
+                const float gv = sg[sub][r][half * KACC + k];
                 acc[k] = fmaf(gv, xv[r], acc[k]);
                 if (do_bias) bacc[k] += gv;
             }
     }
+    (void)r0;
+    // combine the four row quarters in fixed order, one accumulator at a time
+#pragma unroll
+    for (int k = 0; k < KACC; ++k) {
+        __syncthreads();
+        if (sub > 0) sred[sub - 1][tid] = acc[k];
+        __syncthreads();
+        if (sub == 0) acc[k] = ((acc[k] + sred[0][tid]) + sred[1][tid]) + sred[2][tid];
+        if (part_b != nullptr && blockIdx.x == 0) {       // block-uniform (barriers inside)
+            __syncthreads();
+            if (sub > 0) sred[sub - 1][tid] = bacc[k];
+            __syncthreads();
+            if (sub == 0) bacc[k] = ((bacc[k] + sred[0][tid]) + sred[1][tid]) + sred[2][tid];
+        }
+    }
+    if (sub != 0) return;
 #pragma unroll
     for (int k = 0; k < KACC; ++k)
         if (c0 + k < C) {
@@ -208,7 +232,8 @@ using namespace sngnn;
 
 extern "C" int64_t sngnn_head_workspace_bytes(int64_t N)
 {
-    return (N + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK * 8 + 256;
+    (void)N;
+    return (int64_t)HEAD_MAX_BLOCKS * 8 + 256;
 }
 
 extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsigned char *row_mask,
@@ -218,7 +243,7 @@ extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsig
     SN_REQUIRE(N >= 0 && C >= 1, SNGNN_EINVAL, "bad shape");
     SN_REQUIRE(logits && y && row_mask && loss_and_correct && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (int)((N + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK);
+    const int nb = (int)std::min<int64_t>((N + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK, HEAD_MAX_BLOCKS);
     const float scale = 1.0f / (float)(n_masked > 0 ? n_masked : 1);     // nll_loss(reduction='mean')
     if (nb > 0)
         k_head<<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
@@ -248,11 +273,11 @@ extern "C" int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t
         dim3 grid((F + WG_FT - 1) / WG_FT, (C + 2 * kacc - 1) / (2 * kacc), chunks);
         float *pb = grad_bias ? part_b : nullptr;
         switch (kacc) {
-        case 8: k_wgrad_partial<8><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
-        case 16: k_wgrad_partial<16><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
-        case 20: k_wgrad_partial<20><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
-        case 24: k_wgrad_partial<24><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
-        default: k_wgrad_partial<32><<<grid, 256, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 8: k_wgrad_partial<8><<<grid, 256 * WG_SUB, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 16: k_wgrad_partial<16><<<grid, 256 * WG_SUB, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 20: k_wgrad_partial<20><<<grid, 256 * WG_SUB, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        case 24: k_wgrad_partial<24><<<grid, 256 * WG_SUB, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
+        default: k_wgrad_partial<32><<<grid, 256 * WG_SUB, 0, st>>>(grad_out, x, N, C, F, part, pb); break;
         }
     }
     const int64_t len = (int64_t)C * F;

@@ -149,13 +149,10 @@ class GraphedEpoch:
         loss.backward()
         self.opt.step()
         with torch.no_grad():
-            self.metrics[0] = loss.detach()
-            self.metrics[1] = correct
             self.model.eval()
-            for slot, which in ((2, "val"), (4, "test")):
-                l, c = self._loss(which)
-                self.metrics[slot] = l
-                self.metrics[slot + 1] = c
+            vl, vc = self._loss("val")
+            tl, tc = self._loss("test")
+            torch.stack([loss.detach(), correct, vl, vc, tl, tc], out=self.metrics)   # one kernel
 
     def run(self) -> Dict[str, float]:
         """Replay one epoch; returns the metrics (one host read)."""
