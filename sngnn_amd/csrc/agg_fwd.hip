@@ -90,6 +90,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
                            : nullptr;
     a.split_cnt = g->split_cnt; a.grp_cnt = g->grp_cnt; a.split_grp0 = g->split_grp0;
     a.cand2 = a.cand_key ? a.cand_key + (size_t)g->n_tasks * 32 : nullptr;
+    a.cand_src = a.cand2 ? (int32_t *)(a.cand2 + (size_t)g->n_groups * 32) : nullptr;
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     a.nbA = ceil_div(g->n_tasks, WAVES);

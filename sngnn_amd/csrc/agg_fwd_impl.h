@@ -44,6 +44,7 @@ struct FwdArgs {
     int xcd_affinity;
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
+    int32_t *cand_src;              // [n_tasks, k]  their source ids (saves the finalize a dependent load)
     int lowbits;                    // bits needed for a row-local edge index
     int32_t *split_cnt;             // [n_split] groups arrived (in-kernel finalize)
     int32_t *grp_cnt;               // [n_groups] tasks arrived per group of FIN_GT tasks
@@ -664,6 +665,9 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
         // write-through (sc1) stores: the row's last-arriving wave reads these keys
         if (ws.kept0) __hip_atomic_store(ck + prefix_popc(m0), ws.key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ws.kept1) __hip_atomic_store(ck + n0 + prefix_popc(m1), ws.key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int32_t *cs = a.cand_src + (size_t)tq * a.k;
+        if (ws.kept0) cs[prefix_popc(m0)] = a.col[rs + e0 + lane];
+        if (ws.kept1) cs[n0 + prefix_popc(m1)] = a.col[rs + e0 + 64 + lane];
         if (lane >= nsel && lane < a.k)           // empty slots (k <= 32 < 64)
             __hip_atomic_store(ck + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.wsel) {     // the finalize overwrites the kept edges of the row
@@ -904,18 +908,19 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int gid = lane / G, lg = lane % G;
     const int p = blockIdx.x;
-    const int i = a.rperm[p];
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
 
-    // dynamic LDS: [WAVES * C] partial rows | keysA [max_slots] | keysB [max_slots]
+    // dynamic LDS: [WAVES * C] partial rows | keysA | keysB [max_slots] | srcA | srcB | count
     float *s_part = reinterpret_cast<float *>(dyn);
     unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)WAVES * a.C + ((WAVES * a.C) & 1));
     unsigned long long *kB = kA + max_slots;
-    int &s_n = *reinterpret_cast<int *>(kB + max_slots);
+    int *sA = reinterpret_cast<int *>(kB + max_slots);
+    int *sB = sA + max_slots;
+    int &s_n = sB[max_slots];
 
     if (!rank) {
         // streaming row (deg <= top_k or no selection): add the tasks' partial rows
@@ -941,7 +946,10 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     }
 
     int n = (t1 - t0) * a.k;
-    for (int q = tid; q < n; q += BLOCK) kA[q] = a.cand_key[(size_t)t0 * a.k + q];
+    for (int q = tid; q < n; q += BLOCK) {
+        kA[q] = a.cand_key[(size_t)t0 * a.k + q];
+        sA[q] = a.cand_src[(size_t)t0 * a.k + q];
+    }
     __syncthreads();
     while (n > 128) {
         const int groups = (n + 127) / 128;
@@ -952,13 +960,14 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
             wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
             const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
             const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
-            if (k0) kB[g * a.k + prefix_popc(m0)] = key0;
-            if (k1) kB[g * a.k + n0 + prefix_popc(m1)] = key1;
+            if (k0) { const int o = g * a.k + prefix_popc(m0); kB[o] = key0; sB[o] = sA[q0]; }
+            if (k1) { const int o = g * a.k + n0 + prefix_popc(m1); kB[o] = key1; sB[o] = sA[q1]; }
             if (lane >= ns && lane < a.k) kB[g * a.k + lane] = 0ull;
         }
         __syncthreads();
         n = groups * a.k;
         unsigned long long *t = kA; kA = kB; kB = t;
+        int *ts = sA; sA = sB; sB = ts;
     }
     if (wave == 0) {
         const unsigned long long key0 = lane < n ? kA[lane] : 0ull;
@@ -967,36 +976,35 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
         wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
         const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
         const int n0 = __popcll(m0);
-        if (k0) kB[prefix_popc(m0)] = key0;
-        if (k1) kB[n0 + prefix_popc(m1)] = key1;
+        if (k0) { const int o = prefix_popc(m0); kB[o] = key0; sB[o] = sA[lane]; }
+        if (k1) { const int o = n0 + prefix_popc(m1); kB[o] = key1; sB[o] = sA[lane + 64]; }
         if (lane == 0) s_n = n0 + __popcll(m1);
     }
     __syncthreads();
     const int nsel = s_n;
     const unsigned long long *win = kB;
+    const int *wsrc = sB;
 
-    for (int q = tid; q < nsel; q += BLOCK) {
-        const unsigned long long kq = win[q];
-        const int idx = key_index(kq);
-        const float sq = key_score(kq);
-        if (a.wsel) a.wsel[rs + idx] = sq;
-        if (emit) {
-            int rk = 0;
-            for (int r = 0; r < nsel; ++r) rk += win[r] > kq;
-            a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
-            a.sel_w[(size_t)i * a.k + rk] = sq;
-        }
-    }
-
+    // gather first (the long latency), bookkeeping stores behind it
     RowT acc;
     acc.zero();
     for (int q0 = 0; q0 < nsel; q0 += WAVES * NG) {
         const int q = q0 + wave * NG + gid;
         if (q < nsel) {
-            const unsigned long long kq = win[q];
             RowT x;
-            x.load(a.h + (size_t)a.col[rs + key_index(kq)] * a.C, a.C, lg);
-            acc.axpy(key_score(kq), x);
+            x.load(a.h + (size_t)wsrc[q] * a.C, a.C, lg);
+            acc.axpy(key_score(win[q]), x);
+        }
+    }
+    for (int q = tid; q < nsel; q += BLOCK) {
+        const unsigned long long kq = win[q];
+        const float sq = key_score(kq);
+        if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
+        if (emit) {
+            int rk = 0;
+            for (int r = 0; r < nsel; ++r) rk += win[r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = wsrc[q];
+            a.sel_w[(size_t)i * a.k + rk] = sq;
         }
     }
     acc.reduce_across_groups();
@@ -1029,7 +1037,7 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
         // streaming rows and candidate tournament
         const int max_tasks = ceil_div(max_split_deg, CHUNK);
         const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
-        const size_t dyn = ((size_t)WAVES * a.C + 1) * 4 + (size_t)max_slots * 16 + 16;
+        const size_t dyn = ((size_t)WAVES * a.C + 1) * 4 + (size_t)max_slots * 24 + 16;
         if (dyn > 150 * 1024) { set_error("in-degree too large for the split-row finalize"); return SNGNN_EINVAL; }
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,

@@ -407,7 +407,8 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
     // forward: scores of split rows | one partial row per split task
     int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
                   (int64_t)g->n_tasks * 32 * 8 +     // + CAND_MAX_K candidate keys per task
-                  (int64_t)g->n_groups * 32 * 8;     // + champions per finalize group
+                  (int64_t)g->n_groups * 32 * 8 +    // + champions per finalize group
+                  (int64_t)g->n_tasks * 32 * 4;      // + candidate source ids
     // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_tasks * C * 4 +
