@@ -40,13 +40,14 @@ def algorithmic_bytes(e_prime: int, n: int, c: int) -> int:
     return e_prime * (4 * c + 8) + n * (8 * c + 8)
 
 
-def make_rank_inputs(name, rank, world, seed, device):
+def make_rank_inputs(name, rank, world, seed, device, channels=None):
     from sngnn_amd import synth
     n, e, f, classes, max_deg, kind, dens = synth.SHAPES[name]
     rng = np.random.default_rng(seed + 7919 * rank)
     ei = synth.make_edges(rng, n, e, max_deg, n_src=n * world, dst_offset=rank * n)
     x = synth.make_features(rng, n, f, kind, dens)
     torch.manual_seed(seed)                     # same lin on every rank
+    classes = channels or classes               # conv output width (default: #classes, 1 layer)
     lin = torch.nn.Linear(f, classes)
     ei = torch.from_numpy(ei).to(device)
     x = torch.from_numpy(x).to(device)
@@ -80,6 +81,8 @@ def main():
     ap.add_argument("--top_k", type=int, default=16)
     ap.add_argument("--thr", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--channels", type=int, default=None,
+                    help="conv output width C (default: the dataset's class count, 40 for arxiv)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true")
     args = ap.parse_args()
@@ -108,7 +111,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
-    n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device)
+    n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device,
+                                                 args.channels)
     n_total = n * world
     if world > 1:
         part = sn_dist.Partition(rank, world, n)
