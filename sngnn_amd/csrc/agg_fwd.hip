@@ -63,6 +63,10 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
         const char *c2 = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_DEBUG_BLOCKS_PER_CU") : e_bpc;
         a.dbg_classes = c1 ? atoi(c1) : 7;
         a.dbg_blocks_per_cu = c2 ? atoi(c2) : 0;
+        { const char *dy = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_DYNAMIC") : nullptr;
+          static const char *dy0 = getenv("SNGNN_DYNAMIC");
+          if (!dy) dy = dy0;
+          a.dynamic = dy ? atoi(dy) : 0; }
         static const char *e_fin = getenv("SNGNN_INKERNEL_FIN");
         a.inkernel_fin = e_fin ? atoi(e_fin) : 0;
         { const char *xa = getenv("SNGNN_DEBUG_LIVE") ? getenv("SNGNN_XCD_AFFINITY") : nullptr;
@@ -84,6 +88,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk;
     a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
     a.xtask_list = g->xtask_list; a.xtask_ptr = g->xtask_ptr;
+    a.dyn_ctr = g->dyn_ctr;
     a.scores = (float *)workspace;
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
     a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)

@@ -42,6 +42,8 @@ struct FwdArgs {
     const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
     const int32_t *xtask_list, *xtask_ptr;   // tasks grouped by source-range eighth (XCD affinity)
     int xcd_affinity;
+    int dynamic;                // wave rows and small-row sets are handed out by atomic counters
+    int32_t *dyn_ctr;           // [2 classes][DYN_SHARDS] counters, 128 bytes apart, zero at launch
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
     int32_t *cand_src;              // [n_tasks, k]  their source ids (saves the finalize a dependent load)
@@ -57,6 +59,11 @@ struct FwdArgs {
     int use_dma;                // classes A/B stream source rows through LDS-DMA (C % 4 == 0, C <= 256)
 };
 
+// The switches below compile measured-but-unprofitable variants into the
+// main kernel; off by default so they cost the shipped kernel no registers.
+#ifndef SNGNN_EXPERIMENTAL
+#define SNGNN_EXPERIMENTAL 0         // in-kernel finalize, dynamic work counters, XCD-affine tasks
+#endif
 #ifndef SNGNN_ENABLE_DMA
 #define SNGNN_ENABLE_DMA 0           // LDS-DMA scoring path: measured no faster than register staging
 #endif
@@ -240,20 +247,67 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 // one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
+// Hands a wave its small-row sets.  Static: set0, set0 + stride, ...  Dynamic: chunks of
+// DYN_SETS consecutive sets taken from a per-shard atomic counter (shard = workgroup id
+// mod #shards; chunk c of shard x covers sets (x + #shards c) * DYN_SETS ...), the next chunk is
+// requested as soon as the current one is entered so the atomic's latency is hidden.
+constexpr int DYN_SETS = 2;
+constexpr int DYN_SHARDS = 64;          // counters per class (workgroup id mod DYN_SHARDS)
+constexpr int DYN_CTR_STRIDE = 32;      // ints (128 bytes) between counters
+
+__device__ __forceinline__ int dyn_fetch(int32_t *ctr)
+{
+    int v = 0;
+    if (lane_id() == 0) v = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;      // lane 0 holds the value: readfirstlane at the point of use
+}
+
+struct SetSeq {
+    int pos, end, stride, nsets;        // static: pos advances by stride; dynamic: [pos, end) is a chunk
+    int nxt_raw;                        // dynamic: result of the pending dequeue (lane 0)
+    int32_t *ctr;                       // nullptr = static
+    int shard, nsh;                     // this wave's shard and the number of shards
+
+    __device__ __forceinline__ void init_static(int set0, int st, int n)
+    { pos = set0; stride = st; nsets = n; end = n; ctr = nullptr; nxt_raw = 0; shard = 0; nsh = 1; }
+
+    __device__ __forceinline__ void init_dynamic(int32_t *c, int sh, int nshards, int n)
+    {
+        ctr = c; shard = sh; nsh = nshards; nsets = n; stride = 1;
+        const int c0 = __builtin_amdgcn_readfirstlane(dyn_fetch(ctr));
+        pos = (shard + nsh * c0) * DYN_SETS;
+        end = min(pos + DYN_SETS, nsets);
+        nxt_raw = pos < nsets ? dyn_fetch(ctr) : 0;
+    }
+
+    // next set id, or -1 when the wave's share is exhausted
+    __device__ __forceinline__ int next()
+    {
+        if (pos >= nsets) return -1;
+        const int s = pos;
+        pos += stride;
+        if (ctr != nullptr && pos >= end) {             // enter the chunk requested earlier
+            const int c = __builtin_amdgcn_readfirstlane(nxt_raw);
+            pos = (shard + nsh * c) * DYN_SETS;
+            end = min(pos + DYN_SETS, nsets);
+            if (pos < nsets) nxt_raw = dyn_fetch(ctr); else pos = nsets;
+        }
+        return s;
+    }
+};
+
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_small(const FwdArgs &a, int set, int stride, int *lds_wave)
+__device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
     constexpr int CPL = (RPW * SMALL_T + 63) / 64;      // column ids per lane per set
     const int lane = lane_id();
     const int gid = lane / G;
-    const int n_small = a.N - a.n_med_end;
-    const int nsets = (n_small + RPW - 1) / RPW;
-    if (set >= nsets) return;
+    const int nsets = seq.nsets;
 
     auto load_desc = [&](int st) -> int4 {
         const int slot = a.n_med_end + st * RPW + gid;
-        return (st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
+        return (st >= 0 && st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
     };
     // lane l fetches column ids q = l + 64 m of the set: row q / SMALL_T, edge q % SMALL_T
     auto load_cols = [&](const int4 d, int (&c)[CPL]) {
@@ -274,23 +328,28 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set, int stride
         }
     };
 
+    int s_cur = seq.next();
+    if (s_cur < 0) return;
+    int s_nxt = seq.next();
     int *s_colbuf[2] = {lds_wave, lds_wave + 128};      // [RPW][SMALL_T] each
-    int4 d_cur = load_desc(set);
-    int4 d_nxt = load_desc(set + stride);
+    int4 d_cur = load_desc(s_cur);
+    int4 d_nxt = load_desc(s_nxt);
     int cols[CPL];
     load_cols(d_cur, cols);
     store_cols(cols, s_colbuf[0]);
     int buf = 0;
-    while (set < nsets) {
-        const int4 d_n2 = load_desc(set + 2 * stride);
+    while (s_cur >= 0) {
+        const int s_n2 = seq.next();
+        const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
         small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, s_colbuf[buf]);
         store_cols(cols, s_colbuf[buf ^ 1]);
         d_cur = d_nxt;
         d_nxt = d_n2;
+        s_cur = s_nxt;
+        s_nxt = s_n2;
         buf ^= 1;
-        set += stride;
     }
 }
 
@@ -675,7 +734,7 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             if (lane < e1 - e0) __hip_atomic_store(w + lane, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane + 64 < e1 - e0) __hip_atomic_store(w + lane + 64, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (a.inkernel_fin) {
+        if (SNGNN_EXPERIMENTAL && a.inkernel_fin) {
             unsigned long long *champ = reinterpret_cast<unsigned long long *>(lds_wave);   // [32]
             const int t0 = a.split_task0[p], nt = a.split_task0[p + 1] - t0;
             const int gl = c / FIN_GT;                                  // my group inside the row
@@ -719,7 +778,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     const int nw = gridDim.x * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
-    if (a.xcd_affinity && (gridDim.x & 7) == 0) {
+    if (SNGNN_EXPERIMENTAL && a.xcd_affinity && (gridDim.x & 7) == 0) {
         // Workgroups b and b + 8 share an XCD (observed round-robin placement; speed
         // only, never correctness).  XCD group x takes the tasks whose sources lie in
         // the x-th eighth of the node range: ~1/8 of the feature table per L2.
@@ -735,10 +794,30 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
             if (a.dbg_classes & 1) role_task<VEC, G, R>(a, it, lw);
         it -= a.n_tasks;
     }
-    for (; it < n_wave_rows; it += nw)
-        if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, it, lw);
-    it -= n_wave_rows;
-    if (a.dbg_classes & 4) role_small<VEC, G, R>(a, it, nw, lw);
+    constexpr int RPW = 64 / G;
+    const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
+    SetSeq seq;
+    if (SNGNN_EXPERIMENTAL && a.dynamic) {
+        // after its (static) tasks a wave asks for work: waves that also finalized a
+        // split row simply come back later and take less
+        const int nsh = min(DYN_SHARDS, (int)gridDim.x);     // every shard must have a workgroup
+        const int shard = blockIdx.x % nsh;
+        int32_t *ctr_b = a.dyn_ctr + shard * DYN_CTR_STRIDE;
+        int raw = dyn_fetch(ctr_b);
+        for (;;) {
+            const int row = shard + nsh * __builtin_amdgcn_readfirstlane(raw);
+            if (row >= n_wave_rows) break;
+            raw = dyn_fetch(ctr_b);             // requested before the row is processed
+            if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, row, lw);
+        }
+        seq.init_dynamic(a.dyn_ctr + (DYN_SHARDS + shard) * DYN_CTR_STRIDE, shard, nsh, nsets);
+    } else {
+        for (; it < n_wave_rows; it += nw)
+            if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, it, lw);
+        it -= n_wave_rows;
+        seq.init_static(it, nw, nsets);
+    }
+    if (a.dbg_classes & 4) role_small<VEC, G, R>(a, seq, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1027,11 +1106,12 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
     // persistent grid: what the chip holds at the kernel's occupancy, or less
     const int bpc = a.dbg_blocks_per_cu > 0 ? a.dbg_blocks_per_cu : FWD_WAVES_PER_SIMD;
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * bpc);
+    if (SNGNN_EXPERIMENTAL && a.dynamic) SN_HIP(hipMemsetAsync(a.dyn_ctr, 0, 2 * DYN_SHARDS * DYN_CTR_STRIDE * sizeof(int32_t), st));
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
     const bool any_streaming_split = a.k < 0 || a.k > WAVE_T;   // split rows have deg > WAVE_T
-    if (a.n_split > 0 && a.k <= CAND_MAX_K && !any_streaming_split && a.inkernel_fin) {
+    if (SNGNN_EXPERIMENTAL && a.n_split > 0 && a.k <= CAND_MAX_K && !any_streaming_split && a.inkernel_fin) {
         // every split row is finalized inside k_agg_fwd by its last-arriving task
     } else if (a.n_split > 0 && (a.k < 0 || a.k <= CAND_MAX_K)) {
         // streaming rows and candidate tournament

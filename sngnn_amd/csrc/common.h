@@ -71,6 +71,7 @@ struct sngnn_graph {
     int32_t *xtask_list = nullptr;    // [n_tasks] task ids grouped by the eighth of the node range their
     int32_t *xtask_ptr = nullptr;     // [9]       sources fall in (one group per XCD: L2 affinity)
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
+    int32_t *dyn_ctr = nullptr;       // [16 * 32] work counters of the forward kernel (zeroed per launch)
     int32_t *split_cnt = nullptr;     // [n_split] groups arrived (in-kernel finalize); 0 between launches
     int32_t *grp_cnt = nullptr;       // [n_groups] tasks arrived per group of FIN_GT tasks
     int32_t *split_grp0 = nullptr;    // [n_split+1] first group of each split row

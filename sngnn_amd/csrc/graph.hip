@@ -303,6 +303,7 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if ((rc = build_tasks(g->rdeg, g->n_split, &g->task_slot, &g->task_chunk, &g->split_task0,
                           &g->split_soff, &g->n_tasks, &g->split_edges)))
         return rc;
+    if ((rc = dev_alloc(&g->dyn_ctr, 2 * 64 * 32))) return rc;     // 2 classes x DYN_SHARDS x 128 B
     {   // split-row tasks grouped by the XCD whose L2 should hold their source rows
         std::vector<int32_t> bucket((size_t)g->n_tasks, 0), list((size_t)g->n_tasks, 0), ptr(9, 0);
         if (g->n_tasks > 0) {
@@ -388,7 +389,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
-                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt, g->grp_cnt, g->split_grp0, g->xtask_list, g->xtask_ptr,
+                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt, g->grp_cnt, g->split_grp0, g->xtask_list, g->xtask_ptr, g->dyn_ctr,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;

@@ -34,13 +34,13 @@ def timeit(reps=60):
     return float(np.median(ms[10:])) * 1e3, float(np.median(fs[10:])) * 1e3
 
 
-os.environ["SNGNN_INKERNEL_FIN"] = "0"
-for fin in (0, 1):
-    os.environ["SNGNN_XCD_AFFINITY"] = str(fin)
-    for cls in (7, 1):
-        os.environ["SNGNN_DEBUG_CLASSES"] = str(cls)
-        for bpc in (5, 6):
-            os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
-            med, fm = timeit()
-            print(f"xcd_affinity={fin} classes={cls} blocks/CU={bpc}: main {med:7.1f} us  "
-                  f"separate finalize {fm:6.1f} us  total {med + fm:7.1f}", flush=True)
+os.environ["SNGNN_XCD_AFFINITY"] = "0"
+for dyn, fin in ((0, 0), (1, 0), (1, 1)):
+    os.environ["SNGNN_DYNAMIC"] = str(dyn)
+    os.environ["SNGNN_INKERNEL_FIN"] = str(fin)
+    for bpc in (5, 6, 7):
+        os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
+        os.environ["SNGNN_DEBUG_CLASSES"] = "7"
+        med, fm = timeit()
+        print(f"dynamic={dyn} inkernel_fin={fin} blocks/CU={bpc}: main {med:7.1f} us  "
+              f"separate finalize {fm:6.1f} us  total {med + fm:7.1f}", flush=True)
