@@ -150,3 +150,79 @@ def class_similarity_dense_small(x, y):
 def class_similarity_dense_large(x, y):
     """dense.py:104-130: block sums / block sizes (== the small variant's matrix)."""
     return class_similarity_dense_small(x, y)[0]
+
+
+# ---------------------------------------------------------------------------
+# SimGFAToolbox/sparse.py: the same statistics on the column-normalised input
+# (``cosine_similarity_sparse`` returns M_n^T M_n - node-to-node cosine when M is the
+# [N, N] adjacency, as in toolbox-example.py:28-29).  Here the input is densified on
+# the GPU and sent through the MFMA cosine of its transpose; that is the right tool
+# for the small/medium graphs the reference's Python ``getrow`` loops can handle at
+# all.  For inputs too large to densify the scipy path of the reference remains the
+# baseline (SURVEY.md section 2 row 6).
+# ---------------------------------------------------------------------------
+_DENSE_LIMIT = 1 << 31      # elements of the densified input / of the [M, M] result
+
+
+def _as_dense_gpu(mat, device=None) -> torch.Tensor:
+    if isinstance(mat, torch.Tensor):
+        t = mat.to_dense() if mat.layout != torch.strided else mat
+    else:                                   # scipy.sparse matrix
+        coo = mat.tocoo()
+        idx = torch.from_numpy(__import__("numpy").vstack([coo.row, coo.col])).long()
+        t = torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data).float(), coo.shape)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = t.to(device).to_dense()
+    if device is not None:
+        t = t.to(device)
+    if not t.is_cuda:
+        raise ValueError("the matrix must live on the GPU (or be a scipy.sparse matrix)")
+    if t.numel() > _DENSE_LIMIT or t.size(1) ** 2 > _DENSE_LIMIT:
+        raise ValueError("input too large to densify on the GPU; use the reference's scipy path")
+    return t.to(torch.float32)
+
+
+def cosine_similarity_sparse(mat, device=None) -> torch.Tensor:
+    """sparse.py:8-14: normalise the COLUMNS of ``mat`` and return ``M_n.T @ M_n``
+    ([cols, cols], dense on the GPU)."""
+    m = _as_dense_gpu(mat, device)
+    return cosine_similarity_dense_small(m.t().contiguous())
+
+
+def node_similarity_sparse(x, device=None):
+    """sparse.py:17-42: every entry of the similarity (diagonal included, as the
+    reference lists them) and their mean."""
+    sim = cosine_similarity_sparse(x, device)
+    return sim.reshape(-1, 1), torch.mean(sim)
+
+
+def linked_node_similarity_sparse(x, edge_index, device=None):
+    """sparse.py:45-77: the similarity at the linked pairs (edge order preserved)."""
+    sim = cosine_similarity_sparse(x, device)
+    ei = edge_index.to(sim.device)
+    vals = sim[ei[0], ei[1]]
+    return vals.reshape(-1, 1), torch.mean(vals)
+
+
+def neighborhood_similarity_sparse(x, edge_index, device=None):
+    """sparse.py:80-120: per node the mean similarity to its out-neighbours (0 for a
+    node without out-edges) and the mean over all nodes."""
+    sim = cosine_similarity_sparse(x, device)
+    ei = edge_index.to(sim.device)
+    n = sim.size(0)
+    tot, cnt = _mean_by_source(sim[ei[0], ei[1]], ei[0], n)
+    per_node = torch.where(cnt > 0, tot / cnt.clamp(min=1), torch.zeros_like(tot)).to(torch.float32)
+    return per_node.reshape(-1, 1), per_node.sum() / n
+
+
+def class_similarity_sparse(x, y, device=None):
+    """sparse.py:123-152: block sums / block sizes of the similarity per class pair."""
+    sim = cosine_similarity_sparse(x, device)
+    yl = y.to(sim.device).long()
+    n_classes = len(torch.unique(yl))
+    onehot = torch.zeros((sim.size(0), n_classes), dtype=torch.float64, device=sim.device)
+    onehot[torch.arange(sim.size(0), device=sim.device), yl] = 1.0
+    sums = onehot.t() @ sim.double() @ onehot
+    cnt = onehot.sum(0)
+    return (sums / (cnt[:, None] * cnt[None, :])).to(torch.float32)

@@ -45,3 +45,42 @@ for name, (n, e, C, hubs, add, rem, k, thr) in CASES.items():
         arrays["sel_src"] = ref["sel_src"].numpy()
     np.savez_compressed(os.path.join(OUT, f"agg_{name}.npz"), **arrays)
     print(name, "E' =", ref["ei"].size(1))
+
+
+# ---------------------------------------------------------------------------
+# Harness fixture ("Harness row"): the reference trainer's loop
+# (train.py:73-160) on the oracle's restated models, CPU, seeded.
+# ---------------------------------------------------------------------------
+def make_trajectory(kind, args, name, epochs=5):
+    import torch.nn.functional as F
+    from sngnn_amd import synth
+    data = synth.make_dataset("cora", seed=7, scale=0.25)
+    torch.manual_seed(1234)
+    model = getattr(O, kind)(*args(data.x.size(1), data.x.size(0)))
+    init = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    traj = []
+    for _ in range(epochs):
+        model.train()
+        opt.zero_grad()
+        out = model(data)
+        loss = F.nll_loss(out[data.train_mask], data.y[data.train_mask])
+        loss.backward()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            out = model(data)
+            rec = [float(loss)]
+            for m in (data.val_mask, data.test_mask):
+                rec += [float(F.nll_loss(out[m], data.y[m])),
+                        float((out[m].max(1)[1] == data.y[m]).float().mean())]
+        traj.append(rec)
+    final = {"final." + k: v.clone().numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, f"traj_{name}.npz"), traj=np.array(traj, np.float64),
+                        **{"init." + k: v for k, v in init.items()}, **final)
+    print(name, "trajectory", [round(t[0], 4) for t in traj])
+
+
+make_trajectory("SNGNN_Plus", lambda f, n: (f, 16, 7, n, 2, 3, 0.1, 1, 0.0), "plus_2layer")
+make_trajectory("SNGNN_Plus_Plus", lambda f, n: (f, 16, 7, n, 1, 4, 0.2, 0.3, 1, 0.0), "plusplus_1layer")
+make_trajectory("SNGNN", lambda f, n: (f, 16, 7, 1), "sngnn_1layer")

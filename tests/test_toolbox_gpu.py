@@ -95,3 +95,37 @@ def test_toolbox_argument_errors(cuda):
     bad = torch.tensor([[0, 1], [2, 99]])
     with pytest.raises(ValueError, match="outside"):
         T.edge_cosine(x.to(cuda), bad.to(cuda))
+
+
+def test_sparse_variants_against_scipy_sklearn(cuda):
+    """SimGFAToolbox/sparse.py semantics: column-normalised M^T M on the adjacency
+    (toolbox-example.py:28-29), checked against scipy/sklearn, the libraries the
+    reference itself calls (sparse.py:13-14)."""
+    import scipy.sparse as sp
+    import sklearn.preprocessing as pp
+    from sngnn_amd import toolbox as T
+    n = 300
+    ei = random_graph(n, 2500, 8)
+    adj = sp.csc_matrix((np.ones(ei.size(1)), (ei[0].numpy(), ei[1].numpy())), shape=(n, n))
+    coln = pp.normalize(adj.tocsc(), axis=0)
+    ref = torch.from_numpy((coln.T * coln).toarray()).float()
+    sim = T.cosine_similarity_sparse(adj, device=cuda)
+    assert sim.shape == (n, n) and (sim.cpu() - ref).abs().max() < 2e-6
+    allsim, mean = T.node_similarity_sparse(adj, device=cuda)
+    assert allsim.shape == (n * n, 1) and abs(float(mean) - float(ref.mean())) < 1e-6
+    lv, lm = T.linked_node_similarity_sparse(adj, ei, device=cuda)
+    want = ref[ei[0], ei[1]]
+    assert (lv.cpu().flatten() - want).abs().max() < 2e-6 and abs(float(lm) - float(want.mean())) < 1e-6
+    pn, pm = T.neighborhood_similarity_sparse(adj, ei, device=cuda)
+    full = torch.zeros(n)
+    cnt = torch.bincount(ei[0], minlength=n)
+    full.index_add_(0, ei[0], want)
+    full = torch.where(cnt > 0, full / cnt.clamp(min=1), torch.zeros(n))
+    assert (pn.cpu().flatten() - full).abs().max() < 2e-6 and abs(float(pm) - float(full.sum() / n)) < 1e-6
+    y = torch.randint(0, 4, (n,), generator=torch.Generator().manual_seed(1))
+    y[:4] = torch.arange(4)
+    cm = T.class_similarity_sparse(adj, y, device=cuda).cpu()
+    for a in range(4):
+        for b in range(4):
+            blk = ref[y == a][:, y == b]
+            assert abs(float(cm[a, b]) - float(blk.mean())) < 1e-6
