@@ -55,20 +55,30 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 // S = diag(inv) X X^T diag(inv) with fp32 MFMA.  Workgroup = 256 threads = 2x2
 // waves, 128x128 output tile, each wave 64x64 = 2x2 MFMA blocks of 32x32.
-// LDS holds the A (row block) and B (column block) panels [128][BK] with a
-// padded stride so the per-lane reads (lane -> row l&31, k = l>>5) are conflict free.
+//   * S is symmetric: only tiles with row block <= column block are computed, each
+//     writes its mirror image as well (half the flops of the reference's full mm);
+//   * panels [128][32] of the row block and of the column block go through LDS with
+//     a padded stride of 33 floats (lane -> (row l & 31, k = l >> 5) reads hit 32
+//     different banks); global loads are coalesced 128-byte row segments and the
+//     NEXT k-step's panels are already in registers while the current one is
+//     multiplied (one LDS buffer, register double buffering).
 // ---------------------------------------------------------------------------
-constexpr int TB_M = 128, TB_K = 16, TB_LD = TB_K + 1;
+constexpr int TB_M = 128, TB_K = 32, TB_LD = TB_K + 1, TB_LOADS = TB_M * TB_K / 256;
 
 __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x, int64_t N,
                                                      int64_t F, const float *__restrict__ inv,
-                                                     float *__restrict__ S)
+                                                     float *__restrict__ S, int nb)
 {
     __shared__ float sA[TB_M * TB_LD];
     __shared__ float sB[TB_M * TB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;          // wave's 64x64 quadrant
-    const int64_t row0 = (int64_t)blockIdx.y * TB_M, col0 = (int64_t)blockIdx.x * TB_M;
+    // linear workgroup id -> (by <= bx) of the upper triangle, row by row
+    int by = 0, rem = blockIdx.x;
+    while (rem >= nb - by) { rem -= nb - by; ++by; }
+    const int bx = by + rem;
+    const int64_t row0 = (int64_t)by * TB_M, col0 = (int64_t)bx * TB_M;
+    const bool diag = by == bx;
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -77,17 +87,28 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // staging: thread t copies 8 floats of each panel per K step: row t/2, half (t&1)*8
-    const int sr = tid >> 1, sk = (tid & 1) * 8;
-    for (int64_t k0 = 0; k0 < F; k0 += TB_K) {
+    // staging: thread t owns column t & 31 of rows (t >> 5) + 8 u, u = 0..15
+    const int sc = tid & 31, sr = tid >> 5;
+    float ra[TB_LOADS], rb[TB_LOADS];
+    auto fetch = [&](int64_t k0) {
+        const int64_t k = k0 + sc;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t k = k0 + sk + u;
-            const int64_t ra = row0 + sr, rb = col0 + sr;
-            sA[sr * TB_LD + sk + u] = (ra < N && k < F) ? x[ra * F + k] : 0.f;
-            sB[sr * TB_LD + sk + u] = (rb < N && k < F) ? x[rb * F + k] : 0.f;
+        for (int u = 0; u < TB_LOADS; ++u) {
+            const int64_t r_a = row0 + sr + 8 * u, r_b = col0 + sr + 8 * u;
+            ra[u] = (r_a < N && k < F) ? x[r_a * F + k] : 0.f;
+            rb[u] = diag ? ra[u] : ((r_b < N && k < F) ? x[r_b * F + k] : 0.f);
+        }
+    };
+    fetch(0);
+    for (int64_t k0 = 0; k0 < F; k0 += TB_K) {
+        __syncthreads();                                  // previous step's LDS reads are done
+#pragma unroll
+        for (int u = 0; u < TB_LOADS; ++u) {
+            sA[(sr + 8 * u) * TB_LD + sc] = ra[u];
+            sB[(sr + 8 * u) * TB_LD + sc] = rb[u];
         }
         __syncthreads();
+        if (k0 + TB_K < F) fetch(k0 + TB_K);              // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < TB_K; kk += 2) {
             float a[2], b[2];
@@ -103,7 +124,6 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
                 for (int tb = 0; tb < 2; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
-        __syncthreads();
     }
     // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -115,7 +135,11 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t rr = row0 + wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (rr < N && c < N) S[rr * N + c] = acc[ta][tb][r] * (inv[rr] * ic);
+                if (rr < N && c < N) {
+                    const float v = acc[ta][tb][r] * (inv[rr] * ic);
+                    S[rr * N + c] = v;
+                    if (!diag) S[c * N + rr] = v;         // mirror image of an off-diagonal tile
+                }
             }
         }
 }
@@ -235,8 +259,8 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     AsyncBuf inv(st);
     SN_REQUIRE(inv.alloc((size_t)N * 4) == 0, SNGNN_ENOMEM, "out of device memory");
     k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(), nullptr);
-    dim3 grid((unsigned)((N + TB_M - 1) / TB_M), (unsigned)((N + TB_M - 1) / TB_M));
-    k_cosine_mfma<<<grid, 256, 0, st>>>(x, N, F, inv.as<float>(), S);
+    const int nb = (int)((N + TB_M - 1) / TB_M);
+    k_cosine_mfma<<<nb * (nb + 1) / 2, 256, 0, st>>>(x, N, F, inv.as<float>(), S, nb);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
