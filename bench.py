@@ -40,9 +40,11 @@ def algorithmic_bytes(e_prime: int, n: int, c: int) -> int:
     return e_prime * (4 * c + 8) + n * (8 * c + 8)
 
 
-def make_rank_inputs(name, rank, world, seed, device, channels=None):
+def make_rank_inputs(name, rank, world, seed, device, channels=None, scale=1.0):
     from sngnn_amd import synth
     n, e, f, classes, max_deg, kind, dens = synth.SHAPES[name]
+    if scale != 1.0:
+        n, e = int(n * scale), int(e * scale)
     rng = np.random.default_rng(seed + 7919 * rank)
     ei = synth.make_edges(rng, n, e, max_deg, n_src=n * world, dst_offset=rank * n)
     x = synth.make_features(rng, n, f, kind, dens)
@@ -81,6 +83,7 @@ def main():
     ap.add_argument("--top_k", type=int, default=16)
     ap.add_argument("--thr", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (exploration only)")
     ap.add_argument("--channels", type=int, default=None,
                     help="conv output width C (default: the dataset's class count, 40 for arxiv)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +115,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device,
-                                                 args.channels)
+                                                 args.channels, args.scale)
     n_total = n * world
     if world > 1:
         part = sn_dist.Partition(rank, world, n)

@@ -140,3 +140,25 @@ def test_training_trajectory_matches_committed_fixture(cuda, kind, args, name):
         # Adam turns a last-bit difference of a near-zero gradient into a visible step;
         # 5e-5 is 0.1 % of the 0.05 a parameter can move in 5 steps at lr 0.01
         assert np.abs(v.cpu().numpy() - w).max() <= 5e-5, k
+
+
+def test_odd_channel_count_takes_the_padded_path_and_matches_oracle(cuda):
+    """C = 47 (ogbn-products' class count): h is produced with one zero channel so rows
+    are 16-byte aligned; outputs, gradients and the state_dict are unaffected."""
+    n, f, c = 400, 30, 47
+    ei = random_graph(n, 5000, seed=3, hubs=((0, 399), (7, 150)))
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, f, generator=gen)
+    y = torch.randint(0, c, (n,), generator=gen)
+    ours, ref = build_pair("SNGNN_Plus", (f, 47, c, n, 2, 8, 0.0, 1, 0.0))
+    ours = ours.to(cuda)
+    assert ours.lins[0].lin.weight.shape == (47, f)
+    out_ref = ref(Data(x=x, edge_index=ei))
+    out = ours(Data(x=x.to(cuda), edge_index=ei.to(cuda)))
+    assert out.shape == (n, c)
+    assert_close(out, out_ref, what="log-probs", rtol=1e-4, atol=2e-5)
+    F.nll_loss(out_ref, y).backward()
+    F.nll_loss(out, y.to(cuda)).backward()
+    for (name, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
+        scale = q.grad.abs().max().clamp_min(1e-12)
+        assert (p.grad.cpu() - q.grad).abs().max() <= 2e-4 * scale + 1e-7, name
