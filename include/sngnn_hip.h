@@ -211,6 +211,13 @@ int sngnn_head_nll(const float *logits, const int64_t *y, const unsigned char *r
  *   grad_weight [C, F] = grad_out^T [C, N] . x [N, F],  grad_bias [C] = sum_i grad_out[i]
  * (grad_bias may be NULL).  workspace: sngnn_linear_wgrad_workspace_bytes(N, C, F).
  */
+/*
+ * Replaces: self.lin's forward for narrow layers, h = x W^T + b with C <= 64
+ * (models.py:121,237,324).  x dev f32 [N, F], weight dev f32 [C, F], bias dev f32 [C]
+ * or NULL, h dev f32 [N, C].  Exact-fp32 MFMA; HBM-bound (x read once).
+ */
+int sngnn_linear_forward(const float *x, const float *weight, const float *bias,
+                         int64_t N, int F, int C, float *h, void *stream);
 int64_t sngnn_linear_wgrad_workspace_bytes(int64_t N, int C, int F);
 int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t N, int C, int F,
                        float *grad_weight, float *grad_bias, void *workspace, void *stream);

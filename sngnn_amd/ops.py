@@ -171,7 +171,8 @@ def _workspace(key, nbytes, device):
 
 
 class _Linear(torch.autograd.Function):
-    """``self.lin(x)`` (models.py:121,237,324): rocBLAS forward, hand-written weight
+    """``self.lin(x)`` (models.py:121,237,324): hand-written streaming MFMA forward for
+    narrow layers on big graphs (rocBLAS otherwise), hand-written weight
     gradient (the [C, F] result reduces over all N rows - a shape the BLAS heuristic
     handles poorly), grad_x through rocBLAS only when x needs it."""
 
@@ -179,7 +180,18 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        n, f = x.shape
+        c = weight.size(0)
+        if c > 64 or n < 4096:          # wide layer or tiny graph: the BLAS is the right tool
+            return torch.nn.functional.linear(x, weight, bias)
+        xc, wc = x.contiguous(), weight.contiguous()
+        bc = None if bias is None else bias.contiguous()
+        h = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().sngnn_linear_forward(xc.data_ptr(), wc.data_ptr(), _lib.ptr(bc), n, f, c,
+                                                  h.data_ptr(), _stream(x.device))
+        _lib.check(rc, "sngnn_linear_forward")
+        return h
 
     @staticmethod
     def backward(ctx, g):

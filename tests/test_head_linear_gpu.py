@@ -31,7 +31,8 @@ def test_head_matches_log_softmax_nll_and_accuracy(cuda, n, c):
     assert float(l2) == float(loss) and int(c2) == corr_ref
 
 
-@pytest.mark.parametrize("n,f,c", [(3000, 128, 40), (2277, 2325, 5), (1000, 33, 47), (513, 200, 70)])
+@pytest.mark.parametrize("n,f,c", [(3000, 128, 40), (2277, 2325, 5), (1000, 33, 47), (513, 200, 70),
+                                   (9000, 128, 40), (5001, 77, 64), (4500, 1433, 7), (4100, 100, 33)])
 def test_linear_wgrad_matches_autograd(cuda, n, f, c):
     from sngnn_amd import ops
     g = torch.Generator().manual_seed(f)
@@ -42,7 +43,8 @@ def test_linear_wgrad_matches_autograd(cuda, n, f, c):
     gw_ref, gb_ref = lin.weight.grad.clone(), lin.bias.grad.clone()
     lin.zero_grad()
     out = ops.linear(x, lin)
-    assert torch.equal(out, lin(x))
+    ref_out = lin(x)
+    assert (out - ref_out).abs().max() <= 2e-6 * max(1.0, float(ref_out.abs().max()))
     (out * gout).sum().backward()
     tol_w = 2e-5 * float(gw_ref.abs().max())
     assert (lin.weight.grad - gw_ref).abs().max() <= tol_w
