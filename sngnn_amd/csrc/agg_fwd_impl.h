@@ -978,8 +978,10 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
 // one 256-thread workgroup per row merges the tasks' candidate keys 128 at a
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
+constexpr int FINC_BLOCK = 512, FINC_WAVES = FINC_BLOCK / 64;   // 8 waves: the tournament's first level runs wide
+
 template <int VEC, int G, int R>
-__global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
+__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
@@ -993,9 +995,9 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
 
-    // dynamic LDS: [WAVES * C] partial rows | keysA | keysB [max_slots] | srcA | srcB | count
+    // dynamic LDS: [FINC_WAVES * C] partial rows | keysA | keysB [max_slots] | srcA | srcB | count
     float *s_part = reinterpret_cast<float *>(dyn);
-    unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)WAVES * a.C + ((WAVES * a.C) & 1));
+    unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)FINC_WAVES * a.C + ((FINC_WAVES * a.C) & 1));
     unsigned long long *kB = kA + max_slots;
     int *sA = reinterpret_cast<int *>(kB + max_slots);
     int *sB = sA + max_slots;
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
 
     if (!rank) {
         // streaming row (deg <= top_k or no selection): add the tasks' partial rows
-        for (int c = tid; c < a.C; c += BLOCK) {
+        for (int c = tid; c < a.C; c += FINC_BLOCK) {
             float s = 0.f;
             for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
             a.out[(size_t)i * a.C + c] = s / (float)deg;
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
             // selection of a streaming split row: every edge >= thr, ranked.  Rare
             // (needs top_k >= deg > WAVE_T); done by plain counting from the scratch scores.
             const float *sc = a.scores + a.split_soff[p];
-            for (int e = tid; e < deg; e += BLOCK) {
+            for (int e = tid; e < deg; e += FINC_BLOCK) {
                 const float se = sc[e];
                 if (!(se >= a.thr)) continue;
                 int rk = 0;
@@ -1025,14 +1027,14 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     }
 
     int n = (t1 - t0) * a.k;
-    for (int q = tid; q < n; q += BLOCK) {
+    for (int q = tid; q < n; q += FINC_BLOCK) {
         kA[q] = a.cand_key[(size_t)t0 * a.k + q];
         sA[q] = a.cand_src[(size_t)t0 * a.k + q];
     }
     __syncthreads();
     while (n > 128) {
         const int groups = (n + 127) / 128;
-        for (int g = wave; g < groups; g += WAVES) {
+        for (int g = wave; g < groups; g += FINC_WAVES) {
             const int q0 = g * 128 + lane, q1 = q0 + 64;
             const unsigned long long key0 = q0 < n ? kA[q0] : 0ull, key1 = q1 < n ? kA[q1] : 0ull;
             bool k0, k1;
@@ -1067,7 +1069,7 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     // gather first (the long latency), bookkeeping stores behind it
     RowT acc;
     acc.zero();
-    for (int q0 = 0; q0 < nsel; q0 += WAVES * NG) {
+    for (int q0 = 0; q0 < nsel; q0 += FINC_WAVES * NG) {
         const int q = q0 + wave * NG + gid;
         if (q < nsel) {
             RowT x;
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
             acc.axpy(key_score(win[q]), x);
         }
     }
-    for (int q = tid; q < nsel; q += BLOCK) {
+    for (int q = tid; q < nsel; q += FINC_BLOCK) {
         const unsigned long long kq = win[q];
         const float sq = key_score(kq);
         if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
@@ -1089,9 +1091,9 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_cand(const FwdArgs a, int max
     acc.reduce_across_groups();
     if (gid == 0) acc.store(s_part + (size_t)wave * a.C, a.C, lg);
     __syncthreads();
-    for (int ch = tid; ch < a.C; ch += BLOCK) {
+    for (int ch = tid; ch < a.C; ch += FINC_BLOCK) {
         float s = 0.f;
-        for (int w = 0; w < WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
+        for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
         a.out[(size_t)i * a.C + ch] = s / (float)deg;
     }
 }
@@ -1117,12 +1119,12 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
         // streaming rows and candidate tournament
         const int max_tasks = ceil_div(max_split_deg, CHUNK);
         const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
-        const size_t dyn = ((size_t)WAVES * a.C + 1) * 4 + (size_t)max_slots * 24 + 16;
+        const size_t dyn = ((size_t)FINC_WAVES * a.C + 1) * 4 + (size_t)max_slots * 24 + 16;
         if (dyn > 150 * 1024) { set_error("in-degree too large for the split-row finalize"); return SNGNN_EINVAL; }
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        k_agg_fin_cand<VEC, G, R><<<a.n_split, BLOCK, dyn, st>>>(a, max_slots);
+        k_agg_fin_cand<VEC, G, R><<<a.n_split, FINC_BLOCK, dyn, st>>>(a, max_slots);
     } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)(a.k < 0 ? 0 : a.k) * 4;
         const size_t budget = 120 * 1024;
