@@ -978,7 +978,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
 // one 256-thread workgroup per row merges the tasks' candidate keys 128 at a
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
-constexpr int FINC_BLOCK = 512, FINC_WAVES = FINC_BLOCK / 64;   // 8 waves: the tournament's first level runs wide
+constexpr int FINC_BLOCK = 1024, FINC_WAVES = FINC_BLOCK / 64;   // 8 waves: the tournament's first level runs wide
 
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)

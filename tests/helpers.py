@@ -39,7 +39,7 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict):
         return 0
     assert not strict, f"selection differs in rows {diff_rows[:10]} (strict case)"
     ei = res["ei"].numpy()
-    s = res["s"].numpy()
+    s = res["s"].detach().numpy()
     thr32 = np.float32(thr)
     order = np.argsort(ei[1], kind="stable")
     dst_sorted = ei[1][order]
