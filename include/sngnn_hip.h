@@ -157,6 +157,21 @@ int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                        void *workspace, void *stream);
 
 /*
+ * The same two gather-sums on any graph, node-range partitions included (multi-GPU
+ * SNGNN++; new - the reference is single-device).  A rank builds the partition of the
+ * FLIPPED edge list (row 0 and row 1 of edge_index swapped), whose owned "targets" are
+ * its own source nodes; then
+ *   out0_local = sngnn_gather_sum_rows(g_flipped, wt_full, bias)      out[i] = bias + sum_{e in CSR row i} table[col_e]
+ *   dwt_partial = sngnn_scatter_sum_rows(g_flipped, g0_local)         out[v] = sum_{q in CSC row v} vals[dst_q]
+ * table / out of scatter have N_total rows, out of gather / vals have the owned rows.
+ * Requires src_min == 0 (models.py:125's shift would cross partitions otherwise).
+ */
+int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table, const float *bias,
+                          int C, float *out, void *workspace, void *stream);
+int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, float *out,
+                           void *workspace, void *stream);
+
+/*
  * Measurement aid (no reference counterpart): while enabled, sngnn_agg_forward
  * records HIP events on the caller's stream around its launches;
  * sngnn_profile_last_forward waits for the last call and returns the device

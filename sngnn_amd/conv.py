@@ -180,17 +180,37 @@ class SNConv_plus_plus(nn.Module):
         self.w.reset_parameters()
         self.beta.data.fill_(self.init_beta)
 
+    def _flipped(self, edge_index):
+        """edge_index with source and target rows swapped, cached per tensor so the
+        graph cache (keyed on tensor identity) sees a stable object."""
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+        hit = getattr(self, "_flip_cache", None)
+        if hit is None or hit[0] != key:
+            hit = (key, edge_index.flip(0).contiguous(), edge_index)
+            self._flip_cache = hit
+        return hit[1]
+
     def forward(self, x, edge_index):
-        if x.size(0) != self.num_nodes:
+        part = sn_dist.current_partition()
+        if part is None and x.size(0) != self.num_nodes:
             raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
                              "(the adjacency branch is Linear(num_nodes, C))")
-        if sn_dist.current_partition() is not None:
-            raise NotImplementedError("SNConv_plus_plus is single-GPU for now: the adjacency "
-                                      "branch needs the edges partitioned by source as well")
         graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h, c = _lin_aligned(x, self.lin)
-        out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
-        out_1 = ops.aggregate(h, graph, int(self.top_k), float(self.thr))[:, :c]
+        if part is None:
+            out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
+        else:
+            # multi-GPU: edge_index must hold every edge incident to the owned nodes (the
+            # full list is fine); the out-edges come from the partition of the flipped
+            # list.  w.weight is replicated ([C, N_total]); its gradient is each rank's
+            # partial sum, all-reduced with the other parameters (dist.allreduce_grads).
+            if part.n_total != self.num_nodes:
+                raise ValueError("num_nodes must be the partition's N_total")
+            flipped = self._flipped(edge_index)
+            graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
+                                         row_range=(part.row_begin, part.row_end))
+            out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
+        out_1 = _aggregate(h, graph, int(self.top_k), float(self.thr))[:, :c]
         out = self.beta * out_0 + (1 - self.beta) * out_1
         if self.bias is not None:
             out = out + self.bias

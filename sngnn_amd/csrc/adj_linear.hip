@@ -60,3 +60,50 @@ extern "C" int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0
     a.nbA = a.nbB = 0;
     return dispatch_adj(cfg, a, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// The same two gather-sums on ANY graph, partitions included (multi-GPU SNGNN++:
+// the adjacency branch of a rank runs on the partition of the FLIPPED edge list,
+// whose "targets" are the rank's own source nodes).
+// ---------------------------------------------------------------------------
+extern "C" int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table, const float *bias,
+                                     int C, float *out, void *workspace, void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(table && out, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(g->n_tasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    AdjArgs a;
+    a.table = table; a.bias = bias; a.out = out; a.partial = (float *)workspace;
+    a.C = C; a.N = (int)g->N;                    // one segment per owned CSR row
+    a.ptr = g->rowptr; a.idx = g->col; a.perm = g->rperm;
+    a.seg_shift = 0; a.idx_shift = 0;
+    a.n_split = g->n_split; a.n_med_end = g->rows_gt(SMALL_T); a.n_tasks = g->n_tasks;
+    a.task_slot = g->task_slot; a.task_chunk = g->task_chunk; a.split_task0 = g->split_task0;
+    a.nbA = a.nbB = 0;
+    return dispatch_adj(cfg, a, (hipStream_t)stream);
+}
+
+extern "C" int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, float *out,
+                                      void *workspace, void *stream)
+{
+    SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
+    if (g->Ntot == 0) return SNGNN_OK;
+    SN_REQUIRE(out && (vals || g->N == 0), SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(g->n_stasks == 0 || workspace, SNGNN_EINVAL, "workspace is NULL");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
+               "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    AdjArgs a;
+    a.table = vals; a.bias = nullptr; a.out = out; a.partial = (float *)workspace;
+    a.C = C; a.N = (int)g->Ntot;                 // one segment per source node (CSC row)
+    a.ptr = g->cscptr; a.idx = g->csc_dst; a.perm = g->sperm;
+    a.seg_shift = 0; a.idx_shift = 0;
+    a.n_split = g->n_ssplit; a.n_med_end = g->srcs_gt(SMALL_T); a.n_tasks = g->n_stasks;
+    a.task_slot = g->stask_slot; a.task_chunk = g->stask_chunk; a.split_task0 = g->ssplit_task0;
+    a.nbA = a.nbB = 0;
+    return dispatch_adj(cfg, a, (hipStream_t)stream);
+}

@@ -96,5 +96,14 @@ def all_gather_rows(h_local: torch.Tensor, part: Partition) -> torch.Tensor:
 def allreduce_grads(module: torch.nn.Module, part: Partition) -> None:
     """Sum the (replicated) parameters' gradients over the ranks."""
     for p in module.parameters():
-        if p.grad is not None:
-            dist.all_reduce(p.grad, group=part.group)
+        g = p.grad
+        if g is None:
+            continue
+        if g.is_contiguous():
+            dist.all_reduce(g, group=part.group)
+        elif g.dim() == 2 and g.t().is_contiguous():      # SNGNN++'s column-major w.weight
+            dist.all_reduce(g.t(), group=part.group)
+        else:
+            tmp = g.contiguous()
+            dist.all_reduce(tmp, group=part.group)
+            g.copy_(tmp)

@@ -156,6 +156,54 @@ def adj_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], graph: Graph)
     return _AdjLinear.apply(weight, bias, graph)
 
 
+class _AdjLinearPartition(torch.autograd.Function):
+    """The adjacency branch of one rank of a node-range partition.  ``graph_out`` is the
+    partition of the FLIPPED edge list (its owned rows are the rank's own source
+    nodes, its columns the global targets), ``weight`` the full [C, N_total] table.
+    Forward gathers W^T rows of the targets of each owned node's out-edges; backward
+    scatters into the rank's PARTIAL dense gradient of the full table (summed over the
+    ranks by the caller's all-reduce, sngnn_amd/dist.py)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, graph_out):
+        lib = _lib.load()
+        wt = weight.t()
+        if not wt.is_contiguous():
+            wt = wt.contiguous()
+        c = wt.size(1)
+        if wt.size(0) != graph_out.num_total_nodes:
+            raise ValueError("w.weight must cover all N_total nodes")
+        if graph_out.src_min != 0 and graph_out.num_edges > 0:
+            raise ValueError("the partitioned adjacency branch needs a graph whose lowest target id is 0")
+        out = torch.empty((graph_out.num_nodes, c), dtype=torch.float32, device=wt.device)
+        b = None if bias is None else bias.contiguous()
+        with torch.cuda.device(wt.device):
+            rc = lib.sngnn_gather_sum_rows(graph_out.handle, wt.data_ptr(), _lib.ptr(b), c, out.data_ptr(),
+                                           graph_out.workspace(c).data_ptr(), _stream(wt.device))
+        _lib.check(rc, "sngnn_gather_sum_rows")
+        ctx.graph = graph_out
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g0):
+        lib = _lib.load()
+        g0 = g0.contiguous()
+        gr = ctx.graph
+        c = g0.size(1)
+        dwt = torch.empty((gr.num_total_nodes, c), dtype=torch.float32, device=g0.device)
+        with torch.cuda.device(g0.device):
+            rc = lib.sngnn_scatter_sum_rows(gr.handle, g0.data_ptr(), c, dwt.data_ptr(),
+                                            gr.workspace(c).data_ptr(), _stream(g0.device))
+        _lib.check(rc, "sngnn_scatter_sum_rows")
+        db = g0.sum(dim=0) if ctx.has_bias else None
+        return dwt.t(), db, None
+
+
+def adj_linear_partition(weight, bias, graph_out: Graph) -> torch.Tensor:
+    return _AdjLinearPartition.apply(weight, bias, graph_out)
+
+
 # ---------------------------------------------------------------------------
 # Callers on either side of the aggregation (SURVEY.md 8f rank 1)
 # ---------------------------------------------------------------------------

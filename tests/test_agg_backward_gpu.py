@@ -154,3 +154,45 @@ def test_node_range_partitions_reproduce_the_whole_graph(cuda, parts, k, thr):
     assert torch.equal(torch.cat(outs), out_full.detach())
     scale = hf.grad.abs().max()
     assert (grad_sum - hf.grad).abs().max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("parts,rem", [(2, True), (3, False)])
+def test_partitioned_adjacency_branch_reproduces_the_whole_graph(cuda, parts, rem):
+    """Multi-GPU SNGNN++: each rank gathers W^T rows over the out-edges of its own nodes
+    (partition of the flipped edge list); concatenated outputs equal the single-GPU
+    branch and the ranks' partial weight gradients sum to the full one."""
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    n, C = 900, 40
+    n -= n % parts
+    ei = random_graph(n, 9000, seed=31, hubs=((0, n - 1), (4, 300)))
+    ei = torch.cat([ei, torch.stack([torch.zeros(200, dtype=torch.long), torch.arange(200) + 1])], 1)
+    ei = torch.unique(ei, dim=1).to(cuda)                 # node 0 has out-edges: src_min == 0
+    gen = torch.Generator().manual_seed(4)
+    W = torch.randn(C, n, generator=gen)
+    b = torch.randn(C, generator=gen).to(cuda)
+    gout = torch.randn(n, C, generator=gen).to(cuda)
+    Wg = lambda: torch.nn.Parameter(W.t().contiguous().to(cuda).t())
+
+    g_full = Graph(ei, n, True, rem)
+    assert g_full.src_min == 0
+    w_full, b_full = Wg(), b.clone().requires_grad_(True)
+    out_full = ops.adj_linear(w_full, b_full, g_full)
+    (out_full * gout).sum().backward()
+
+    flipped = ei.flip(0).contiguous()
+    step = n // parts
+    outs, dW, db = [], torch.zeros(C, n, device=cuda), torch.zeros(C, device=cuda)
+    for r in range(parts):
+        lo, hi = r * step, (r + 1) * step
+        g_out = Graph(flipped, n, True, rem, row_range=(lo, hi))
+        w_r, b_r = Wg(), b.clone().requires_grad_(True)
+        o = ops.adj_linear_partition(w_r, b_r, g_out)
+        assert o.shape == (step, C)
+        (o * gout[lo:hi]).sum().backward()
+        outs.append(o.detach())
+        dW += w_r.grad
+        db += b_r.grad
+    assert_close(torch.cat(outs), out_full.detach(), what="out_0", rtol=1e-5, atol=1e-5)
+    assert_grad_close(dW, w_full.grad, "dW")
+    assert_grad_close(db, b_full.grad, "db")
