@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void k_head_reduce(const float *__restrict__ p
 // ---------------------------------------------------------------------------
 constexpr int WG_ROWS = 512, WG_FT = 128, WG_STEP = 16, WG_SUB = 4;   // 4 sub-blocks of 128 rows
 
+// Thread = one feature column f and KACC channels; x[i][f] comes in coalesced vector
+// loads (WG_STEP rows in flight), the g tile of the step goes through LDS and is read
+// back as 16-byte broadcasts (4 channels per LDS instruction).
 template <int KACC>
 __global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__restrict__ g,
                                                                 const float *__restrict__ x, int64_t N, int C,
@@ -152,21 +155,22 @@ __global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__r
                                                                 float *__restrict__ part_b)
 {
     constexpr int CT = 2 * KACC;
-    __shared__ float sg[WG_SUB][WG_STEP][CT];
+    static_assert(KACC % 4 == 0, "16-byte LDS reads");
+    __shared__ __attribute__((aligned(16))) float sg[WG_SUB][WG_STEP][CT];
     __shared__ float sred[WG_SUB - 1][256];
     const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const int fl = tid & (WG_FT - 1), half = tid >> 7;
     const int f = blockIdx.x * WG_FT + fl;
     const int ct0 = blockIdx.y * CT, c0 = ct0 + half * KACC;
-    const int64_t r0 = (int64_t)blockIdx.z * WG_ROWS + sub * (WG_ROWS / WG_SUB);
-    const int64_t r1 = min(N, r0 + WG_ROWS / WG_SUB);
+    const int64_t rb = (int64_t)blockIdx.z * WG_ROWS + sub * (WG_ROWS / WG_SUB);
+    const int64_t r1 = min(N, rb + WG_ROWS / WG_SUB);
     float acc[KACC], bacc[KACC];
 #pragma unroll
     for (int k = 0; k < KACC; ++k) { acc[k] = 0.f; bacc[k] = 0.f; }
     const bool fok = f < F;
     const bool do_bias = part_b != nullptr && blockIdx.x == 0 && fl == 0;
-    for (int64_t ib = (int64_t)blockIdx.z * WG_ROWS + sub * (WG_ROWS / WG_SUB), it = 0;
-         it < WG_ROWS / WG_SUB / WG_STEP; ib += WG_STEP, ++it) {         // uniform trip count (barriers)
+    int64_t ib = rb;
+    for (int it = 0; it < WG_ROWS / WG_SUB / WG_STEP; ib += WG_STEP, ++it) {   // uniform trip count (barriers)
         float xv[WG_STEP];
 #pragma unroll
         for (int r = 0; r < WG_STEP; ++r)
@@ -180,13 +184,18 @@ __global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__r
 #pragma unroll
         for (int r = 0; r < WG_STEP; ++r)
 #pragma unroll
-            for (int k = 0; k < KACC; ++k) {
-                const float gv = sg[sub][r][half * KACC + k];
-                acc[k] = fmaf(gv, xv[r], acc[k]);
-                if (do_bias) bacc[k] += gv;
+            for (int k4 = 0; k4 < KACC / 4; ++k4) {
+                const float4 gv = *reinterpret_cast<const float4 *>(&sg[sub][r][half * KACC + 4 * k4]);
+                acc[4 * k4 + 0] = fmaf(gv.x, xv[r], acc[4 * k4 + 0]);
+                acc[4 * k4 + 1] = fmaf(gv.y, xv[r], acc[4 * k4 + 1]);
+                acc[4 * k4 + 2] = fmaf(gv.z, xv[r], acc[4 * k4 + 2]);
+                acc[4 * k4 + 3] = fmaf(gv.w, xv[r], acc[4 * k4 + 3]);
+                if (do_bias) {
+                    bacc[4 * k4 + 0] += gv.x; bacc[4 * k4 + 1] += gv.y;
+                    bacc[4 * k4 + 2] += gv.z; bacc[4 * k4 + 3] += gv.w;
+                }
             }
     }
-    (void)r0;
     // combine the four row quarters in fixed order, one accumulator at a time
 #pragma unroll
     for (int k = 0; k < KACC; ++k) {
@@ -210,20 +219,25 @@ __global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__r
         }
 }
 
-// out[j] = sum over chunks of part[chunk][j]: 4 threads per output take every 4th
+// out[j] = sum over chunks of part[chunk][j]: 16 threads per output take every 16th
 // chunk, then their sums are added in fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, int nchunks,
                                                       int64_t len, float *__restrict__ out)
 {
-    __shared__ float s[4][64];
-    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 64 + o;
+    __shared__ float s[16][16];
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + o;
     float a = 0.f;
     if (j < len)
-        for (int k = q; k < nchunks; k += 4) a += part[(size_t)k * len + j];
+        for (int k = q; k < nchunks; k += 16) a += part[(size_t)k * len + j];
     s[q][o] = a;
     __syncthreads();
-    if (q == 0 && j < len) out[j] = (s[0][o] + s[1][o]) + (s[2][o] + s[3][o]);
+    if (q == 0 && j < len) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s[w][o];
+        out[j] = t;
+    }
 }
 
 }  // namespace sngnn
@@ -281,8 +295,8 @@ extern "C" int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t
         }
     }
     const int64_t len = (int64_t)C * F;
-    k_sum_partials<<<(unsigned)((len + 63) / 64), 256, 0, st>>>(part, chunks, len, grad_weight);
-    if (grad_bias) k_sum_partials<<<(C + 63) / 64, 256, 0, st>>>(part_b, chunks, C, grad_bias);
+    k_sum_partials<<<(unsigned)((len + 15) / 16), 256, 0, st>>>(part, chunks, len, grad_weight);
+    if (grad_bias) k_sum_partials<<<(C + 15) / 16, 256, 0, st>>>(part_b, chunks, C, grad_bias);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
