@@ -113,3 +113,57 @@ def test_trainer_loop_early_stopping_semantics():
     # the output never changes -> val loss never improves after epoch 0 -> stop at epoch 3
     assert len(res["history"]) == 4 and model.calls == 12
     assert res["final_test_acc"] == res["history"][0]["test_acc"]
+
+
+def _write_geom(tmp, index_features):
+    import numpy as np
+    raw = tmp / "raw"
+    raw.mkdir()
+    if index_features:
+        lines = ["node_id\tfeature(feature_amount:5)\tlabel", "2\t0,4\t1", "0\t1\t0", "1\t2,3,5\t2", "3\t\t1"]
+    else:
+        lines = ["node_id\tfeature\tlabel", "0\t0.5,1.0,0\t0", "1\t0,0,2.5\t2", "2\t1,1,1\t1", "3\t0,3,0\t1"]
+    (raw / "out1_node_feature_label.txt").write_text("\n".join(lines) + "\n")
+    (raw / "out1_graph_edges.txt").write_text("node_id\tnode_id\n2\t1\n0\t1\n2\t1\n3\t3\n1\t0\n")
+    for i in (1, 0):
+        np.savez(raw / f"toy_split_0.6_0.2_{i}.npz", train_mask=np.array([1, 0, i, 0], np.uint8),
+                 val_mask=np.array([0, 1, 0, 0], np.uint8), test_mask=np.array([0, 0, 1 - i, 1], np.uint8))
+    return str(raw)
+
+
+@pytest.mark.parametrize("index_features", [False, True])
+def test_geom_gcn_parser(tmp_path, index_features):
+    """datasets/datasets.py:157-190, 208-250 (dense feature rows) and :263-304 (Actor's
+    feature-index lists): coalesced edges, stacked split masks in split order."""
+    from sngnn_amd import datasets as DS
+    d = DS.load_geom_gcn(_write_geom(tmp_path, index_features), "toy")
+    assert d.edge_index.tolist() == [[0, 1, 2, 3], [1, 0, 1, 3]]          # sorted, de-duplicated
+    assert d.train_mask.shape == (2, 4) and d.train_mask[1].tolist() == [True, False, True, False]
+    if index_features:
+        assert d.x.shape == (4, 6) and d.x[1].tolist() == [0, 0, 1, 1, 0, 1] and d.x[3].sum() == 0
+        assert d.y.tolist() == [0, 2, 1, 1]                               # placed by node id
+    else:
+        assert d.x.shape == (4, 3) and d.x[1].tolist() == [0, 0, 2.5] and d.y.tolist() == [0, 2, 1, 1]
+    s = DS.select_split(d, 0)
+    assert s.train_mask.tolist() == [True, False, False, False] and s.x is d.x
+
+
+def test_actor_fixture_statistics():
+    """tests/golden/actor_topology.npz was parsed from the raw files the reference
+    bundles (datasets/data/Actor/raw); its statistics are the ones SURVEY.md row 13
+    measured independently."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "actor_topology.npz"))
+    n, e, loops, max_deg, zero_deg, f, classes = (int(v) for v in z["stats"])
+    assert (n, e, loops, max_deg, zero_deg, f, classes) == (7600, 30019, 93, 1296, 2236, 932, 5)
+    ei = z["edge_index"].astype(np.int64)
+    assert ei.shape == (2, e) and (np.diff(ei[0] * n + ei[1]) > 0).all()
+    assert (int(z["train_mask0"].sum()), int(z["val_mask0"].sum()), int(z["test_mask0"].sum())) == \
+        (3648, 2432, 1520)
+    raw = "/root/reference/datasets/data/Actor/raw"
+    if os.path.isdir(raw):                                  # where the reference is mounted: re-parse
+        from sngnn_amd import datasets as DS
+        d = DS.load_geom_gcn(raw, "film")
+        assert np.array_equal(d.edge_index.numpy(), ei) and d.x.shape == (n, f)
+        assert np.array_equal(d.y.numpy(), z["y"].astype(np.int64))

@@ -162,3 +162,32 @@ def test_odd_channel_count_takes_the_padded_path_and_matches_oracle(cuda):
     for (name, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
         scale = q.grad.abs().max().clamp_min(1e-12)
         assert (p.grad.cpu() - q.grad).abs().max() <= 2e-4 * scale + 1e-7, name
+
+
+def test_actor_topology_sngnn_plus_plus(cuda):
+    """BASELINE config 3 on the REAL Actor graph (tests/golden/actor_topology.npz: 30 019
+    edges, 93 self-loops, max in-degree 1296, 29 % isolated targets) with synthetic
+    bag-of-words features: SNGNN_Plus_Plus top_k=10 thr=0.9 init_beta=0.0, forward and
+    gradients against the oracle."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "actor_topology.npz"))
+    ei = torch.from_numpy(z["edge_index"].astype(np.int64))
+    n, f, c = 7600, 64, 5
+    gen = torch.Generator().manual_seed(8)
+    x = (torch.rand(n, f, generator=gen) < 0.08).float()
+    x[100] = x[101]
+    y = torch.from_numpy(z["y"].astype(np.int64))
+    mask = torch.from_numpy(z["train_mask0"])
+    for args in ((f, 32, c, n, 1, 10, 0.9, 0.0, 1, 0.0), (f, 32, c, n, 2, 10, 0.5, 0.3, 0, 0.0)):
+        ours, ref = build_pair("SNGNN_Plus_Plus", args)
+        ours = ours.to(cuda)
+        out_ref = ref(Data(x=x, edge_index=ei))
+        out = ours(Data(x=x.to(cuda), edge_index=ei.to(cuda)))
+        assert_close(out, out_ref, what="log-probs", rtol=1e-4, atol=2e-5)
+        F.nll_loss(out_ref[mask], y[mask]).backward()
+        F.nll_loss(out[mask.to(cuda)], y.to(cuda)[mask.to(cuda)]).backward()
+        for (name, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
+            gq = q.grad.to_dense() if q.grad.is_sparse else q.grad
+            scale = gq.abs().max().clamp_min(1e-12)
+            assert (p.grad.cpu() - gq).abs().max() <= 2e-4 * scale + 1e-7, name
