@@ -63,13 +63,16 @@ typedef struct sngnn_graph sngnn_graph_t;
  *   edge_index_dev  int64 [2, E] row-major (row 0 = source, row 1 = target),
  *                   exactly what the reference passes as ``edge_index``
  *   add_loops       append (v, v) for every v at the END of the list
- *   remove_loops    then drop EVERY edge with src == dst (so add+remove == remove)
+ *   remove_loops    1: then drop EVERY edge with src == dst (so add+remove == remove)
+ *                   2 (SNGNN_LOOPS_REPLACE): drop the ORIGINAL loops first, then
+ *                   append - AGNNConv's order (models.py:393-395)
  *
  * The resulting list of E' edges keeps the reference's order; the library
  * stores it as CSR by target with the original relative order inside each row
  * (stable), which is what makes "first occurrence wins a tie" reproducible.
  * Synchronises the stream (one-time setup).
  */
+#define SNGNN_LOOPS_REPLACE 2
 int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N,
                        int add_loops, int remove_loops, void *stream,
                        sngnn_graph_t **out_graph);
@@ -155,6 +158,27 @@ int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
 int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                        const float *grad_out, const float *wsel, float *grad_h,
                        void *workspace, void *stream);
+
+/*
+ * Cosine-attention mode of the same gather skeleton.
+ * Replaces: AGNNConv.forward after ``lin`` + message + aggr='add'
+ * (models.py:396-405): alpha_e = softmax over the in-edges of target i of
+ * cos(h_i, h_j), out_i = sum_e alpha_e * h_j.  Build the graph with
+ * add_loops = 1, remove_loops = SNGNN_LOOPS_REPLACE for AGNNConv's edge list.
+ * A cosine lies in [-1, 1], so exp() is applied without the running maximum PyG's
+ * softmax subtracts (identical up to rounding; the 1e-16 added to a sum >= e^-1 is
+ * below fp32 resolution).
+ *
+ *   out    dev f32 [N, C]
+ *   alpha  dev f32 [E'] or NULL  attention coefficients in CSR order (what
+ *                                sngnn_attn_backward needs)
+ */
+int sngnn_attn_forward(const sngnn_graph_t *g, const float *h, int C, float *out,
+                       float *alpha, void *workspace, void *stream);
+/* autograd of the lines above; same conventions as sngnn_agg_backward */
+int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C,
+                        const float *grad_out, const float *alpha, float *grad_h,
+                        void *workspace, void *stream);
 
 /*
  * The same two gather-sums on any graph, node-range partitions included (multi-GPU

@@ -228,6 +228,44 @@ def propagate_mean(x: Tensor, norm: Tensor, ei: Tensor, top_k: Optional[int],
     return out, s, weight, rounds
 
 
+def segment_softmax(src: Tensor, index: Tensor, num_nodes: int) -> Tensor:
+    """torch_geometric.utils.softmax (2.0.4) as called at models.py:404 with
+    ``ptr=None``: per target group subtract the group maximum, exponentiate, divide
+    by the group sum + 1e-16.  (Published algorithm; PyG is not vendored.)"""
+    src_max = src.new_full((num_nodes,), float("-inf")).scatter_reduce(
+        0, index, src, reduce="amax", include_self=True)
+    out = (src - src_max.index_select(0, index)).exp()
+    out_sum = src.new_zeros(num_nodes).scatter_add(0, index, out) + 1e-16
+    return out / out_sum.index_select(0, index)
+
+
+def agnn_edge_list(edge_index: Tensor, num_nodes: int) -> Tensor:
+    """models.py:393-395: original self-loops removed FIRST, then one loop per node
+    appended (the opposite order of the SNConv layers)."""
+    return add_self_loops(remove_self_loops(edge_index), num_nodes)
+
+
+def propagate_attention(x: Tensor, norm: Tensor, ei: Tensor):
+    """PyG ``propagate`` + ``message`` (models.py:400-405) + ``aggr='add'`` (:381):
+    alpha = softmax over each target's in-edges of the cosine, out_i = sum alpha * x_j."""
+    N = x.size(0)
+    s = edge_cosine(norm, ei)
+    alpha = segment_softmax(s, ei[1], N)
+    msg = x.index_select(0, ei[0]) * alpha.view(-1, 1)
+    out = x.new_zeros(N, x.size(1)).index_add_(0, ei[1], msg)
+    return out, s, alpha
+
+
+def attention_reference(h: Tensor, edge_index: Tensor):
+    """Operator-level contract of the attention mode (everything after ``lin`` in
+    models.py:392-399): dict(out [N,C], ei [2,E'], s [E'], alpha [E'])."""
+    N = h.size(0)
+    ei = agnn_edge_list(edge_index, N)
+    norm = F.normalize(h, p=2., dim=-1)
+    out, s, alpha = propagate_attention(h, norm, ei)
+    return dict(out=out, ei=ei, s=s, alpha=alpha)
+
+
 # --------------------------------------------------------------------------
 # Conv layers (same constructor signatures, parameter names and init order as
 # the reference, so seeded construction gives identical parameters)
@@ -448,6 +486,49 @@ class SNGNN_Plus_Plus(_Stack):
                     self.bns.append(nn.BatchNorm1d(hidden_channels))
             self.lins.append(conv(hidden_channels, out_channels))
         self.dropout = nn.Dropout(p=droput_rate)
+        self.reset_parameters()
+
+
+class AGNNConv(nn.Module):
+    """models.py:377-405 (the reference's own AGNNConv: a Linear, no beta)."""
+
+    def __init__(self, in_channels, out_channels, aggr='add', add_self_loops: bool = True):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels)
+        self.add_self_loops = add_self_loops      # stored, never read (models.py:386)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+
+    def forward(self, x, edge_index):
+        ei = agnn_edge_list(edge_index, x.size(0))
+        x = self.lin(x)
+        x_norm = F.normalize(x, p=2., dim=-1)
+        return propagate_attention(x, x_norm, ei)[0]
+
+
+class AGNN(_Stack):
+    """models.py:336-374."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, bn=False):
+        super().__init__()
+        self.bn = bn
+        self.lins = nn.ModuleList()
+        if self.bn:
+            self.bns = nn.ModuleList()
+        if num_layers == 1:
+            self.lins.append(AGNNConv(in_channels, out_channels))
+        else:
+            self.lins.append(AGNNConv(in_channels, hidden_channels))
+            if self.bn:
+                self.bns.append(nn.BatchNorm1d(hidden_channels))
+            for _ in range(num_layers - 2):
+                self.lins.append(AGNNConv(hidden_channels, hidden_channels))
+                if self.bn:
+                    self.bns.append(nn.BatchNorm1d(hidden_channels))
+            self.lins.append(AGNNConv(hidden_channels, out_channels))
+        self.dropout = nn.Dropout(p=0.5)
         self.reset_parameters()
 
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
     "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),

@@ -17,7 +17,7 @@ from torch.nn.parameter import Parameter
 
 from . import dist as sn_dist
 from . import ops
-from .graph import GLOBAL_CACHE
+from .graph import GLOBAL_CACHE, LOOPS_REPLACE
 
 
 def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remove_loops: bool):
@@ -81,6 +81,31 @@ class SNConv(nn.Module):
         if self.bias is not None:
             out = out + self.bias
         return out
+
+
+class AGNNConv(nn.Module):
+    """models.py:377-405, the reference's own cosine-attention layer:
+    original loops replaced by one per node, ``alpha`` = per-target softmax of the
+    cosines, ``aggr='add'``.  Same kernel skeleton as SNConv, softmax instead of mean."""
+
+    def __init__(self, in_channels, out_channels, aggr='add', add_self_loops: bool = True):
+        super().__init__()
+        if aggr != 'add':
+            raise ValueError("only aggr='add' is implemented (the reference's setting)")
+        self.lin = nn.Linear(in_channels, out_channels)
+        self.add_self_loops = add_self_loops      # stored, never read (models.py:386)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin.reset_parameters()
+
+    def forward(self, x, edge_index):
+        graph = _graph_for(x, edge_index, True, LOOPS_REPLACE)
+        h, c = _lin_aligned(x, self.lin)
+        part = sn_dist.current_partition()
+        if part is not None:
+            h = sn_dist.all_gather_rows(h, part)
+        return ops.attention(h, graph)[:, :c]
 
 
 class SNConv_plus(nn.Module):

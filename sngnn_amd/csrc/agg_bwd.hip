@@ -35,6 +35,7 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
     a.nbA = a.nbB = 0;
+    a.attn = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {
     case 1: return launch_agg_bwd_v1(cfg, a, st);

@@ -35,6 +35,7 @@ struct BwdArgs {
     const int32_t *stask_slot, *stask_chunk, *ssplit_task0;
     float *partS;
     int nbA, nbB;
+    int attn;       // attention mode (attn_impl.h): wsel = alpha_e, sum instead of mean
 };
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
@@ -205,10 +206,9 @@ __device__ __forceinline__ void s_edge(const BwdArgs &a, int q, float w, int lg,
     Row<VEC, G, R> x, gi;
     const int i = a.csc_dst[q];               // local target row
     const int e = a.csc_eid[q];
-    const int deg = a.rowptr[i + 1] - a.rowptr[i];
     x.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     gi.load(a.gout + (size_t)i * a.C, a.C, lg);
-    gi.div((float)deg);
+    if (!a.attn) gi.div((float)(a.rowptr[i + 1] - a.rowptr[i]));
     const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
     fma_row<VEC, G, R>(msg, w, gi);
     fma_row<VEC, G, R>(dns, a.ds[e] * invi, x);
@@ -277,7 +277,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
         const int i = kept ? a.csc_dst[qs + t] : -1;
         s_i[t] = i;
         if (kept) {
-            s_deg[t] = a.rowptr[i + 1] - a.rowptr[i];
+            s_deg[t] = a.attn ? 1 : a.rowptr[i + 1] - a.rowptr[i];
             s_w[t] = w;
             s_ds[t] = a.ds[e];
         }

@@ -74,16 +74,6 @@ constexpr int FWD_WAVES_PER_SIMD = 6;   // register budget of the main kernel (<
 
 template <int R> struct Unroll { static constexpr int U = (R >= 4) ? 1 : (R == 2 ? 2 : 4); };
 
-template <int VEC, int G, int R>
-__device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i,
-                                            const Row<VEC, G, R> &x)
-{
-    float d = group_sum<G>(a.dot_partial(x));
-    float q = group_sum<G>(x.dot_partial(x));
-    float s = d * (inv_i * inv_norm_of(q));
-    return s + 0.0f;     // -0.0 -> +0.0: the reference orders floats, not bit patterns
-}
-
 // ---------------------------------------------------------------------------
 // Wave-level top-k of up to 128 selection keys, two per lane (0 = no key).
 // Keys are unique, so "the k largest" is well defined: bitwise search for the

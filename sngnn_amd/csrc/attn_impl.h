@@ -1,0 +1,403 @@
+// Cosine-attention mode of the gather skeleton (gfx950): AGNNConv of the reference,
+// models/models.py:377-405 after ``lin``.
+//
+//     s_e     = cos(h_i, h_j)                              per in-edge e = (j -> i)
+//     alpha_e = exp(s_e) / sum_{e' into i} exp(s_e')       (softmax per target)
+//     out_i   = sum_e alpha_e * h_j                        (aggr = 'add')
+//
+// s_e is bounded by 1 in magnitude, so exp needs no running maximum and the row sum
+// l_i = sum exp(s_e) and the weighted row sum are accumulated in ONE pass over the
+// source rows (partial sums of split rows simply add).  Row classes as in the
+// aggregation kernels (common.h): small rows one lane group each, wave rows one wave,
+// split rows CHUNK-edge tasks + a per-row finalize.
+//
+// Backward.  With t_e = <G_i, h_j> and dot_i = sum_e alpha_e t_e (= <G_i, out_i>):
+//     ds_e  = alpha_e (t_e - dot_i)                        softmax Jacobian
+//     dnT_i = sum_e ds_e n_j = A_i - dot_i B_i,   A_i = sum alpha_e t_e n_j,  B_i = sum alpha_e n_j
+// so pass T is again a single gather pass (A, B and dot accumulate together); it
+// leaves ds_e per edge and dnT per row, after which the source-side pass S and the
+// F.normalize Jacobian are the aggregation's own kernels (agg_bwd_impl.h) with
+// weight alpha_e and no mean division.  No floating-point atomics anywhere.
+#pragma once
+#include "agg_bwd_impl.h"
+
+namespace sngnn {
+
+struct AttnArgs {
+    const float *h;
+    int C, N, row_off;
+    const int32_t *col;
+    const int4 *rdesc;           // per degree-sorted slot: {row, first edge, in-degree, 0}
+    float *out, *alpha;          // alpha may be NULL
+    int n_split, n_med_end, n_tasks;
+    const int32_t *task_slot, *task_chunk, *split_task0;
+    float *partial;              // [n_tasks][C + 4]: weighted row sum | l, 0, 0, 0
+    int nbA, nbB;
+};
+
+constexpr int ATTN_LDS = 2 * WAVE_T;    // words per wave: source ids | exp(s) (or t_e)
+
+// ------------------------------ forward ------------------------------------
+template <int VEC, int G, int R>
+__device__ __forceinline__ void attn_small(const AttnArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
+    if (slot >= a.N) return;                              // group-uniform
+    const int4 d = a.rdesc[slot];
+    const int i = d.x, rs = d.y, deg = d.z;
+    int *s_j = lds_wave + gid * 2 * SMALL_T;
+    float *s_e = reinterpret_cast<float *>(s_j + SMALL_T);
+    for (int t = lg; t < deg; t += G) s_j[t] = a.col[rs + t];
+    RowT hi, acc;
+    hi.load(a.h + (size_t)(a.row_off + i) * a.C, a.C, lg);
+    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+    acc.zero();
+    float l = 0.f;
+    wave_lds_sync();
+    for (int t0 = 0; t0 < deg; t0 += 2) {
+        const bool two = t0 + 1 < deg;
+        RowT x0, x1;
+        x0.load(a.h + (size_t)s_j[t0] * a.C, a.C, lg);
+        if (two) x1.load(a.h + (size_t)s_j[t0 + 1] * a.C, a.C, lg);
+        const float e0 = expf(edge_score<VEC, G, R>(hi, inv_i, x0));
+        l += e0;
+        fma_row<VEC, G, R>(acc, e0, x0);
+        if (lg == 0) s_e[t0] = e0;
+        if (two) {
+            const float e1 = expf(edge_score<VEC, G, R>(hi, inv_i, x1));
+            l += e1;
+            fma_row<VEC, G, R>(acc, e1, x1);
+            if (lg == 0) s_e[t0 + 1] = e1;
+        }
+    }
+    if (deg > 0) acc.div(l);
+    acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    if (a.alpha) {
+        wave_lds_sync();
+        for (int t = lg; t < deg; t += G) a.alpha[rs + t] = s_e[t] / l;
+    }
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void attn_wave(const AttnArgs &a, int blk, int *lds_wave, bool task)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    int slot, e0 = 0, tq = 0;
+    if (task) {
+        tq = blk * WAVES + wave;
+        if (tq >= a.n_tasks) return;
+        slot = a.task_slot[tq];
+        e0 = a.task_chunk[tq] * CHUNK;
+    } else {
+        slot = a.n_split + blk * WAVES + wave;
+        if (slot >= a.n_med_end) return;
+    }
+    const int4 d = a.rdesc[slot];
+    const int i = d.x, rs = d.y, deg = d.z;
+    const int n = task ? min(deg - e0, CHUNK) : deg;      // <= WAVE_T edges for this wave
+    int *s_j = lds_wave;
+    float *s_e = reinterpret_cast<float *>(lds_wave + WAVE_T);
+    for (int t = lane; t < n; t += 64) s_j[t] = a.col[rs + e0 + t];
+    RowT hi, acc;
+    hi.load(a.h + (size_t)(a.row_off + i) * a.C, a.C, lg);
+    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
+    acc.zero();
+    float l = 0.f;
+    wave_lds_sync();
+    for (int q0 = 0; q0 < n; q0 += NG) {
+        const int q = q0 + gid;
+        if (q < n) {
+            RowT x;
+            x.load(a.h + (size_t)s_j[q] * a.C, a.C, lg);
+            const float e = expf(edge_score<VEC, G, R>(hi, inv_i, x));
+            l += e;
+            fma_row<VEC, G, R>(acc, e, x);
+            if (lg == 0) s_e[q] = e;
+        }
+    }
+    l = cross_group_sum<G>(l);
+    acc.reduce_across_groups();
+    wave_lds_sync();
+    if (task) {
+        // unnormalised: the row's finalize divides by the sum over all its tasks
+        float *p = a.partial + (size_t)tq * (a.C + 4);
+        if (gid == 0) {
+            acc.store(p, a.C, lg);
+            if (lg == 0) p[a.C] = l;
+        }
+        if (a.alpha)
+            for (int t = lane; t < n; t += 64) a.alpha[rs + e0 + t] = s_e[t];
+    } else {
+        acc.div(l);
+        if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
+        if (a.alpha)
+            for (int t = lane; t < n; t += 64) a.alpha[rs + t] = s_e[t] / l;
+    }
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_attn_fwd(const AttnArgs a)
+{
+    __shared__ int lds[WAVES][ATTN_LDS];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) attn_wave<VEC, G, R>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) attn_wave<VEC, G, R>(a, b - a.nbA, lw, false);
+    else attn_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+}
+
+// split rows: l_i and the weighted sum over the row's tasks (fixed order), then the
+// row's exp(s_e) become alpha_e
+static __global__ __launch_bounds__(256) void k_attn_fin(const AttnArgs a)
+{
+    __shared__ float s[4][64];
+    __shared__ float s_l;
+    const int p = blockIdx.x;
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t stride = (size_t)a.C + 4;
+    if (threadIdx.x == 0) {
+        float l = 0.f;
+        for (int t = t0; t < t1; ++t) l += a.partial[t * stride + a.C];
+        s_l = l;
+    }
+    __syncthreads();
+    const float l = s_l;
+    for (int c0 = 0; c0 < a.C; c0 += 64) {
+        const int c = c0 + cl;
+        float v = 0.f;
+        if (c < a.C)
+            for (int t = t0 + q; t < t1; t += 4) v += a.partial[t * stride + c];
+        s[q][cl] = v;
+        __syncthreads();
+        if (q == 0 && c < a.C)
+            a.out[(size_t)i * a.C + c] = ((s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl])) / l;
+        __syncthreads();
+    }
+    if (a.alpha)
+        for (int t = threadIdx.x; t < deg; t += 256) a.alpha[rs + t] = a.alpha[rs + t] / l;
+}
+
+template <int VEC, int G, int R> int launch_attn_fwd(const AttnArgs &a0, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    AttnArgs a = a0;
+    a.nbA = ceil_div(a.n_tasks, WAVES);
+    a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
+    const int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
+    if (a.nbA + a.nbB + nbC > 0) k_attn_fwd<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.n_split > 0) k_attn_fin<<<a.n_split, 256, 0, st>>>(a);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+// ------------------------------ backward, pass T ----------------------------
+// BwdArgs (agg_bwd_impl.h) with wsel = alpha, attn = 1, partT rows of 2C + 4 floats.
+
+// one in-edge: accumulates A, B, dot; returns t_e
+template <int VEC, int G, int R>
+__device__ __forceinline__ float attn_t_edge(const Row<VEC, G, R> &x, const Row<VEC, G, R> &gp,
+                                             float al, Row<VEC, G, R> &A, Row<VEC, G, R> &B,
+                                             float &dot)
+{
+    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));    // same bits as the forward
+    const float t = group_sum<G>(gp.dot_partial(x));
+    const float at = al * t;
+    dot += at;
+    fma_row<VEC, G, R>(A, at * invj, x);
+    fma_row<VEC, G, R>(B, al * invj, x);
+    return t;
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void attn_t_small(const BwdArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
+    if (slot >= a.N) return;
+    const int i = a.rperm[slot];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    int *s_j = lds_wave + gid * 3 * SMALL_T;
+    float *s_a = reinterpret_cast<float *>(s_j + SMALL_T);
+    float *s_t = reinterpret_cast<float *>(s_j + 2 * SMALL_T);
+    for (int t = lg; t < deg; t += G) {
+        s_j[t] = a.col[rs + t];
+        s_a[t] = a.wsel[rs + t];
+    }
+    RowT gp, A, B;
+    gp.load(a.gout + (size_t)i * a.C, a.C, lg);
+    A.zero();
+    B.zero();
+    float dot = 0.f;
+    wave_lds_sync();
+    for (int t0 = 0; t0 < deg; t0 += 2) {
+        const bool two = t0 + 1 < deg;
+        RowT x0, x1;
+        x0.load(a.h + (size_t)s_j[t0] * a.C, a.C, lg);
+        if (two) x1.load(a.h + (size_t)s_j[t0 + 1] * a.C, a.C, lg);
+        const float ta = attn_t_edge<VEC, G, R>(x0, gp, s_a[t0], A, B, dot);
+        if (lg == 0) s_t[t0] = ta;
+        if (two) {
+            const float tb = attn_t_edge<VEC, G, R>(x1, gp, s_a[t0 + 1], A, B, dot);
+            if (lg == 0) s_t[t0 + 1] = tb;
+        }
+    }
+    fma_row<VEC, G, R>(A, -dot, B);                       // dnT_i = A - dot * B
+    A.store(a.dnT + (size_t)i * a.C, a.C, lg);
+    wave_lds_sync();
+    for (int t = lg; t < deg; t += G) a.ds[rs + t] = s_a[t] * (s_t[t] - dot);
+}
+
+template <int VEC, int G, int R>
+__device__ __forceinline__ void attn_t_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    int i, e0 = 0, tq = 0;
+    if (task) {
+        tq = blk * WAVES + wave;
+        if (tq >= a.n_tasks) return;
+        i = a.rperm[a.task_slot[tq]];
+        e0 = a.task_chunk[tq] * CHUNK;
+    } else {
+        const int slot = a.n_split + blk * WAVES + wave;
+        if (slot >= a.n_med_end) return;
+        i = a.rperm[slot];
+    }
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const int n = task ? min(deg - e0, CHUNK) : deg;
+    int *s_j = lds_wave;
+    float *s_a = reinterpret_cast<float *>(lds_wave + WAVE_T);
+    float *s_t = reinterpret_cast<float *>(lds_wave + 2 * WAVE_T);
+    for (int t = lane; t < n; t += 64) {
+        s_j[t] = a.col[rs + e0 + t];
+        s_a[t] = a.wsel[rs + e0 + t];
+    }
+    RowT gp, A, B;
+    gp.load(a.gout + (size_t)i * a.C, a.C, lg);
+    A.zero();
+    B.zero();
+    float dot = 0.f;
+    wave_lds_sync();
+    for (int q0 = 0; q0 < n; q0 += NG) {
+        const int q = q0 + gid;
+        if (q < n) {
+            RowT x;
+            x.load(a.h + (size_t)s_j[q] * a.C, a.C, lg);
+            const float t = attn_t_edge<VEC, G, R>(x, gp, s_a[q], A, B, dot);
+            if (lg == 0) s_t[q] = t;
+        }
+    }
+    dot = cross_group_sum<G>(dot);
+    A.reduce_across_groups();
+    B.reduce_across_groups();
+    wave_lds_sync();
+    if (task) {
+        // raw t_e now; the row's finalize knows dot_i and turns them into ds_e
+        float *p = a.partT + (size_t)tq * (2 * a.C + 4);
+        if (gid == 0) {
+            A.store(p, a.C, lg);
+            B.store(p + a.C, a.C, lg);
+            if (lg == 0) p[2 * a.C] = dot;
+        }
+        for (int t = lane; t < n; t += 64) a.ds[rs + e0 + t] = s_t[t];
+    } else {
+        fma_row<VEC, G, R>(A, -dot, B);
+        if (gid == 0) A.store(a.dnT + (size_t)i * a.C, a.C, lg);
+        for (int t = lane; t < n; t += 64) a.ds[rs + t] = s_a[t] * (s_t[t] - dot);
+    }
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_attn_bwd_t(const BwdArgs a)
+{
+    __shared__ int lds[WAVES][3 * WAVE_T];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) attn_t_wave<VEC, G, R>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) attn_t_wave<VEC, G, R>(a, b - a.nbA, lw, false);
+    else attn_t_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+}
+
+static __global__ __launch_bounds__(256) void k_attn_bwd_t_fin(const BwdArgs a)
+{
+    __shared__ float sA[4][64], sB[4][64];
+    __shared__ float s_dot;
+    const int p = blockIdx.x;
+    const int i = a.rperm[p];
+    const int rs = a.rowptr[i];
+    const int deg = a.rowptr[i + 1] - rs;
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t stride = 2 * (size_t)a.C + 4;
+    if (threadIdx.x == 0) {
+        float dsum = 0.f;
+        for (int t = t0; t < t1; ++t) dsum += a.partT[t * stride + 2 * a.C];
+        s_dot = dsum;
+    }
+    __syncthreads();
+    const float dot = s_dot;
+    for (int c0 = 0; c0 < a.C; c0 += 64) {
+        const int c = c0 + cl;
+        float va = 0.f, vb = 0.f;
+        if (c < a.C)
+            for (int t = t0 + q; t < t1; t += 4) {
+                va += a.partT[t * stride + c];
+                vb += a.partT[t * stride + a.C + c];
+            }
+        sA[q][cl] = va;
+        sB[q][cl] = vb;
+        __syncthreads();
+        if (q == 0 && c < a.C) {
+            const float A = (sA[0][cl] + sA[1][cl]) + (sA[2][cl] + sA[3][cl]);
+            const float B = (sB[0][cl] + sB[1][cl]) + (sB[2][cl] + sB[3][cl]);
+            a.dnT[(size_t)i * a.C + c] = fmaf(-dot, B, A);
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < deg; t += 256) a.ds[rs + t] = a.wsel[rs + t] * (a.ds[rs + t] - dot);
+}
+
+template <int VEC, int G, int R> int launch_attn_bwd(const BwdArgs &a0, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    BwdArgs a = a0;
+    a.nbA = ceil_div(a.n_tasks, WAVES);
+    a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
+    int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
+    if (a.nbA + a.nbB + nbC > 0) k_attn_bwd_t<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.n_split > 0) k_attn_bwd_t_fin<<<a.n_split, 256, 0, st>>>(a);
+    // pass S: the aggregation's kernels (every edge kept, weight alpha_e, no mean division)
+    a.nbA = ceil_div(a.n_stasks, WAVES);
+    a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
+    nbC = ceil_div(a.Ntot - a.n_smed_end, (int64_t)WAVES * RPW);
+    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+int launch_attn_fwd_v1(const RowCfg &cfg, const AttnArgs &a, hipStream_t st);
+int launch_attn_fwd_v2(const RowCfg &cfg, const AttnArgs &a, hipStream_t st);
+int launch_attn_fwd_v4(const RowCfg &cfg, const AttnArgs &a, hipStream_t st);
+int launch_attn_bwd_v1(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+int launch_attn_bwd_v2(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+int launch_attn_bwd_v4(const RowCfg &cfg, const BwdArgs &a, hipStream_t st);
+
+}  // namespace sngnn

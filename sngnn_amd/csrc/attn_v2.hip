@@ -1,0 +1,17 @@
+// Instantiates the cosine-attention kernels for rows read 2 float(s) per lane.
+#include "attn_impl.h"
+#include "agg_fwd_impl.h"   // SNGNN_DISPATCH_GR
+
+namespace sngnn {
+
+int launch_attn_fwd_v2(const RowCfg &cfg, const AttnArgs &a, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_attn_fwd, 2, cfg, a, st)
+}
+
+int launch_attn_bwd_v2(const RowCfg &cfg, const BwdArgs &a, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_attn_bwd, 2, cfg, a, st)
+}
+
+}  // namespace sngnn

@@ -203,4 +203,15 @@ __device__ __forceinline__ float inv_norm_of(float sumsq)
 // F.normalize clamps the norm at eps; below it the normalisation is a plain scale
 __device__ __forceinline__ bool norm_clamped(float sumsq) { return sumsq < EPS_NORM * EPS_NORM; }
 
+// cosine of target row a (inverse norm inv_i) and source row x
+template <int VEC, int G, int R>
+__device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i,
+                                            const Row<VEC, G, R> &x)
+{
+    float d = group_sum<G>(a.dot_partial(x));
+    float q = group_sum<G>(x.dot_partial(x));
+    float s = d * (inv_i * inv_norm_of(q));
+    return s + 0.0f;     // -0.0 -> +0.0: the reference orders floats, not bit patterns
+}
+
 }  // namespace sngnn

@@ -41,7 +41,9 @@ __global__ void k_mark(const int64_t *__restrict__ ei, int64_t E, int64_t T, int
     if (t < E) { s = ei[t]; d = ei[E + t]; } else { s = d = row0 + (t - E); }
     if (s < 0 || s >= Ntot || d < 0 || d >= Ntot) { atomicOr(bad, 1); keep[t] = 0; return; }
     // a partition keeps only the edges that point into its own node range
-    keep[t] = ((remove_loops && s == d) || d < row0 || d >= row1) ? 0 : 1;
+    // remove_loops 1: every loop goes; 2 (SNGNN_LOOPS_REPLACE): only the original ones
+    const bool drop_loop = s == d && (remove_loops == 1 || (remove_loops == 2 && t < E));
+    keep[t] = (drop_loop || d < row0 || d >= row1) ? 0 : 1;
 }
 
 __global__ void k_compact(const int64_t *__restrict__ ei, int64_t E, int64_t T, int64_t row0,
@@ -198,7 +200,7 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
                  int64_t row1, int add_loops, int remove_loops, hipStream_t st)
 {
     const int64_t N = row1 - row0;                                   // owned target rows
-    const int64_t n_loops = (add_loops && !remove_loops) ? N : 0;   // add+remove == remove
+    const int64_t n_loops = (add_loops && remove_loops != 1) ? N : 0;   // add+remove == remove
     const int64_t T = E + n_loops;
     SN_REQUIRE(T < ((int64_t)1 << 31) - 1 && Ntot < ((int64_t)1 << 31) - 1, SNGNN_EINVAL,
                "graph too large for 32-bit indices");
@@ -369,10 +371,12 @@ int sngnn_graph_create_partition(const int64_t *edge_index_dev, int64_t E, int64
     SN_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= N_total, SNGNN_EINVAL,
                "row range must satisfy 0 <= row_begin <= row_end <= N_total");
     SN_REQUIRE(E == 0 || edge_index_dev != nullptr, SNGNN_EINVAL, "edge_index is NULL");
+    SN_REQUIRE(remove_loops >= 0 && remove_loops <= SNGNN_LOOPS_REPLACE, SNGNN_EINVAL,
+               "remove_loops must be 0, 1 or SNGNN_LOOPS_REPLACE");
     sngnn_graph *g = new (std::nothrow) sngnn_graph();
     SN_REQUIRE(g != nullptr, SNGNN_ENOMEM, "out of host memory");
     int rc = build(g, edge_index_dev, E, N_total, row_begin, row_end, add_loops != 0,
-                   remove_loops != 0, (hipStream_t)stream);
+                   remove_loops, (hipStream_t)stream);
     if (rc != 0) { sngnn_graph_destroy(g); return rc; }
     *out_graph = g;
     return SNGNN_OK;
@@ -412,8 +416,9 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
                   (int64_t)g->n_tasks * 32 * 4;      // + candidate source ids
     // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
-    int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 + (int64_t)g->n_tasks * C * 4 +
-                  (int64_t)g->n_stasks * C * 4 * 2;
+    //           (attention mode: 2 rows + 4 scalars) | partS (2 rows) per split-source task
+    int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 +
+                  (int64_t)g->n_tasks * (2 * C + 4) * 4 + (int64_t)g->n_stasks * C * 4 * 2;
     int64_t b = std::max(fwd, bwd);
     return (b + 255) / 256 * 256;
 }

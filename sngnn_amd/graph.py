@@ -18,6 +18,9 @@ from . import _lib
 _ARRAYS = {"rowptr": 0, "col": 1, "eid": 2, "cscptr": 3, "csc_eid": 4, "rperm": 5}
 
 
+LOOPS_REPLACE = 2      # SNGNN_LOOPS_REPLACE: drop the original loops, then append one per node
+
+
 class Graph:
     """Owns a ``sngnn_graph_t`` handle."""
 
@@ -33,7 +36,8 @@ class Graph:
         lib = _lib.load()
         ei = edge_index.contiguous()
         self.device = ei.device
-        self.add_loops, self.remove_loops = bool(add_loops), bool(remove_loops)
+        # remove_loops: False/True as in the SNConv layers, or LOOPS_REPLACE (AGNNConv's order)
+        self.add_loops, self.remove_loops = bool(add_loops), int(remove_loops)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -95,7 +99,7 @@ class GraphCache:
     def get(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
             remove_loops: bool, row_range=None) -> Graph:
         key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version,
-               int(num_nodes), bool(add_loops), bool(remove_loops), str(edge_index.device),
+               int(num_nodes), bool(add_loops), int(remove_loops), str(edge_index.device),
                None if row_range is None else tuple(map(int, row_range)))
         hit = self._entries.get(key)
         if hit is None:

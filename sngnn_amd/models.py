@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .conv import SNConv, SNConv_plus, SNConv_plus_plus
+from .conv import AGNNConv, SNConv, SNConv_plus, SNConv_plus_plus
 
 
 class _Stack(nn.Module):
@@ -49,6 +49,18 @@ class _Stack(nn.Module):
                 if self.bn:
                     self.bns.append(nn.BatchNorm1d(hidden_channels))
             self.lins.append(conv(hidden_channels, out_channels))
+
+
+class AGNN(_Stack):
+    """models.py:336-374: the cosine-attention baseline on the same kernel skeleton."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, bn=False):
+        super().__init__()
+        self.bn = bn
+        self._build(lambda i, o: AGNNConv(i, o), in_channels, hidden_channels, out_channels,
+                    num_layers)
+        self.dropout = nn.Dropout(p=0.5)
+        self.reset_parameters()
 
 
 class SNGNN(_Stack):

@@ -104,6 +104,60 @@ def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float) -
     return _Aggregate.apply(h, graph, top_k, thr)
 
 
+def attention_forward(graph: Graph, h: torch.Tensor, save_for_backward: bool = True):
+    """``sngnn_attn_forward``: softmax-of-cosine attention (AGNNConv after ``lin``,
+    models.py:396-405).  Returns (out [N, C], alpha [E'] in CSR order or None)."""
+    lib = _lib.load()
+    h = _check_rows(h, graph.num_total_nodes, "h")
+    c = h.size(1)
+    out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=h.device)
+    alpha = (torch.empty(graph.num_edges, dtype=torch.float32, device=h.device)
+             if save_for_backward else None)
+    with torch.cuda.device(h.device):
+        rc = lib.sngnn_attn_forward(graph.handle, h.data_ptr(), c, out.data_ptr(), _lib.ptr(alpha),
+                                    graph.workspace(c).data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_attn_forward")
+    return out, alpha
+
+
+def attention_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
+                       alpha: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    h = _check_rows(h, graph.num_total_nodes, "h")
+    grad_out = _check_rows(grad_out, graph.num_nodes, "grad_out")
+    c = h.size(1)
+    grad_h = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        rc = lib.sngnn_attn_backward(graph.handle, h.data_ptr(), c, grad_out.data_ptr(),
+                                     alpha.data_ptr(), grad_h.data_ptr(),
+                                     graph.workspace(c).data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_attn_backward")
+    return grad_h
+
+
+class _Attention(torch.autograd.Function):
+    """autograd seam of the attention mode (output fresh and unsaved: in-place ReLU safe)."""
+
+    @staticmethod
+    def forward(ctx, h, graph):
+        need_grad = ctx.needs_input_grad[0]
+        out, alpha = attention_forward(graph, h, save_for_backward=need_grad)
+        if need_grad:
+            ctx.graph = graph
+            ctx.save_for_backward(h, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        h, alpha = ctx.saved_tensors
+        return attention_backward(ctx.graph, h, grad_out.contiguous(), alpha), None
+
+
+def attention(h: torch.Tensor, graph: Graph) -> torch.Tensor:
+    """Differentiable cosine-attention aggregation: [N_total, C] -> [N, C]."""
+    return _Attention.apply(h, graph)
+
+
 def adj_linear_forward(graph: Graph, wt: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     lib = _lib.load()
     wt = _check_rows(wt, graph.num_nodes, "wt")

@@ -36,6 +36,25 @@ def test_against_committed_golden_vectors(cuda, path):
         np.testing.assert_array_equal(sel_src.cpu().numpy().astype(np.int64), z["sel_src"])
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "attn_*.npz"))))
+def test_attention_against_committed_golden_vectors(cuda, path):
+    from sngnn_amd import ops
+    from sngnn_amd.graph import Graph, LOOPS_REPLACE
+    z = np.load(path)
+    h = torch.from_numpy(z["h"]).to(cuda).requires_grad_(True)
+    g = Graph(torch.from_numpy(z["edge_index"]).to(cuda), h.size(0), True, LOOPS_REPLACE)
+    assert g.num_edges == z["ei_prime"].shape[1]
+    out = ops.attention(h, g)
+    (out * torch.from_numpy(z["gout"]).to(cuda)).sum().backward()
+    assert_close(out, torch.from_numpy(z["out"]))
+    gref = torch.from_numpy(z["grad_h"])
+    assert (h.grad.cpu() - gref).abs().max() <= 2e-5 * gref.abs().max()
+    _, alpha = ops.attention_forward(g, h.detach())
+    a_list = torch.empty(g.num_edges)
+    a_list[torch.from_numpy(g.array("eid").astype(np.int64))] = alpha.cpu()
+    assert_close(a_list, torch.from_numpy(z["alpha"]), what="alpha", atol=1e-7)
+
+
 @pytest.mark.parametrize("k,thr", [(16, 0.0), (1, 0.99), (16, 0.9)])
 def test_full_arxiv_size_against_c_oracle(cuda, k, thr):
     """Config 4 at full size: out within rtol 1e-5; selected indices bit-exact except

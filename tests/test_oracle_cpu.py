@@ -153,3 +153,29 @@ def test_toolbox_small_variants():
     assert w.numel() == int(ei[0].max()) + 1
     cm, _ = O.class_similarity_dense_small(x, y)
     np.testing.assert_allclose(cm.numpy(), O.class_similarity_dense_large(x, y).numpy(), atol=1e-6)
+
+
+def test_attention_restatement_known_answers():
+    """models.py:393-405.  Hand-derived: two orthogonal unit rows and their sum."""
+    h = torch.tensor([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    ei = torch.tensor([[0, 1, 2, 2], [2, 2, 2, 0]])          # (2,2) is an ORIGINAL loop
+    res = O.attention_reference(h, ei)
+    # loop removed first, then one loop per node appended at the end
+    assert res["ei"].tolist() == [[0, 1, 2, 0, 1, 2], [2, 2, 0, 0, 1, 2]]
+    r = 2 ** -0.5
+    np.testing.assert_allclose(res["s"].numpy(), [r, r, r, 1, 1, 1], rtol=1e-6)
+    e, o = np.exp(r), np.exp(1.0)
+    alpha = [e / (2 * e + o), e / (2 * e + o), e / (e + o), o / (e + o), 1.0, o / (2 * e + o)]
+    np.testing.assert_allclose(res["alpha"].numpy(), alpha, rtol=1e-6)
+    out2 = (alpha[0] * h[0] + alpha[1] * h[1] + alpha[5] * h[2]).numpy()
+    np.testing.assert_allclose(res["out"][2].numpy(), out2, rtol=1e-6)
+    np.testing.assert_allclose(res["out"][1].numpy(), [0.0, 1.0])
+    # the segment softmax equals torch.softmax applied group by group
+    gen = torch.Generator().manual_seed(0)
+    s = torch.rand(200, generator=gen) * 2 - 1
+    idx = torch.randint(0, 17, (200,), generator=gen)
+    got = O.segment_softmax(s, idx, 17)
+    for i in range(17):
+        m = idx == i
+        if m.any():
+            np.testing.assert_allclose(got[m].numpy(), torch.softmax(s[m], 0).numpy(), rtol=2e-6)

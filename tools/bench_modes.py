@@ -41,3 +41,20 @@ for name, add, rem, k, thr in (("SNConv (no selection, loops kept)", True, False
         hg.grad = None
         ops.aggregate(hg, g, k, thr).backward(gout)
     print(f"{name:40s} E'={g.num_edges:8d}  fwd {fwd:7.1f} us   fwd+bwd {timed(fb, reps=50):7.1f} us", flush=True)
+
+# cosine-attention mode (AGNNConv): loops replaced, softmax instead of mean
+from sngnn_amd.graph import LOOPS_REPLACE  # noqa: E402
+g = Graph(ei, n, True, LOOPS_REPLACE)
+fwd = timed(lambda: ops.attention_forward(g, h, save_for_backward=False))
+fwd_a = timed(lambda: ops.attention_forward(g, h))
+hg = h.clone().requires_grad_(True)
+gout = torch.randn_like(h)
+
+
+def fb_attn():
+    hg.grad = None
+    ops.attention(hg, g).backward(gout)
+
+
+print(f"{'AGNNConv attention':40s} E'={g.num_edges:8d}  fwd {fwd:7.1f} us (+alpha {fwd_a:7.1f})   "
+      f"fwd+bwd {timed(fb_attn, reps=50):7.1f} us", flush=True)
