@@ -51,6 +51,15 @@ def edge_cosine(x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
     return sim
 
 
+def signed_edge_attention(indices: torch.Tensor, wh: torch.Tensor):
+    """GGCNlayer_SP.get_sparse_att's values (models.py:1512-1519): the per-edge cosine
+    of ``wh`` rows split into its positive and negative parts, (relu(s), -relu(-s)),
+    each [nnz] in the order of ``indices`` ([2, nnz], the adjacency's COO indices).
+    Forward only (no autograd); rows below 1e-8 in norm follow F.normalize's clamp."""
+    s = edge_cosine(wh, indices)
+    return torch.relu(s), -torch.relu(-s)
+
+
 def class_block_sums(x: torch.Tensor, y: torch.Tensor, n_classes: int):
     """(sums [c, c] f64 of S over every class pair, diagonal sum f64) without forming S:
     sum_{i in A, j in B} <n_i, n_j> = <sum_A n, sum_B n>."""

@@ -179,3 +179,13 @@ def test_attention_restatement_known_answers():
         m = idx == i
         if m.any():
             np.testing.assert_allclose(got[m].numpy(), torch.softmax(s[m], 0).numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden",
+                                                                "attn_*.npz"))))
+def test_attention_golden_vectors_reproduce(path):
+    z = np.load(path)
+    res = O.attention_reference(torch.from_numpy(z["h"]), torch.from_numpy(z["edge_index"]))
+    assert np.array_equal(res["ei"].numpy(), z["ei_prime"])
+    np.testing.assert_allclose(res["out"].numpy(), z["out"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(res["alpha"].numpy(), z["alpha"], rtol=1e-6)

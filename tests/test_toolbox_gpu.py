@@ -129,3 +129,19 @@ def test_sparse_variants_against_scipy_sklearn(cuda):
         for b in range(4):
             blk = ref[y == a][:, y == b]
             assert abs(float(cm[a, b]) - float(blk.mean())) < 1e-6
+
+
+def test_signed_edge_attention_ggcn(cuda):
+    """models.py:1512-1519 with core torch as the checker (F.cosine_similarity is what
+    the reference calls there)."""
+    import torch.nn.functional as F
+    from sngnn_amd import toolbox as T
+    from tests.helpers import random_graph
+    n, c = 700, 64
+    wh = torch.randn(n, c, generator=torch.Generator().manual_seed(8))
+    idx = random_graph(n, 9000, seed=2)
+    sim = F.cosine_similarity(wh[idx[0]], wh[idx[1]])
+    pos, neg = T.signed_edge_attention(idx.to(cuda), wh.to(cuda))
+    np.testing.assert_allclose(pos.cpu().numpy(), F.relu(sim).numpy(), atol=2e-6)
+    np.testing.assert_allclose(neg.cpu().numpy(), (-F.relu(-sim)).numpy(), atol=2e-6)
+    assert (pos >= 0).all() and (neg <= 0).all() and ((pos == 0) | (neg == 0)).all()
