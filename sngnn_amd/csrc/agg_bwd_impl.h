@@ -17,6 +17,9 @@
 //             without the projection where the eps clamp is active)
 // Both passes are gathers with a fixed summation order: no floating-point
 // atomics, bitwise reproducible.  Row classes by degree as in the forward.
+// Pass T leaves one record per edge, wd[e] = {w_e / deg_i (or the UNSELECTED marker),
+// ds_e}, in CSR order (coalesced writes), so pass S needs a single random 8-byte read
+// per out-edge - not the cosine, ds_e and the target's degree from three arrays.
 #pragma once
 #include "device_utils.h"
 
@@ -27,7 +30,8 @@ struct BwdArgs {
     int C, N, Ntot, row_off;      // N owned target rows; Ntot sources / rows of h, grad_h
     const int32_t *rowptr, *col, *rperm;
     const int32_t *cscptr, *csc_eid, *csc_dst, *sperm;
-    float *ds, *dnT, *grad_h;
+    float2 *wd;                   // [E'] per-edge record written by pass T, read by pass S
+    float *dnT, *grad_h;
     int n_split, n_med_end, n_tasks;
     const int32_t *task_slot, *task_chunk, *split_task0;
     float *partT;
@@ -35,7 +39,6 @@ struct BwdArgs {
     const int32_t *stask_slot, *stask_chunk, *ssplit_task0;
     float *partS;
     int nbA, nbB;
-    int attn;       // attention mode (attn_impl.h): wsel = alpha_e, sum instead of mean
 };
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
@@ -50,43 +53,38 @@ __device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<
 }
 
 // ------------------------------- pass T ------------------------------------
-// one kept in-edge of target i: ds_e and its contribution to dnT_i
+// one kept in-edge of target i (source row x, record weight wq = w_e / deg_i):
+// ds_e, its record, and its contribution to dnT_i
 template <int VEC, int G, int R>
-__device__ __forceinline__ void t_edge(const BwdArgs &a, int e, const Row<VEC, G, R> &gp, int lg,
-                                       Row<VEC, G, R> &acc)
-{
-    Row<VEC, G, R> x;
-    const int j = a.col[e];
-    x.load(a.h + (size_t)j * a.C, a.C, lg);
-    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
-    const float d = group_sum<G>(gp.dot_partial(x));
-    if (lg == 0) a.ds[e] = d;
-    fma_row<VEC, G, R>(acc, d * invj, x);
-}
-
-// the same with the source row already loaded
-template <int VEC, int G, int R>
-__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, const Row<VEC, G, R> &x,
+__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, float wq, const Row<VEC, G, R> &x,
                                            const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc)
 {
-    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));
+    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
     const float d = group_sum<G>(gp.dot_partial(x));
-    if (lg == 0) a.ds[e] = d;
+    if (lg == 0) a.wd[e] = make_float2(wq, d);
     fma_row<VEC, G, R>(acc, d * invj, x);
 }
 
-// kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[];
-// lanes cover the range 64 at a time
-__device__ __forceinline__ int kept_list(const float *__restrict__ wsel, int rs, int e0, int e1,
-                                         int *list)
+// kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[] with their
+// record weights w * wscale in wlist[]; unkept edges get their (final) record here.
+// Lanes cover the range 64 at a time.
+__device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, float wscale,
+                                         int *list, float *wlist)
 {
     const int lane = lane_id();
     int n = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
-        const bool kept = t < e1 && is_kept(wsel[rs + t]);
+        const float w = t < e1 ? a.wsel[rs + t] : SNGNN_UNSELECTED;
+        const bool kept = is_kept(w);
         const unsigned long long m = __ballot(kept);
-        if (kept) list[n + prefix_popc(m)] = t;
+        if (kept) {
+            const int o = n + prefix_popc(m);
+            list[o] = t;
+            wlist[o] = w * wscale;
+        } else if (t < e1) {
+            a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+        }
         n += __popcll(m);
     }
     return n;
@@ -108,11 +106,18 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     const int rs = a.rowptr[i];
     const int deg = a.rowptr[i + 1] - rs;
     int *s_j = lds_wave + gid * 2 * SMALL_T;                 // [SMALL_T] source id or -1
-    for (int t = lg; t < deg; t += G)
-        s_j[t] = is_kept(a.wsel[rs + t]) ? a.col[rs + t] : -1;
+    float *s_w = reinterpret_cast<float *>(s_j + SMALL_T);   // [SMALL_T] w_e / deg_i
+    const float invdeg = 1.0f / (float)max(deg, 1);
+    for (int t = lg; t < deg; t += G) {
+        const float w = a.wsel[rs + t];
+        const bool kept = is_kept(w);
+        s_j[t] = kept ? a.col[rs + t] : -1;
+        s_w[t] = w * invdeg;
+        if (!kept) a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+    }
     RowT gp, acc;
     gp.load(a.gout + (size_t)i * a.C, a.C, lg);
-    gp.div((float)max(deg, 1));
+    gp.scale(invdeg);
     acc.zero();
     wave_lds_sync();
     for (int t0 = 0; t0 < deg; t0 += 2) {
@@ -120,8 +125,8 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
         RowT x0, x1;
         if (j0 >= 0) x0.load(a.h + (size_t)j0 * a.C, a.C, lg);
         if (j1 >= 0) x1.load(a.h + (size_t)j1 * a.C, a.C, lg);
-        if (j0 >= 0) t_edge_row<VEC, G, R>(a, rs + t0, x0, gp, lg, acc);
-        if (j1 >= 0) t_edge_row<VEC, G, R>(a, rs + t0 + 1, x1, gp, lg, acc);
+        if (j0 >= 0) t_edge_row<VEC, G, R>(a, rs + t0, s_w[t0], x0, gp, lg, acc);
+        if (j1 >= 0) t_edge_row<VEC, G, R>(a, rs + t0 + 1, s_w[t0 + 1], x1, gp, lg, acc);
     }
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
@@ -149,14 +154,21 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
     const int deg = a.rowptr[i + 1] - rs;
     e1 = task ? min(deg, e0 + CHUNK) : deg;
     RowT gp, acc;
+    const float invdeg = 1.0f / (float)deg;
     gp.load(a.gout + (size_t)i * a.C, a.C, lg);
-    gp.div((float)deg);
+    gp.scale(invdeg);
     acc.zero();
-    const int nsel = kept_list(a.wsel, rs, e0, e1, lds_wave);
+    float *wlist = reinterpret_cast<float *>(lds_wave + WAVE_T);
+    const int nsel = kept_list(a, rs, e0, e1, invdeg, lds_wave, wlist);
     wave_lds_sync();
     for (int q0 = 0; q0 < nsel; q0 += NG) {
         const int q = q0 + gid;
-        if (q < nsel) t_edge<VEC, G, R>(a, rs + lds_wave[q], gp, lg, acc);
+        if (q < nsel) {
+            const int e = rs + lds_wave[q];
+            RowT x;
+            x.load(a.h + (size_t)a.col[e] * a.C, a.C, lg);
+            t_edge_row<VEC, G, R>(a, e, wlist[q], x, gp, lg, acc);
+        }
     }
     acc.reduce_across_groups();
     if (gid == 0) {
@@ -168,7 +180,7 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][256];
+    __shared__ __align__(16) int lds[WAVES][256];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
@@ -177,7 +189,8 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 }
 
 // split targets: dnT_i = sum of the tasks' partial rows.  Thread (c, q) adds every 4th
-// task, the four sums are combined in fixed order (deterministic).
+// task (four independent chains, so the loads of a hub's ~100 tasks overlap); the sums are
+// combined in fixed order (deterministic).
 static __global__ __launch_bounds__(256) void k_bwd_t_fin(const BwdArgs a)
 {
     __shared__ float s[4][64];
@@ -187,10 +200,18 @@ static __global__ __launch_bounds__(256) void k_bwd_t_fin(const BwdArgs a)
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int c0 = 0; c0 < a.C; c0 += 64) {
         const int c = c0 + cl;
-        float v = 0.f;
-        if (c < a.C)
-            for (int t = t0 + q; t < t1; t += 4) v += a.partT[(size_t)t * a.C + c];
-        s[q][cl] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (c < a.C) {
+            int t = t0 + q;
+            for (; t + 12 < t1; t += 16) {
+                v0 += a.partT[(size_t)t * a.C + c];
+                v1 += a.partT[(size_t)(t + 4) * a.C + c];
+                v2 += a.partT[(size_t)(t + 8) * a.C + c];
+                v3 += a.partT[(size_t)(t + 12) * a.C + c];
+            }
+            for (; t < t1; t += 4) v0 += a.partT[(size_t)t * a.C + c];
+        }
+        s[q][cl] = (v0 + v1) + (v2 + v3);
         __syncthreads();
         if (q == 0 && c < a.C) a.dnT[(size_t)i * a.C + c] = (s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl]);
         __syncthreads();
@@ -198,20 +219,17 @@ static __global__ __launch_bounds__(256) void k_bwd_t_fin(const BwdArgs a)
 }
 
 // ------------------------------- pass S ------------------------------------
-// one kept out-edge (CSC entry q) of source v
+// one kept out-edge of source v: target row i (local), record {w / deg_i, ds_e}
 template <int VEC, int G, int R>
-__device__ __forceinline__ void s_edge(const BwdArgs &a, int q, float w, int lg,
+__device__ __forceinline__ void s_edge(const BwdArgs &a, int i, float2 rec, int lg,
                                        Row<VEC, G, R> &msg, Row<VEC, G, R> &dns)
 {
     Row<VEC, G, R> x, gi;
-    const int i = a.csc_dst[q];               // local target row
-    const int e = a.csc_eid[q];
     x.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     gi.load(a.gout + (size_t)i * a.C, a.C, lg);
-    if (!a.attn) gi.div((float)(a.rowptr[i + 1] - a.rowptr[i]));
     const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
-    fma_row<VEC, G, R>(msg, w, gi);
-    fma_row<VEC, G, R>(dns, a.ds[e] * invi, x);
+    fma_row<VEC, G, R>(msg, rec.x, gi);
+    fma_row<VEC, G, R>(dns, rec.y * invi, x);
 }
 
 // dh_v from msg_v and dn_v = dnT_v + dnS_v
@@ -239,13 +257,12 @@ __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VE
     msg.store(a.grad_h + (size_t)v * a.C, a.C, lg);
 }
 
-// one kept out-edge with its per-edge scalars already fetched
+// the same with both rows already loaded
 template <int VEC, int G, int R>
-__device__ __forceinline__ void s_edge_rows(const BwdArgs &a, const Row<VEC, G, R> &x, Row<VEC, G, R> &gi,
-                                            float w, float dse, int deg, Row<VEC, G, R> &msg,
+__device__ __forceinline__ void s_edge_rows(const Row<VEC, G, R> &x, const Row<VEC, G, R> &gi,
+                                            float w, float dse, Row<VEC, G, R> &msg,
                                             Row<VEC, G, R> &dns)
 {
-    gi.div((float)deg);
     const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
     fma_row<VEC, G, R>(msg, w, gi);
     fma_row<VEC, G, R>(dns, dse * invi, x);
@@ -266,21 +283,15 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     const int v = a.sperm[slot];
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
-    int *s_i = lds_wave + gid * 4 * SMALL_T;                          // target row or -1
-    int *s_deg = s_i + SMALL_T;
-    float *s_w = reinterpret_cast<float *>(s_i + 2 * SMALL_T);
-    float *s_ds = reinterpret_cast<float *>(s_i + 3 * SMALL_T);
+    int *s_i = lds_wave + gid * 3 * SMALL_T;                          // target row or -1
+    float *s_w = reinterpret_cast<float *>(s_i + SMALL_T);
+    float *s_ds = reinterpret_cast<float *>(s_i + 2 * SMALL_T);
     for (int t = lg; t < od; t += G) {
-        const int e = a.csc_eid[qs + t];
-        const float w = a.wsel[e];
-        const bool kept = is_kept(w);
-        const int i = kept ? a.csc_dst[qs + t] : -1;
-        s_i[t] = i;
-        if (kept) {
-            s_deg[t] = a.attn ? 1 : a.rowptr[i + 1] - a.rowptr[i];
-            s_w[t] = w;
-            s_ds[t] = a.ds[e];
-        }
+        const float2 rec = a.wd[a.csc_eid[qs + t]];
+        const bool kept = is_kept(rec.x);
+        s_i[t] = kept ? a.csc_dst[qs + t] : -1;
+        s_w[t] = rec.x;
+        s_ds[t] = rec.y;
     }
     RowT msg, dns;
     msg.zero();
@@ -297,8 +308,8 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
             x1.load(a.h + (size_t)(i1 + a.row_off) * a.C, a.C, lg);
             g1.load(a.gout + (size_t)i1 * a.C, a.C, lg);
         }
-        if (i0 >= 0) s_edge_rows<VEC, G, R>(a, x0, g0, s_w[t0], s_ds[t0], s_deg[t0], msg, dns);
-        if (i1 >= 0) s_edge_rows<VEC, G, R>(a, x1, g1, s_w[t0 + 1], s_ds[t0 + 1], s_deg[t0 + 1], msg, dns);
+        if (i0 >= 0) s_edge_rows<VEC, G, R>(x0, g0, s_w[t0], s_ds[t0], msg, dns);
+        if (i1 >= 0) s_edge_rows<VEC, G, R>(x1, g1, s_w[t0 + 1], s_ds[t0 + 1], msg, dns);
     }
     s_finish<VEC, G, R>(a, v, lg, msg, dns);
 }
@@ -325,15 +336,15 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
     const int e1 = task ? min(od, e0 + CHUNK) : od;
-    int *s_q = lds_wave;                                         // [WAVE_T] CSC positions
-    float *s_w = reinterpret_cast<float *>(lds_wave + WAVE_T);  // their cosines
+    int *s_i = lds_wave;                                         // [WAVE_T] kept target rows
+    float2 *s_rec = reinterpret_cast<float2 *>(lds_wave + WAVE_T);   // their records
     int nsel = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
-        const float w = t < e1 ? a.wsel[a.csc_eid[qs + t]] : SNGNN_UNSELECTED;
-        const bool kept = is_kept(w);
+        const float2 rec = t < e1 ? a.wd[a.csc_eid[qs + t]] : make_float2(SNGNN_UNSELECTED, 0.f);
+        const bool kept = is_kept(rec.x);
         const unsigned long long m = __ballot(kept);
-        if (kept) { const int o = nsel + prefix_popc(m); s_q[o] = qs + t; s_w[o] = w; }
+        if (kept) { const int o = nsel + prefix_popc(m); s_i[o] = a.csc_dst[qs + t]; s_rec[o] = rec; }
         nsel += __popcll(m);
     }
     wave_lds_sync();
@@ -342,7 +353,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     dns.zero();
     for (int q0 = 0; q0 < nsel; q0 += NG) {
         const int q = q0 + gid;
-        if (q < nsel) s_edge<VEC, G, R>(a, s_q[q], s_w[q], lg, msg, dns);
+        if (q < nsel) s_edge<VEC, G, R>(a, s_i[q], s_rec[q], lg, msg, dns);
     }
     msg.reduce_across_groups();
     dns.reduce_across_groups();
@@ -359,7 +370,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][512];
+    __shared__ __align__(16) int lds[WAVES][512];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) s_role_wave<VEC, G, R>(a, b, lw, true);

@@ -53,10 +53,10 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     a.C = C; a.N = (int)g->N; a.Ntot = (int)g->Ntot; a.row_off = (int)g->row_off;
     a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
     a.cscptr = g->cscptr; a.csc_eid = g->csc_eid; a.csc_dst = g->csc_dst; a.sperm = g->sperm;
-    // workspace layout (sngnn_graph_workspace_bytes): ds | dnT | partT (2C+4 per task) | partS
+    // workspace layout (sngnn_graph_workspace_bytes): wd (2 floats per edge) | dnT | partT (2C+4 per task) | partS
     float *ws = (float *)workspace;
-    a.ds = ws;
-    const size_t ds_len = ((size_t)g->Ep + 3) / 4 * 4;
+    a.wd = (float2 *)ws;
+    const size_t ds_len = (2 * (size_t)g->Ep + 3) / 4 * 4;
     a.dnT = ws + ds_len;
     a.partT = a.dnT + (size_t)g->N * C;
     a.partS = a.partT + (size_t)g->n_tasks * (2 * C + 4);
@@ -66,7 +66,6 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
     a.nbA = a.nbB = 0;
-    a.attn = 1;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {
     case 1: return launch_attn_bwd_v1(cfg, a, st);

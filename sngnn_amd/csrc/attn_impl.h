@@ -15,9 +15,9 @@
 //     ds_e  = alpha_e (t_e - dot_i)                        softmax Jacobian
 //     dnT_i = sum_e ds_e n_j = A_i - dot_i B_i,   A_i = sum alpha_e t_e n_j,  B_i = sum alpha_e n_j
 // so pass T is again a single gather pass (A, B and dot accumulate together); it
-// leaves ds_e per edge and dnT per row, after which the source-side pass S and the
-// F.normalize Jacobian are the aggregation's own kernels (agg_bwd_impl.h) with
-// weight alpha_e and no mean division.  No floating-point atomics anywhere.
+// leaves the records {alpha_e, ds_e} per edge and dnT per row, after which the
+// source-side pass S and the F.normalize Jacobian are the aggregation's own kernels
+// (agg_bwd_impl.h).  No floating-point atomics anywhere.
 #pragma once
 #include "agg_bwd_impl.h"
 
@@ -201,7 +201,8 @@ template <int VEC, int G, int R> int launch_attn_fwd(const AttnArgs &a0, hipStre
 }
 
 // ------------------------------ backward, pass T ----------------------------
-// BwdArgs (agg_bwd_impl.h) with wsel = alpha, attn = 1, partT rows of 2C + 4 floats.
+// BwdArgs (agg_bwd_impl.h) with wsel = alpha, records wd[e] = {alpha_e, ds_e}, partT rows
+// of 2C + 4 floats.
 
 // one in-edge: accumulates A, B, dot; returns t_e
 template <int VEC, int G, int R>
@@ -258,7 +259,7 @@ __device__ __forceinline__ void attn_t_small(const BwdArgs &a, int blk, int *lds
     fma_row<VEC, G, R>(A, -dot, B);                       // dnT_i = A - dot * B
     A.store(a.dnT + (size_t)i * a.C, a.C, lg);
     wave_lds_sync();
-    for (int t = lg; t < deg; t += G) a.ds[rs + t] = s_a[t] * (s_t[t] - dot);
+    for (int t = lg; t < deg; t += G) a.wd[rs + t] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
 }
 
 template <int VEC, int G, int R>
@@ -309,25 +310,25 @@ __device__ __forceinline__ void attn_t_wave(const BwdArgs &a, int blk, int *lds_
     B.reduce_across_groups();
     wave_lds_sync();
     if (task) {
-        // raw t_e now; the row's finalize knows dot_i and turns them into ds_e
+        // records carry the raw t_e for now; the row's finalize knows dot_i and makes them ds_e
         float *p = a.partT + (size_t)tq * (2 * a.C + 4);
         if (gid == 0) {
             A.store(p, a.C, lg);
             B.store(p + a.C, a.C, lg);
             if (lg == 0) p[2 * a.C] = dot;
         }
-        for (int t = lane; t < n; t += 64) a.ds[rs + e0 + t] = s_t[t];
+        for (int t = lane; t < n; t += 64) a.wd[rs + e0 + t] = make_float2(s_a[t], s_t[t]);
     } else {
         fma_row<VEC, G, R>(A, -dot, B);
         if (gid == 0) A.store(a.dnT + (size_t)i * a.C, a.C, lg);
-        for (int t = lane; t < n; t += 64) a.ds[rs + t] = s_a[t] * (s_t[t] - dot);
+        for (int t = lane; t < n; t += 64) a.wd[rs + t] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
     }
 }
 
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t(const BwdArgs a)
 {
-    __shared__ int lds[WAVES][3 * WAVE_T];
+    __shared__ __align__(16) int lds[WAVES][3 * WAVE_T];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) attn_t_wave<VEC, G, R>(a, b, lw, true);
@@ -371,7 +372,11 @@ static __global__ __launch_bounds__(256) void k_attn_bwd_t_fin(const BwdArgs a)
         }
         __syncthreads();
     }
-    for (int t = threadIdx.x; t < deg; t += 256) a.ds[rs + t] = a.wsel[rs + t] * (a.ds[rs + t] - dot);
+    for (int t = threadIdx.x; t < deg; t += 256) {
+        float2 rec = a.wd[rs + t];
+        rec.y = rec.x * (rec.y - dot);
+        a.wd[rs + t] = rec;
+    }
 }
 
 template <int VEC, int G, int R> int launch_attn_bwd(const BwdArgs &a0, hipStream_t st)

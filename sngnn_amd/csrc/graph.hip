@@ -414,10 +414,10 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
                   (int64_t)g->n_tasks * 32 * 8 +     // + CAND_MAX_K candidate keys per task
                   (int64_t)g->n_groups * 32 * 8 +    // + champions per finalize group
                   (int64_t)g->n_tasks * 32 * 4;      // + candidate source ids
-    // backward: ds per edge | dnT per node | partT per split task | partS (2 rows) per
+    // backward: {w, ds} record per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     //           (attention mode: 2 rows + 4 scalars) | partS (2 rows) per split-source task
-    int64_t bwd = (g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 +
+    int64_t bwd = (2 * g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 +
                   (int64_t)g->n_tasks * (2 * C + 4) * 4 + (int64_t)g->n_stasks * C * 4 * 2;
     int64_t b = std::max(fwd, bwd);
     return (b + 255) / 256 * 256;
