@@ -33,6 +33,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (!(cond)) { sngnn::set_error(msg); return (code); }             \
     } while (0)
 
+// MFMA weight gradient of self.lin (linear.hip), used by sngnn_linear_wgrad (head.hip)
+constexpr int WGRAD_MFMA_WGS = 256;           // persistent workgroups = partial results
+int wgrad_mfma_partials(int64_t N, int C, int F);
+int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, float *part, float *part_b,
+                      hipStream_t st);
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Lane layout of one node row for C channels:

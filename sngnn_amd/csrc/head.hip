@@ -37,6 +37,91 @@ __device__ __forceinline__ int wmin_i(int v)
 constexpr int HEAD_ROWS_PER_BLOCK = 16;    // 4 waves x 4 rows per step
 constexpr int HEAD_MAX_BLOCKS = 2048;      // persistent grid: partials stay few
 
+// Lane-per-row variant for C <= 64: a lane keeps its whole row in registers, so the
+// log-softmax needs no cross-lane step at all (the wave-per-row form below spends its
+// time in three 6-step shuffle reductions per row).  A row is 4 C contiguous bytes: every
+// byte of every line a lane touches is used, by that lane.  Same arithmetic per row as
+// the wave-per-row form (max, exp(z - max) summed in channel order, first maximum wins).
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, const int64_t *__restrict__ y,
+                                                   const unsigned char *__restrict__ sel, int64_t N, int C,
+                                                   float scale, float *__restrict__ grad,
+                                                   float *__restrict__ part)
+{
+    __shared__ float s_loss[4], s_corr[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss = 0.f, corr = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const bool on = sel[i] != 0;
+        float *gi = grad ? grad + i * C : nullptr;
+        if (!on) {
+            if (gi) {
+                if constexpr (VEC4) {
+                    for (int k = 0; 4 * k < C; ++k) reinterpret_cast<float4 *>(gi)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int c = 0; c < C; ++c) gi[c] = 0.f;
+                }
+            }
+            continue;
+        }
+        const float *zi = z + i * C;
+        const int yi = (int)y[i];
+        float v[64];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (4 * k < C) {                       // C is uniform: a scalar branch
+                if constexpr (VEC4) {
+                    const float4 t = reinterpret_cast<const float4 *>(zi)[k];
+                    v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * k + e] = 4 * k + e < C ? zi[4 * k + e] : -INFINITY;
+                }
+            }
+        }
+        float mx = -INFINITY, zy = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            if (c < C) {
+                if (v[c] > mx) { mx = v[c]; arg = c; }          // first maximum
+                if (c == yi) zy = v[c];
+            }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+        loss += -(zy - mx - logf(se));
+        corr += (arg == yi) ? 1.f : 0.f;
+        if (gi) {
+            const float inv = scale / se;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (4 * k < C) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[4 * k + e] * inv - (4 * k + e == yi ? scale : 0.f);
+                    if constexpr (VEC4) {
+                        reinterpret_cast<float4 *>(gi)[k] = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * k + e < C) gi[4 * k + e] = o[e];
+                    }
+                }
+            }
+        }
+    }
+    loss = wsum(loss);
+    corr = wsum(corr);
+    if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        part[2 * blockIdx.x + 1] = (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+    }
+}
+
 // One wave per row.  sel[i] != 0 marks the rows of the mask.  Per-block partial (loss
 // sum, correct count) go to part[]; grad (optional, dense [N, C]) = (softmax - onehot)
 // * scale on masked rows, 0 elsewhere.  C <= 64: the row lives in one register per lane.
@@ -257,9 +342,16 @@ extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsig
     SN_REQUIRE(N >= 0 && C >= 1, SNGNN_EINVAL, "bad shape");
     SN_REQUIRE(logits && y && row_mask && loss_and_correct && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (int)std::min<int64_t>((N + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK, HEAD_MAX_BLOCKS);
+    const bool rows = C <= 64;      // lane-per-row kernel
+    const int64_t per_block = rows ? 256 : HEAD_ROWS_PER_BLOCK;
+    const int nb = (int)std::min<int64_t>((N + per_block - 1) / per_block, HEAD_MAX_BLOCKS);
     const float scale = 1.0f / (float)(n_masked > 0 ? n_masked : 1);     // nll_loss(reduction='mean')
-    if (nb > 0)
+    const bool vec4 = C % 4 == 0 && (uintptr_t)logits % 16 == 0 && (grad_logits == nullptr || (uintptr_t)grad_logits % 16 == 0);
+    if (nb > 0 && rows && vec4)
+        k_head_rows<true><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
+    else if (nb > 0 && rows)
+        k_head_rows<false><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
+    else if (nb > 0)
         k_head<<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
     k_head_reduce<<<1, 256, 0, st>>>((const float *)workspace, nb, scale, loss_and_correct);
     SN_HIP(hipGetLastError());
@@ -268,7 +360,7 @@ extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsig
 
 extern "C" int64_t sngnn_linear_wgrad_workspace_bytes(int64_t N, int C, int F)
 {
-    const int64_t chunks = (N + WG_ROWS - 1) / WG_ROWS;
+    const int64_t chunks = std::max<int64_t>((N + WG_ROWS - 1) / WG_ROWS, wgrad_mfma_partials(N, C, F));
     return chunks * (int64_t)C * (F + 1) * 4 + 256;
 }
 
@@ -278,10 +370,14 @@ extern "C" int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t
     SN_REQUIRE(N >= 0 && C >= 1 && F >= 1, SNGNN_EINVAL, "bad shape");
     SN_REQUIRE(grad_out && x && grad_weight && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    const int chunks = (int)((N + WG_ROWS - 1) / WG_ROWS);
+    const int nmfma = wgrad_mfma_partials(N, C, F);
+    const bool mfma = nmfma > 0 && (uintptr_t)x % 16 == 0;
+    const int chunks = mfma ? nmfma : (int)((N + WG_ROWS - 1) / WG_ROWS);
     float *part = (float *)workspace;
     float *part_b = part + (size_t)chunks * C * F;
-    if (chunks > 0) {
+    if (mfma) {
+        if (int rc = launch_wgrad_mfma(grad_out, x, N, C, F, part, grad_bias ? part_b : nullptr, st)) return rc;
+    } else if (chunks > 0) {
         // accumulators per thread: the smallest tile that covers C (or 64 channels per pass)
         const int kacc = C <= 16 ? 8 : C <= 32 ? 16 : C <= 40 ? 20 : C <= 48 ? 24 : 32;
         dim3 grid((F + WG_FT - 1) / WG_FT, (C + 2 * kacc - 1) / (2 * kacc), chunks);

@@ -5,9 +5,22 @@
 // through LDS in coalesced 128-byte segments with the next panel already in
 // registers, and multiplies with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): 4 waves x
 // (32 rows x NT*32 columns).  W^T panels come from L2.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sngnn {
+
+// Orders LDS traffic between the lanes of ONE wave: LDS-only fences (the wave's global
+// loads and stores stay in flight - an all-address-space fence would wait for them with
+// s_waitcnt vmcnt(0) and serialise the pipeline below).
+__device__ __forceinline__ void wave_barrier_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int LF_M = 128, LF_K = 32, LF_LD = LF_K + 1;
@@ -75,6 +88,370 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Row-tile variant for F in {16, 32, 64, 128} (F = 16 FQ): persistent waves, each
+// owning 16-row tiles.  v_mfma_f32_16x16x4_f32 contracts 4 k's per step and the order
+// of the k's is free, so lane (row r = l & 15, quarter q = l >> 4) takes the
+// CONTIGUOUS quarter k in [q F/4, (q+1) F/4) of its row (A) / of its output column's
+// weight row (B): the whole W^T slice a lane ever needs is NT * F/4 registers, loaded
+// once per wave, and x is the only stream.  A tile of x is fetched with fully
+// coalesced 16-byte lane loads (whole rows), transposed through a wave-private LDS
+// tile (row stride F + 4 floats: conflict-free 16-byte reads); two tiles are staged in
+// registers, so a tile's loads are issued two multiply blocks before they are needed.
+// x and h are addressed through buffer resources: the hardware bounds check replaces
+// the row / column predicates (no branches, no 64-bit address arithmetic in the loop).
+// No workgroup barriers.
+// ---------------------------------------------------------------------------
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr unsigned BUF_OOB = 0x80000000u;       // an offset no table of < 2 GiB contains
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int NT, int FQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                   int N, int C, float *__restrict__ h, int ntiles)
+{
+    constexpr int F = 16 * FQ, KS = 4 * FQ, LD = F + 4;
+    constexpr int RPI = 16 / FQ;                     // rows covered by one wave-wide 16-byte load
+    __shared__ __align__(16) float lds[4][16 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    float *tile = lds[wave];
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, (unsigned)N * F * 4u);
+    const __amdgpu_buffer_rsrc_t hr = make_rsrc(h, (unsigned)N * (unsigned)C * 4u);
+
+    const int lrow = lane / KS, lc4 = lane % KS;     // staging: row within a load, float4 within the row
+    const unsigned xoff_lane = (unsigned)(lrow * F + 4 * lc4) * 4u;
+    // load q of a tile covers rows [q RPI, (q+1) RPI): RPI * F * 4 = 1024 bytes further on
+    auto xload = [&](unsigned tile_off, int q) {
+        return __builtin_amdgcn_raw_buffer_load_b128(xr, tile_off + xoff_lane + (unsigned)q * 1024u, 0, 0);
+    };
+    // Two staged tiles in named registers (a loop-carried private array gets demoted to
+    // LDS/scratch): set a holds tiles 0, 2, 4.. of this wave, set b tiles 1, 3, 5..; a set is
+    // refilled right after it has been copied to LDS, i.e. two multiply blocks ahead of use.
+    // Tiles past the end read out of bounds: zeros, never used.
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    u32x4 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+    a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = b0 = b1 = b2 = b3 = b4 = b5 = b6 = b7 = u32x4{0u, 0u, 0u, 0u};
+#define SNGNN_FETCH_TILE(P, TL)                                                            \
+    {                                                                                      \
+        const unsigned to_ = (unsigned)(TL) * (16u * F * 4u);                              \
+        P##0 = xload(to_, 0);                                                              \
+        if constexpr (FQ > 1) P##1 = xload(to_, 1);                                        \
+        if constexpr (FQ > 2) { P##2 = xload(to_, 2); P##3 = xload(to_, 3); }              \
+        if constexpr (FQ > 4) { P##4 = xload(to_, 4); P##5 = xload(to_, 5); P##6 = xload(to_, 6); P##7 = xload(to_, 7); } \
+    }
+#define SNGNN_PUT_TILE(P)                                                                  \
+    {                                                                                      \
+        auto put = [&](int q, const u32x4 &v) {                                            \
+            *reinterpret_cast<u32x4 *>(tile + (q * RPI + lrow) * LD + 4 * lc4) = v;        \
+        };                                                                                 \
+        put(0, P##0);                                                                      \
+        if constexpr (FQ > 1) put(1, P##1);                                                \
+        if constexpr (FQ > 2) { put(2, P##2); put(3, P##3); }                              \
+        if constexpr (FQ > 4) { put(4, P##4); put(5, P##5); put(6, P##6); put(7, P##7); }  \
+    }
+    const int nwaves = gridDim.x * 4;
+    int tl = blockIdx.x * 4 + wave;
+    SNGNN_FETCH_TILE(a, tl)
+    SNGNN_FETCH_TILE(b, tl + nwaves)
+
+    // B operands: W[c = 16 t + r16][kq KS + s].  (Columns >= C are clamped, not masked: they
+    // only feed outputs that are never stored.)
+    float bw[NT][KS];
+    float bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = min(16 * t + r16, C - 1);
+        bias[t] = b != nullptr ? b[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < FQ; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)c * F + kq * KS + 4 * j);
+            bw[t][4 * j + 0] = v.x; bw[t][4 * j + 1] = v.y; bw[t][4 * j + 2] = v.z; bw[t][4 * j + 3] = v.w;
+        }
+    }
+    // D: col = lane & 15, row = 4 (lane >> 4) + reg.  Byte offset of this lane's element (t, r)
+    // inside a tile of h; a column >= C gets an out-of-bounds offset (the store is dropped),
+    // and so does, by itself, a row >= N.
+    unsigned hoff[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            hoff[t][r] = (16 * t + r16 < C) ? (unsigned)((4 * kq + r) * C + 16 * t + r16) * 4u : BUF_OOB;
+    auto store_tile = [&](int tl_, const f32x4 (&v)[NT]) {
+        const unsigned to = (unsigned)tl_ * 16u * (unsigned)C * 4u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), hr, hoff[t][r] + to, 0, 0);
+    };
+    // The finished values of tile i (bias added) stay in their own registers and are stored
+    // in iteration i + 1, before that iteration's loads are issued.  A store reads its data
+    // registers late, so registers that were just handed to a store cannot be rewritten
+    // until it completes (s_waitcnt vmcnt): with a whole multiply block between the stores
+    // and the next write of prev[] that wait is free, and the loads behind the stores in the
+    // in-order vmcnt queue are not waited for.
+    f32x4 prev[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) prev[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int prev_tl = ntiles;            // "no tile yet": its stores fall out of bounds
+    // The W registers are re-defined by empty asm statements before the loop, so their loads
+    // are waited for HERE: otherwise the loop body keeps the waits its first trip needs for
+    // them (s_waitcnt vmcnt(n) in front of the MFMAs), and on every later trip those same
+    // waits drain the stores issued just before them.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        asm volatile("" : "+v"(bias[t]));
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(bw[t][k]));
+    }
+    auto multiply = [&](int tcur) {
+        float4 a[FQ];
+#pragma unroll
+        for (int j = 0; j < FQ; ++j)
+            a[j] = *reinterpret_cast<const float4 *>(tile + r16 * LD + kq * KS + 4 * j);
+        // keep the loads above the multiply block (the scheduler would sink them below it to
+        // save registers, which exposes the whole memory latency every iteration)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < FQ; ++j) {
+            const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[t][4 * j + e], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prev[t][r] = acc[t][r] + bias[t];
+        prev_tl = tcur;
+    };
+#define SNGNN_TILE_STEP(P, TCUR)                                                           \
+    {                                                                                      \
+        wave_barrier_lds();          /* the previous tile's LDS reads are done */          \
+        SNGNN_PUT_TILE(P)                                                                  \
+        wave_barrier_lds();                                                                \
+        store_tile(prev_tl, prev);                                                         \
+        SNGNN_FETCH_TILE(P, (TCUR) + 2 * nwaves)                                           \
+        multiply(TCUR);                                                                    \
+    }
+    for (; tl < ntiles; tl += 2 * nwaves) {
+        SNGNN_TILE_STEP(a, tl)
+        if (tl + nwaves < ntiles) SNGNN_TILE_STEP(b, tl + nwaves)
+    }
+    store_tile(prev_tl, prev);
+}
+
+#undef SNGNN_TILE_STEP
+#undef SNGNN_PUT_TILE
+#undef SNGNN_FETCH_TILE
+
+// ---------------------------------------------------------------------------
+// Weight gradient of the same layer on the matrix cores:
+//     dW[C, F] = g^T [C, N] . x [N, F],   db[C] = sum_rows g          (train.py:86)
+// The contraction runs over the N rows, so every wave streams its own 16-row blocks and
+// keeps a full C x F partial in accumulators (NT x UF tiles of 16 x 16).  Both the row order
+// inside a block and the assignment of output rows / columns to lanes are free, which
+// lets every operand come straight from a coalesced global load, no LDS:
+//   A (16 channels x 4 rows): lane (i = l & 15, kq = l >> 4) holds g[row + kq][NT i + t]
+//       - NT consecutive floats per lane,
+//   B (4 rows x 16 features): lane (j, kq) holds x[row + kq][f(j, u)] with
+//       f(j, u) = 64 (u / 4) + 4 j + u % 4  (UF >= 4)  or  UF j + u  - one or two 16-byte
+//       loads per lane, a whole row per 16 lanes.
+// Rows past N and channels past C read out of bounds (zero) through buffer resources.
+// A workgroup's four partials are added in LDS in wave order and written out; the
+// existing k_sum_partials adds the workgroups (fixed order: deterministic).
+// ---------------------------------------------------------------------------
+template <int NT, int UF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void k_wgrad_mfma(const float *__restrict__ g, const float *__restrict__ x, int N, int C,
+                  float *__restrict__ part, float *__restrict__ part_b, int nblocks)
+{
+    constexpr int F = 16 * UF;
+    constexpr int XV = UF >= 4 ? 4 : UF;            // floats per x load
+    constexpr int XL = UF / XV;                     // x loads per row (1 or 2)
+    __shared__ float red[NT * UF * 4][64];
+    __shared__ float redb[NT][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(g, (unsigned)N * (unsigned)C * 4u);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, (unsigned)N * F * 4u);
+
+    // per-lane byte offsets inside a 16-row block: row kq of step 0 (step s adds 4 rows)
+    unsigned goff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        goff[t] = (NT * i16 + t < C) ? (unsigned)(kq * C + NT * i16 + t) * 4u : BUF_OOB;
+    const unsigned xoff = (unsigned)(kq * F + XV * i16) * 4u;
+    const unsigned gstep = 4u * (unsigned)C * 4u;   // 4 rows of g
+
+    f32x4 acc[NT][UF];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < UF; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
+
+    struct Blk { float a[4][NT]; float b[4][UF]; };
+    auto fetch = [&](Blk &k, int blk) {
+        const unsigned go = (unsigned)blk * 16u * (unsigned)C * 4u;
+        const unsigned xo = (unsigned)blk * 16u * F * 4u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                k.a[s][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, goff[t] + go + s * gstep, 0, 0));
+#pragma unroll
+            for (int q = 0; q < XL; ++q) {
+                const unsigned o = xo + xoff + (unsigned)(s * 4 * F * 4 + q * 256);
+                if constexpr (XV == 4) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+                    k.b[s][4 * q + 0] = __uint_as_float(v[0]); k.b[s][4 * q + 1] = __uint_as_float(v[1]);
+                    k.b[s][4 * q + 2] = __uint_as_float(v[2]); k.b[s][4 * q + 3] = __uint_as_float(v[3]);
+                } else if constexpr (XV == 2) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(xr, o, 0, 0);
+                    k.b[s][0] = __uint_as_float(v[0]); k.b[s][1] = __uint_as_float(v[1]);
+                } else {
+                    k.b[s][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, o, 0, 0));
+                }
+            }
+        }
+    };
+    auto multiply = [&](const Blk &k) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bsum[t] += k.a[s][t];
+#pragma unroll
+                for (int u = 0; u < UF; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.a[s][t], k.b[s][u], acc[t][u], 0, 0, 0);
+            }
+    };
+    const int nwaves = gridDim.x * 4;
+    int blk = blockIdx.x * 4 + wave;
+    Blk k0, k1;
+    fetch(k0, blk);                      // (blocks past the end read zeros)
+    fetch(k1, blk + nwaves);
+    for (; blk < nblocks; blk += 2 * nwaves) {
+        multiply(k0);
+        fetch(k0, blk + 2 * nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(k1);
+        fetch(k1, blk + 3 * nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // workgroup reduction in wave order; slot (t, u, r) of lane l is
+    // dW[c = NT (4 (l >> 4) + r) + t][f = f(l & 15, u)]
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int u = 0; u < UF; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float *p = &red[(t * UF + u) * 4 + r][lane];
+                        *p = wv == 0 ? acc[t][u][r] : *p + acc[t][u][r];
+                    }
+                float bs = bsum[t];
+                bs += __shfl_xor(bs, 16, 64);
+                bs += __shfl_xor(bs, 32, 64);
+                if (kq == 0) redb[t][i16] = wv == 0 ? bs : redb[t][i16] + bs;
+            }
+        }
+        __syncthreads();
+    }
+    float *pw = part + (size_t)blockIdx.x * C * F;
+    for (int q = threadIdx.x; q < NT * UF * 4 * 64; q += 256) {
+        const int l = q & 63, slot = q >> 6;
+        const int r = slot & 3, u = (slot >> 2) % UF, t = (slot >> 2) / UF;
+        const int c = NT * (4 * (l >> 4) + r) + t;
+        const int j = l & 15;
+        const int f = UF >= 4 ? 64 * (u / 4) + 4 * j + u % 4 : UF * j + u;
+        if (c < C) pw[(size_t)c * F + f] = red[slot][l];
+    }
+    if (part_b != nullptr && threadIdx.x < NT * 16) {
+        const int t = threadIdx.x / 16, i = threadIdx.x % 16;
+        const int c = NT * i + t;
+        if (c < C) part_b[(size_t)blockIdx.x * C + c] = redb[t][i];
+    }
+}
+
+template <int UF>
+static int launch_wgrad_uf(const float *g, const float *x, int N, int C, float *part, float *part_b,
+                           int nwg, hipStream_t st)
+{
+    const int nblocks = (N + 15) / 16;
+    switch ((C + 15) / 16) {
+    case 1: k_wgrad_mfma<1, UF><<<nwg, 256, 0, st>>>(g, x, N, C, part, part_b, nblocks); break;
+    case 2: k_wgrad_mfma<2, UF><<<nwg, 256, 0, st>>>(g, x, N, C, part, part_b, nblocks); break;
+    case 3: k_wgrad_mfma<3, UF><<<nwg, 256, 0, st>>>(g, x, N, C, part, part_b, nblocks); break;
+    default: k_wgrad_mfma<4, UF><<<nwg, 256, 0, st>>>(g, x, N, C, part, part_b, nblocks); break;
+    }
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+// number of per-workgroup partials the MFMA weight gradient writes for N rows (0: shape
+// not handled, the caller falls back to k_wgrad_partial)
+int wgrad_mfma_partials(int64_t N, int C, int F)
+{
+    const int64_t lim = ((int64_t)1 << 31) - ((int64_t)64 << 20);
+    if (C > 64 || (F != 16 && F != 32 && F != 64 && F != 128)) return 0;
+    if (N < 1024 || N * F * 4 >= lim || N * (int64_t)C * 4 >= lim) return 0;
+    return (int)std::min<int64_t>(WGRAD_MFMA_WGS, (N + 63) / 64);
+}
+
+int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, float *part, float *part_b,
+                      hipStream_t st)
+{
+    const int nwg = wgrad_mfma_partials(N, C, F);
+    SN_REQUIRE(nwg > 0, SNGNN_EINVAL, "shape not handled by the MFMA weight gradient");
+    SN_REQUIRE((uintptr_t)x % 16 == 0, SNGNN_EINVAL, "x must be 16-byte aligned");
+    switch (F) {
+    case 16: return launch_wgrad_uf<1>(g, x, (int)N, C, part, part_b, nwg, st);
+    case 32: return launch_wgrad_uf<2>(g, x, (int)N, C, part, part_b, nwg, st);
+    case 64: return launch_wgrad_uf<4>(g, x, (int)N, C, part, part_b, nwg, st);
+    default: return launch_wgrad_uf<8>(g, x, (int)N, C, part, part_b, nwg, st);
+    }
+}
+
+template <int FQ>
+static int launch_linear_rows(const float *x, const float *w, const float *b, int N, int C, float *h,
+                              hipStream_t st)
+{
+    const int ntiles = (int)((N + 15) / 16);
+    // one workgroup per CU (one wave per SIMD): measured faster than two (29 vs 36 us at
+    // arxiv size) - the kernel is bound by its MFMA stream, more waves only add W traffic
+    static const int wg_cap = getenv("SNGNN_DEBUG_LIN_GRID") ? atoi(getenv("SNGNN_DEBUG_LIN_GRID")) : 256;
+    const int grid = std::min(wg_cap, (ntiles + 3) / 4);
+    switch ((C + 15) / 16) {
+    case 1: k_linear_rows<1, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
+    case 2: k_linear_rows<2, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
+    case 3: k_linear_rows<3, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
+    default: k_linear_rows<4, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
+    }
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
 }  // namespace sngnn
 
 using namespace sngnn;
@@ -87,6 +464,18 @@ extern "C" int sngnn_linear_forward(const float *x, const float *weight, const f
     if (N == 0) return SNGNN_OK;
     SN_REQUIRE(x && weight && h, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
+    const bool al16 = ((uintptr_t)x % 16 == 0) && ((uintptr_t)weight % 16 == 0);
+    // buffer addressing: both tables below 2 GiB (plus two tiles of slack for the prefetch)
+    const int64_t lim = ((int64_t)1 << 31) - ((int64_t)64 << 20);
+    if (al16 && N * F * 4 < lim && N * (int64_t)C * 4 < lim) {
+        switch (F) {
+        case 16: return launch_linear_rows<1>(x, weight, bias, (int)N, C, h, st);
+        case 32: return launch_linear_rows<2>(x, weight, bias, (int)N, C, h, st);
+        case 64: return launch_linear_rows<4>(x, weight, bias, (int)N, C, h, st);
+        case 128: return launch_linear_rows<8>(x, weight, bias, (int)N, C, h, st);
+        default: break;
+        }
+    }
     const unsigned grid = (unsigned)((N + LF_M - 1) / LF_M);
     if (C <= 32) k_linear_fwd<1><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h);
     else k_linear_fwd<2><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h);

@@ -32,7 +32,10 @@ def test_head_matches_log_softmax_nll_and_accuracy(cuda, n, c):
 
 
 @pytest.mark.parametrize("n,f,c", [(3000, 128, 40), (2277, 2325, 5), (1000, 33, 47), (513, 200, 70),
-                                   (9000, 128, 40), (5001, 77, 64), (4500, 1433, 7), (4100, 100, 33)])
+                                   (9000, 128, 40), (5001, 77, 64), (4500, 1433, 7), (4100, 100, 33),
+                                   # row-tile MFMA path: F in {16, 32, 64, 128}, every tile count
+                                   (5000, 16, 5), (4097, 32, 40), (6000, 64, 64), (4500, 128, 17),
+                                   (70001, 128, 40), (4111, 32, 33), (8200, 64, 1)])
 def test_linear_wgrad_matches_autograd(cuda, n, f, c):
     from sngnn_amd import ops
     g = torch.Generator().manual_seed(f)
