@@ -54,12 +54,14 @@ __device__ __forceinline__ int wave_sum_i(int v)
 }
 
 // Orders LDS traffic between the lanes of ONE wave (DS ops of a wave execute in
-// issue order; the fences stop the compiler from moving accesses across).
+// issue order; the fences stop the compiler from moving LDS accesses across).  The
+// fences name the LDS address space only: an all-address-space fence would also drain
+// the wave's outstanding global loads and stores (s_waitcnt vmcnt(0)) at every call.
 __device__ __forceinline__ void wave_lds_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // number of set bits of `mask` below this lane
