@@ -10,6 +10,7 @@ are the drop-in surface and are used here with the same positional arguments.
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, Optional
 
@@ -100,6 +101,13 @@ class GraphedEpoch:
         self.metrics = torch.zeros(6, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
             g["capturable"] = True
+            # one multi-tensor kernel per step instead of ~10 small ones (same update rule);
+            # only when the caller did not choose an implementation and every parameter is a
+            # plain contiguous tensor (SNGNN++ keeps w.weight column-major)
+            if (isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)) and g.get("fused") is None
+                    and g.get("foreach") is None and os.environ.get("SNGNN_FUSED_ADAM", "1") == "1"
+                    and all(p.is_contiguous() and p.is_cuda for p in g["params"])):
+                g["fused"] = True
         self._materialise_adam_state()
         with torch.no_grad():            # library handles / workspaces exist before the capture
             model.eval()
@@ -144,7 +152,10 @@ class GraphedEpoch:
 
     def _epoch(self):
         self.model.train()
-        self.opt.zero_grad(set_to_none=False)
+        # grads set to None: autograd then ASSIGNS the fresh gradient tensors (allocated in
+        # the graph's private pool, same addresses on every replay) instead of zero-filling
+        # and accumulating - two small kernels per parameter less
+        self.opt.zero_grad(set_to_none=True)
         loss, correct = self._loss("train")
         loss.backward()
         self.opt.step()
