@@ -283,8 +283,8 @@ void k_wgrad_mfma(const float *__restrict__ g, const float *__restrict__ x, int 
     constexpr int F = 16 * UF;
     constexpr int XV = UF >= 4 ? 4 : UF;            // floats per x load
     constexpr int XL = UF / XV;                     // x loads per row (1 or 2)
-    __shared__ float red[NT * UF * 4][64];
-    __shared__ float redb[NT][16];
+    __shared__ float red[4][NT * UF * 4][64];      // (NT = 4, UF = 8: 128 KiB of the CU's 160)
+    __shared__ float redb[4][NT][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(g, (unsigned)N * (unsigned)C * 4u);
@@ -332,9 +332,34 @@ void k_wgrad_mfma(const float *__restrict__ g, const float *__restrict__ x, int 
             }
         }
     };
-    auto multiply = [&](const Blk &k) {
+    // one 4-row step of a block: loads of step s of block `blk` into set k
+    auto fetch_step = [&](Blk &k, int blk, int s) {
+        const unsigned go = (unsigned)blk * 16u * (unsigned)C * 4u;
+        const unsigned xo = (unsigned)blk * 16u * F * 4u;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int t = 0; t < NT; ++t)
+            k.a[s][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gr, goff[t] + go + s * gstep, 0, 0));
+#pragma unroll
+        for (int q = 0; q < XL; ++q) {
+            const unsigned o = xo + xoff + (unsigned)(s * 4 * F * 4 + q * 256);
+            if constexpr (XV == 4) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+                k.b[s][4 * q + 0] = __uint_as_float(v[0]); k.b[s][4 * q + 1] = __uint_as_float(v[1]);
+                k.b[s][4 * q + 2] = __uint_as_float(v[2]); k.b[s][4 * q + 3] = __uint_as_float(v[3]);
+            } else if constexpr (XV == 2) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(xr, o, 0, 0);
+                k.b[s][0] = __uint_as_float(v[0]); k.b[s][1] = __uint_as_float(v[1]);
+            } else {
+                k.b[s][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, o, 0, 0));
+            }
+        }
+    };
+    // Multiply a block and refill its set, step by step: the loads of step s of the block
+    // three ahead are issued right behind the MFMAs that consumed step s, so with one wave
+    // per SIMD the load issue hides in the MFMA pipeline instead of following it.
+    auto multiply_refill = [&](Blk &k, int next_blk) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bsum[t] += k.a[s][t];
@@ -342,42 +367,43 @@ void k_wgrad_mfma(const float *__restrict__ g, const float *__restrict__ x, int 
                 for (int u = 0; u < UF; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(k.a[s][t], k.b[s][u], acc[t][u], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_step(k, next_blk, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
+    // Three operand sets in rotation: a set is needed again two multiply blocks (~3 us)
+    // after its refill - one block is less than the memory latency.  Blocks past the end
+    // read zeros.
     const int nwaves = gridDim.x * 4;
     int blk = blockIdx.x * 4 + wave;
-    Blk k0, k1;
-    fetch(k0, blk);                      // (blocks past the end read zeros)
+    Blk k0, k1, k2;
+    fetch(k0, blk);
     fetch(k1, blk + nwaves);
-    for (; blk < nblocks; blk += 2 * nwaves) {
-        multiply(k0);
-        fetch(k0, blk + 2 * nwaves);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(k1);
-        fetch(k1, blk + 3 * nwaves);
-        __builtin_amdgcn_sched_barrier(0);
+    fetch(k2, blk + 2 * nwaves);
+    for (; blk < nblocks; blk += 3 * nwaves) {
+        multiply_refill(k0, blk + 3 * nwaves);
+        if (blk + nwaves >= nblocks) break;
+        multiply_refill(k1, blk + 4 * nwaves);
+        if (blk + 2 * nwaves >= nblocks) break;
+        multiply_refill(k2, blk + 5 * nwaves);
     }
 
-    // workgroup reduction in wave order; slot (t, u, r) of lane l is
-    // dW[c = NT (4 (l >> 4) + r) + t][f = f(l & 15, u)]
-    for (int wv = 0; wv < 4; ++wv) {
-        if (wave == wv) {
+    // workgroup reduction: every wave parks its partial in LDS, then each thread adds the
+    // four copies of its outputs in wave order (deterministic) and writes them out.
+    // slot (t, u, r) of lane l is dW[c = NT (4 (l >> 4) + r) + t][f = f(l & 15, u)]
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int u = 0; u < UF; ++u)
+        for (int u = 0; u < UF; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float *p = &red[(t * UF + u) * 4 + r][lane];
-                        *p = wv == 0 ? acc[t][u][r] : *p + acc[t][u][r];
-                    }
-                float bs = bsum[t];
-                bs += __shfl_xor(bs, 16, 64);
-                bs += __shfl_xor(bs, 32, 64);
-                if (kq == 0) redb[t][i16] = wv == 0 ? bs : redb[t][i16] + bs;
-            }
-        }
-        __syncthreads();
+            for (int r = 0; r < 4; ++r) red[wave][(t * UF + u) * 4 + r][lane] = acc[t][u][r];
+        float bs = bsum[t];
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (kq == 0) redb[wave][t][i16] = bs;
     }
+    __syncthreads();
     float *pw = part + (size_t)blockIdx.x * C * F;
     for (int q = threadIdx.x; q < NT * UF * 4 * 64; q += 256) {
         const int l = q & 63, slot = q >> 6;
@@ -385,12 +411,13 @@ void k_wgrad_mfma(const float *__restrict__ g, const float *__restrict__ x, int 
         const int c = NT * (4 * (l >> 4) + r) + t;
         const int j = l & 15;
         const int f = UF >= 4 ? 64 * (u / 4) + 4 * j + u % 4 : UF * j + u;
-        if (c < C) pw[(size_t)c * F + f] = red[slot][l];
+        if (c < C) pw[(size_t)c * F + f] = ((red[0][slot][l] + red[1][slot][l]) + red[2][slot][l]) + red[3][slot][l];
     }
     if (part_b != nullptr && threadIdx.x < NT * 16) {
         const int t = threadIdx.x / 16, i = threadIdx.x % 16;
         const int c = NT * i + t;
-        if (c < C) part_b[(size_t)blockIdx.x * C + c] = redb[t][i];
+        if (c < C)
+            part_b[(size_t)blockIdx.x * C + c] = ((redb[0][t][i] + redb[1][t][i]) + redb[2][t][i]) + redb[3][t][i];
     }
 }
 
