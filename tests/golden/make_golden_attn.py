@@ -39,3 +39,39 @@ for name, (n, e, C, hubs) in CASES.items():
                         s=ref["s"].detach().numpy(), alpha=ref["alpha"].detach().numpy(),
                         ei_prime=ref["ei"].numpy())
     print(name, "E' =", ref["ei"].size(1))
+
+
+# Harness fixture for the attention model (as make_golden.py's make_trajectory): the
+# reference trainer's loop (train.py:73-160) on the oracle's AGNN, CPU, seeded.  One layer:
+# the wrapper's dropout (p = 0.5) never runs, so the trajectory is RNG-free.
+def make_trajectory(epochs=5):
+    import torch.nn.functional as F
+    from sngnn_amd import synth
+    data = synth.make_dataset("cora", seed=7, scale=0.25)
+    torch.manual_seed(1234)
+    model = O.AGNN(data.x.size(1), 16, 7, 1)
+    init = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    traj = []
+    for _ in range(epochs):
+        model.train()
+        opt.zero_grad()
+        out = model(data)
+        loss = F.nll_loss(out[data.train_mask], data.y[data.train_mask])
+        loss.backward()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            out = model(data)
+            rec = [float(loss)]
+            for m in (data.val_mask, data.test_mask):
+                rec += [float(F.nll_loss(out[m], data.y[m])),
+                        float((out[m].max(1)[1] == data.y[m]).float().mean())]
+        traj.append(rec)
+    final = {"final." + k: v.clone().numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "traj_agnn_1layer.npz"), traj=np.array(traj, np.float64),
+                        **{"init." + k: v for k, v in init.items()}, **final)
+    print("agnn trajectory", [round(t[0], 4) for t in traj])
+
+
+make_trajectory()

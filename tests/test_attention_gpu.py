@@ -178,3 +178,22 @@ def test_bad_arguments(cuda):
         ops.attention_forward(g, torch.zeros(30, 513, device=cuda))
     with pytest.raises(ValueError):
         Graph(ei, 30, True, 3)
+
+
+def test_agnn_graphed_epoch_matches_eager(cuda):
+    """The attention model runs under the HIP-graph epoch like the SNGNN family."""
+    import sngnn_amd
+    from sngnn_amd import synth
+    from sngnn_amd import train as T
+    data = synth.make_dataset("cora", scale=0.5).to(cuda)
+    n, f = data.x.shape
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(11)
+        model = sngnn_amd.AGNN(f, 16, 7, 1).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
+        fn = T.train_graphed if graphed else T.train
+        runs.append(fn(model, data, opt, epochs=5, patience=100))
+    for a, b in zip(runs[0]["history"], runs[1]["history"]):
+        for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_acc"):
+            assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (a["epoch"], k, a[k], b[k])

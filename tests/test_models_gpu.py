@@ -110,6 +110,7 @@ def test_graphed_epoch_matches_eager_trajectory(cuda):
     ("SNGNN_Plus", lambda f, n: (f, 16, 7, n, 2, 3, 0.1, 1, 0.0), "plus_2layer"),
     ("SNGNN_Plus_Plus", lambda f, n: (f, 16, 7, n, 1, 4, 0.2, 0.3, 1, 0.0), "plusplus_1layer"),
     ("SNGNN", lambda f, n: (f, 16, 7, 1), "sngnn_1layer"),
+    ("AGNN", lambda f, n: (f, 16, 7, 1), "agnn_1layer"),
 ])
 def test_training_trajectory_matches_committed_fixture(cuda, kind, args, name):
     """SURVEY.md 8 harness row: 5 epochs of the reference loop (train.py:73-160) on the
