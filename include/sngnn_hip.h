@@ -181,6 +181,21 @@ int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C,
                         void *workspace, void *stream);
 
 /*
+ * Replaces: the SNGNN++ blend  out = beta * out_0 + (1 - beta) * out_1  (models.py:134)
+ * and its autograd, one pass over the n = N * C elements each way instead of five
+ * elementwise launches.  beta: dev f32 [1] (the layer's Parameter).  Backward writes
+ * grad0 = beta * grad_out, grad1 = (1 - beta) * grad_out and grad_beta [1] =
+ * sum grad_out * (out_0 - out_1) (fixed-order sum).  workspace:
+ * sngnn_blend_workspace_bytes().
+ */
+int64_t sngnn_blend_workspace_bytes(void);
+int sngnn_blend_forward(const float *out0, const float *out1, const float *beta, int64_t n,
+                        float *out, void *stream);
+int sngnn_blend_backward(const float *grad_out, const float *out0, const float *out1,
+                         const float *beta, int64_t n, float *grad0, float *grad1,
+                         float *grad_beta, void *workspace, void *stream);
+
+/*
  * The same two gather-sums on any graph, node-range partitions included (multi-GPU
  * SNGNN++; new - the reference is single-device).  A rank builds the partition of the
  * FLIPPED edge list (row 0 and row 1 of edge_index swapped), whose owned "targets" are

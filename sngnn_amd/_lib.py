@@ -39,6 +39,9 @@ SIGNATURES = {
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_blend_workspace_bytes": (_i64, []),
+    "sngnn_blend_forward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "sngnn_blend_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),

@@ -236,7 +236,7 @@ class SNConv_plus_plus(nn.Module):
                                          row_range=(part.row_begin, part.row_end))
             out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
         out_1 = _aggregate(h, graph, int(self.top_k), float(self.thr))[:, :c]
-        out = self.beta * out_0 + (1 - self.beta) * out_1
+        out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias
         return out

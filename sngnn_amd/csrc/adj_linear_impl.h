@@ -102,18 +102,36 @@ __global__ __launch_bounds__(BLOCK) void k_adj(const AdjArgs a)
     }
 }
 
-// split segments: add the tasks' partial rows in task order (+ bias)
-static __global__ void k_adj_fin(const AdjArgs a)
+// split segments: the sum of the tasks' partial rows (+ bias).  Thread (c, q) adds every
+// 4th task in four independent chains (the loads of a hub's ~100 tasks overlap); the sums
+// are combined in fixed order (deterministic).
+static __global__ __launch_bounds__(256) void k_adj_fin(const AdjArgs a)
 {
+    __shared__ float s[4][64];
     const int p = blockIdx.x;
     const int seg = a.perm[p];
     const int r = seg - a.seg_shift;
-    if (r < 0) return;
+    if (r < 0) return;                                  // block-uniform
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-        float s = a.bias ? a.bias[c] : 0.f;
-        for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-        a.out[(size_t)r * a.C + c] = s;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < a.C; c0 += 64) {
+        const int c = c0 + cl;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (c < a.C) {
+            int t = t0 + q;
+            for (; t + 12 < t1; t += 16) {
+                v0 += a.partial[(size_t)t * a.C + c];
+                v1 += a.partial[(size_t)(t + 4) * a.C + c];
+                v2 += a.partial[(size_t)(t + 8) * a.C + c];
+                v3 += a.partial[(size_t)(t + 12) * a.C + c];
+            }
+            for (; t < t1; t += 4) v0 += a.partial[(size_t)t * a.C + c];
+        }
+        s[q][cl] = (v0 + v1) + (v2 + v3);
+        __syncthreads();
+        if (q == 0 && c < a.C)
+            a.out[(size_t)r * a.C + c] = ((s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl])) + (a.bias ? a.bias[c] : 0.f);
+        __syncthreads();
     }
 }
 

@@ -1,0 +1,113 @@
+// SNGNN++ blend (models/models.py:134): out = beta * out_0 + (1 - beta) * out_1, beta a
+// learnable scalar kept on the device.  PyTorch runs this line as five elementwise
+// kernels forward and about as many backward, each a full pass over [N, C]; here it is
+// one pass each way, with the reference's rounding (every product and the sum rounded
+// separately; the library is built with -ffp-contract=off).
+#include "common.h"
+
+namespace sngnn {
+
+constexpr int BLEND_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void k_blend_fwd(const float *__restrict__ o0, const float *__restrict__ o1,
+                                                   const float *__restrict__ beta, int64_t n4, int64_t n,
+                                                   float *__restrict__ out)
+{
+    const float b = beta[0], nb = 1.0f - b;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(o0)[i], y = reinterpret_cast<const float4 *>(o1)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(b * x.x + nb * y.x, b * x.y + nb * y.y,
+                                                          b * x.z + nb * y.z, b * x.w + nb * y.w);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = b * o0[i] + nb * o1[i];
+}
+
+// g0 = beta * g, g1 = (1 - beta) * g, per-block partial of d beta = sum g * (out_0 - out_1)
+__global__ __launch_bounds__(256) void k_blend_bwd(const float *__restrict__ g, const float *__restrict__ o0,
+                                                   const float *__restrict__ o1, const float *__restrict__ beta,
+                                                   int64_t n4, int64_t n, float *__restrict__ g0,
+                                                   float *__restrict__ g1, float *__restrict__ part)
+{
+    __shared__ float s[256];
+    const float b = beta[0], nb = 1.0f - b;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(o0)[i], y = reinterpret_cast<const float4 *>(o1)[i];
+        const float4 d = reinterpret_cast<const float4 *>(g)[i];
+        reinterpret_cast<float4 *>(g0)[i] = make_float4(b * d.x, b * d.y, b * d.z, b * d.w);
+        reinterpret_cast<float4 *>(g1)[i] = make_float4(nb * d.x, nb * d.y, nb * d.z, nb * d.w);
+        acc += (d.x * (x.x - y.x) + d.y * (x.y - y.y)) + (d.z * (x.z - y.z) + d.w * (x.w - y.w));
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float d = g[i];
+        g0[i] = b * d;
+        g1[i] = nb * d;
+        acc += d * (o0[i] - o1[i]);
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) s[threadIdx.x] += s[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void k_blend_reduce(const float *__restrict__ part, int nblocks,
+                                                      float *__restrict__ dbeta)
+{
+    __shared__ double s[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) a += part[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) s[threadIdx.x] += s[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbeta[0] = (float)s[0];
+}
+
+static int blend_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(BLEND_BLOCKS, (n / 4 + 255) / 256)); }
+
+}  // namespace sngnn
+
+using namespace sngnn;
+
+extern "C" int64_t sngnn_blend_workspace_bytes(void) { return (int64_t)BLEND_BLOCKS * 4 + 256; }
+
+extern "C" int sngnn_blend_forward(const float *out0, const float *out1, const float *beta, int64_t n,
+                                   float *out, void *stream)
+{
+    SN_REQUIRE(n >= 0, SNGNN_EINVAL, "negative size");
+    if (n == 0) return SNGNN_OK;
+    SN_REQUIRE(out0 && out1 && beta && out, SNGNN_EINVAL, "NULL argument");
+    const bool al = ((uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)out) % 16 == 0;
+    k_blend_fwd<<<blend_grid(n), 256, 0, (hipStream_t)stream>>>(out0, out1, beta, al ? n / 4 : 0, n, out);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_blend_backward(const float *grad_out, const float *out0, const float *out1,
+                                    const float *beta, int64_t n, float *grad0, float *grad1,
+                                    float *grad_beta, void *workspace, void *stream)
+{
+    SN_REQUIRE(n >= 0, SNGNN_EINVAL, "negative size");
+    SN_REQUIRE(grad_beta && workspace, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = 0;
+    if (n > 0) {
+        SN_REQUIRE(grad_out && out0 && out1 && beta && grad0 && grad1, SNGNN_EINVAL, "NULL argument");
+        const bool al = ((uintptr_t)grad_out | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)grad0 |
+                         (uintptr_t)grad1) % 16 == 0;
+        nb = blend_grid(n);
+        k_blend_bwd<<<nb, 256, 0, st>>>(grad_out, out0, out1, beta, al ? n / 4 : 0, n, grad0, grad1,
+                                        (float *)workspace);
+    }
+    k_blend_reduce<<<1, 256, 0, st>>>((const float *)workspace, nb, grad_beta);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}

@@ -325,6 +325,46 @@ def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     return lin(x)
 
 
+class _Blend(torch.autograd.Function):
+    """``beta * out_0 + (1 - beta) * out_1`` (models.py:134) in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, out0, out1, beta):
+        lib = _lib.load()
+        out = torch.empty_like(out0)
+        with torch.cuda.device(out0.device):
+            rc = lib.sngnn_blend_forward(out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), out0.numel(),
+                                         out.data_ptr(), _stream(out0.device))
+        _lib.check(rc, "sngnn_blend_forward")
+        ctx.save_for_backward(out0, out1, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out0, out1, beta = ctx.saved_tensors
+        lib = _lib.load()
+        g = g.contiguous()
+        g0, g1 = torch.empty_like(g), torch.empty_like(g)
+        gbeta = torch.empty_like(beta)
+        ws = _workspace("blend", lib.sngnn_blend_workspace_bytes(), g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.sngnn_blend_backward(g.data_ptr(), out0.data_ptr(), out1.data_ptr(), beta.data_ptr(),
+                                          g.numel(), g0.data_ptr(), g1.data_ptr(), gbeta.data_ptr(),
+                                          ws.data_ptr(), _stream(g.device))
+        _lib.check(rc, "sngnn_blend_backward")
+        return g0, g1, gbeta
+
+
+def blend(out0: torch.Tensor, out1: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """SNGNN++'s ``beta * out_0 + (1 - beta) * out_1``; fused for contiguous fp32 GPU tensors of
+    one shape with a one-element fp32 ``beta``, the plain expression otherwise."""
+    if (out0.is_cuda and out0.dtype == torch.float32 and out1.dtype == torch.float32 and out0.shape == out1.shape
+            and out0.is_contiguous() and out1.is_contiguous() and beta.numel() == 1
+            and beta.dtype == torch.float32 and beta.is_cuda):
+        return _Blend.apply(out0, out1, beta)
+    return beta * out0 + (1 - beta) * out1
+
+
 class _HeadNLL(torch.autograd.Function):
     """mean NLL of log_softmax(logits) over the masked rows; also returns the number
     of correctly classified masked rows (no gradient)."""

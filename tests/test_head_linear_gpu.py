@@ -59,3 +59,27 @@ def test_linear_wgrad_matches_autograd(cuda, n, f, c):
     xr2 = x.clone().requires_grad_(True)
     (lin(xr2) * gout).sum().backward()
     assert (xr.grad - xr2.grad).abs().max() <= 1e-4 * float(xr2.grad.abs().max())
+
+
+@pytest.mark.parametrize("n,c", [(1000, 40), (777, 5), (4096, 47), (1, 1)])
+def test_blend_matches_the_reference_expression(cuda, n, c):
+    """models.py:134 and its autograd: forward and both tensor gradients bit-exact, the
+    scalar gradient a differently ordered sum."""
+    from sngnn_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    o0 = torch.randn(n, c, generator=g).to(cuda).requires_grad_(True)
+    o1 = torch.randn(n, c, generator=g).to(cuda).requires_grad_(True)
+    gout = torch.randn(n, c, generator=g).to(cuda)
+    beta = torch.tensor([0.3], device=cuda, requires_grad=True)
+    ref = beta * o0 + (1 - beta) * o1
+    ref.backward(gout)
+    want = (ref.detach().clone(), o0.grad.clone(), o1.grad.clone(), beta.grad.clone())
+    o0.grad = o1.grad = beta.grad = None
+    out = ops.blend(o0, o1, beta)
+    out.backward(gout)
+    assert torch.equal(out, want[0])
+    assert torch.equal(o0.grad, want[1]) and torch.equal(o1.grad, want[2])
+    assert abs(float(beta.grad) - float(want[3])) <= 2e-5 * max(1.0, abs(float(want[3])))
+    # anything the fused path does not take falls back to the expression
+    assert torch.equal(ops.blend(o0.detach()[:, : max(c - 1, 1)], o1.detach()[:, : max(c - 1, 1)], beta.detach()),
+                       (beta * o0[:, : max(c - 1, 1)] + (1 - beta) * o1[:, : max(c - 1, 1)]).detach())
