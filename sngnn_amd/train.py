@@ -101,12 +101,15 @@ class GraphedEpoch:
         self.metrics = torch.zeros(6, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
             g["capturable"] = True
-            # one multi-tensor kernel per step instead of ~10 small ones (same update rule);
-            # only when the caller did not choose an implementation and every parameter is a
-            # plain contiguous tensor (SNGNN++ keeps w.weight column-major)
+            # one multi-tensor kernel per step instead of ~10 small ones per parameter (same
+            # update rule); only when the caller did not choose an implementation and every
+            # parameter is dense (SNGNN++'s column-major w.weight is: its gradient and the
+            # Adam state share its strides, so the flat multi-tensor walk lines up)
+            def dense(p):
+                return p.is_contiguous() or (p.dim() == 2 and p.t().is_contiguous())
             if (isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)) and g.get("fused") is None
                     and g.get("foreach") is None and os.environ.get("SNGNN_FUSED_ADAM", "1") == "1"
-                    and all(p.is_contiguous() and p.is_cuda for p in g["params"])):
+                    and all(dense(p) and p.is_cuda for p in g["params"])):
                 g["fused"] = True
         self._materialise_adam_state()
         with torch.no_grad():            # library handles / workspaces exist before the capture

@@ -84,8 +84,10 @@ def test_state_dict_round_trip(cuda):
     assert ours2.lins[0].w.weight.t().is_contiguous()
 
 
-def test_graphed_epoch_matches_eager_trajectory(cuda):
-    """The HIP-graph epoch is the same arithmetic as the reference-style eager loop."""
+@pytest.mark.parametrize("kind", ["SNGNN_Plus", "SNGNN_Plus_Plus"])
+def test_graphed_epoch_matches_eager_trajectory(cuda, kind):
+    """The HIP-graph epoch is the same arithmetic as the reference-style eager loop
+    (SNGNN++: fused blend, fused Adam over the column-major w.weight)."""
     import sngnn_amd
     from sngnn_amd import train as T
     from sngnn_amd import synth
@@ -94,7 +96,10 @@ def test_graphed_epoch_matches_eager_trajectory(cuda):
     runs = []
     for graphed in (False, True):
         torch.manual_seed(11)
-        model = sngnn_amd.SNGNN_Plus(f, 16, 7, n, 2, 3, 0.1, 1, 0.0).to(cuda)
+        if kind == "SNGNN_Plus":
+            model = sngnn_amd.SNGNN_Plus(f, 16, 7, n, 2, 3, 0.1, 1, 0.0).to(cuda)
+        else:
+            model = sngnn_amd.SNGNN_Plus_Plus(f, 16, 7, n, 2, 3, 0.1, 0.4, 1, 0.0).to(cuda)
         # same optimizer flavour on both sides: torch's capturable Adam keeps the step
         # count and bias corrections on the device (fp32), which alone moves the
         # trajectory by ~1e-3 relative to the default host-side (fp64) bookkeeping
