@@ -96,6 +96,8 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     a.split_cnt = g->split_cnt; a.grp_cnt = g->grp_cnt; a.split_grp0 = g->split_grp0;
     a.cand2 = a.cand_key ? a.cand_key + (size_t)g->n_tasks * 32 : nullptr;
     a.cand_src = a.cand2 ? (int32_t *)(a.cand2 + (size_t)g->n_groups * 32) : nullptr;
+    // split rows whose (tasks * top_k) candidates exceed one 128-key wave selection
+    a.n_split_gt_wave = top_k > 0 ? g->rows_gt((int64_t)(128 / std::min(top_k, 128)) * CHUNK) : 0;
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     a.nbA = ceil_div(g->n_tasks, WAVES);

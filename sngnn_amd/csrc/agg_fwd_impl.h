@@ -56,6 +56,7 @@ struct FwdArgs {
     int dbg_classes;            // tuning aid: bit 0 tasks, bit 1 wave rows, bit 2 small rows
     int dbg_blocks_per_cu;      // tuning aid: persistent grid size override (0 = default)
     int inkernel_fin;           // split rows finalized by their last-arriving task (experimental)
+    int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
     int use_dma;                // classes A/B stream source rows through LDS-DMA (C % 4 == 0, C <= 256)
 };
 
@@ -968,6 +969,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
 // one 256-thread workgroup per row merges the tasks' candidate keys 128 at a
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
+constexpr int FIN_WAVE_MIN_ROWS = 2048;   // fewer moderate split rows than this: one launch (k_agg_fin_cand) for all
 constexpr int FINC_BLOCK = 1024, FINC_WAVES = FINC_BLOCK / 64;   // 8 waves: the tournament's first level runs wide
 
 template <int VEC, int G, int R>
@@ -1088,6 +1090,79 @@ __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, in
     }
 }
 
+// The same finalize for split rows whose candidates fit one wave-level selection
+// ((tasks) * k <= 128, i.e. deg <= 8 * CHUNK at k = 16): one WAVE per row, no workgroup
+// barrier, 4 rows per workgroup.  On graphs with many moderately large rows
+// (products-like: ~10^5 split rows) the 1024-thread tournament above is mostly idle.
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int first, int count)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    __shared__ unsigned long long s_key[WAVES][CAND_MAX_K];
+    __shared__ int s_src[WAVES][CAND_MAX_K];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int q = blockIdx.x * WAVES + wave;
+    if (q >= count) return;                                   // wave-uniform
+    const int p = first + q;
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    if (a.k < 0) {
+        for (int c = lane; c < a.C; c += 64) {
+            float s = 0.f;
+            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+            a.out[(size_t)i * a.C + c] = s / (float)deg;
+        }
+        return;
+    }
+    const bool emit = a.sel_src != nullptr;
+    const int n = (t1 - t0) * a.k;                            // <= 128 by the launch split
+    const size_t c0 = (size_t)t0 * a.k;
+    const unsigned long long key0 = lane < n ? a.cand_key[c0 + lane] : 0ull;
+    const unsigned long long key1 = lane + 64 < n ? a.cand_key[c0 + lane + 64] : 0ull;
+    const int src0 = lane < n ? a.cand_src[c0 + lane] : 0;
+    const int src1 = lane + 64 < n ? a.cand_src[c0 + lane + 64] : 0;
+    bool k0, k1;
+    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
+    if (k0) { const int o = prefix_popc(m0); s_key[wave][o] = key0; s_src[wave][o] = src0; }
+    if (k1) { const int o = n0 + prefix_popc(m1); s_key[wave][o] = key1; s_src[wave][o] = src1; }
+    wave_lds_sync();
+    RowT acc;
+    acc.zero();
+    constexpr int GU = R >= 4 ? 2 : 4;                        // winner rows in flight per lane group
+    for (int w0 = 0; w0 < nsel; w0 += GU * NG) {
+        RowT x[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int w = w0 + u * NG + gid;
+            if (w < nsel) x[u].load(a.h + (size_t)s_src[wave][w] * a.C, a.C, lg);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int w = w0 + u * NG + gid;
+            if (w < nsel) acc.axpy(key_score(s_key[wave][w]), x[u]);
+        }
+    }
+    if (lane < nsel) {
+        const unsigned long long kq = s_key[wave][lane];
+        const float sq = key_score(kq);
+        if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
+        if (emit) {
+            int rk = 0;
+            for (int r = 0; r < nsel; ++r) rk += s_key[wave][r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = s_src[wave][lane];
+            a.sel_w[(size_t)i * a.k + rk] = sq;
+        }
+    }
+    acc.reduce_across_groups();
+    acc.div((float)deg);
+    if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
+}
+
 template <int VEC, int G, int R>
 int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
@@ -1114,7 +1189,15 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        k_agg_fin_cand<VEC, G, R><<<a.n_split, FINC_BLOCK, dyn, st>>>(a, max_slots);
+        // rows are in descending degree order: the first n_big need the workgroup tournament,
+        // the rest fit one wave-level selection
+        // (a second launch only pays when there are many such rows: arxiv-like graphs have a
+        // few hundred split rows in all, products-like ones 10^5)
+        const int n_wave = a.n_split - std::min(a.n_split, a.n_split_gt_wave);
+        const int n_big = (a.k > 0 && n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - n_wave : (a.k > 0 ? a.n_split : 0);
+        if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
+        if (a.n_split > n_big)
+            k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
     } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)(a.k < 0 ? 0 : a.k) * 4;
         const size_t budget = 120 * 1024;

@@ -94,3 +94,33 @@ def test_saved_weights_match_oracle(cuda):
     ref_sel[ref["sel_pos"][ref["sel_pos"] >= 0]] = True
     assert torch.equal(sel, ref_sel)
     assert_close(w_list[sel], ref["s"][sel], what="wsel", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,thr,C", [(16, 0.0, 40), (5, 0.1, 7), (32, -0.5, 64)])
+def test_many_moderate_split_rows(cuda, k, thr, C):
+    """Products-like degree profile: thousands of rows just above the wave-row limit plus a
+    few very large hubs, so the split-row finalize runs BOTH its forms (one wave per row for
+    rows whose candidates fit one selection, the workgroup tournament for the hubs);
+    compared with the C oracle (selection exact up to the near-tie rule of tests/helpers.py:
+    with ~10^6 random cosines a pair one ulp apart does occur)."""
+    from oracle import c_oracle as CO
+    n = 6000
+    rng = np.random.default_rng(11)
+    hubs = [(int(v), int(d)) for v, d in zip(range(0, 2300), rng.integers(129, 700, size=2300))]
+    hubs += [(2300, 5000), (2301, 3000), (2302, 1100)]
+    ei = random_graph(n, 20000, seed=5, hubs=hubs)
+    h = torch.randn(n, C, generator=torch.Generator().manual_seed(3))
+    ref = CO.aggregate(h.numpy(), ei.numpy(), add_loops=True, remove_loops=True, top_k=k, thr=thr)
+    g, out, wsel, inv, sel_src, sel_w = run_gpu(cuda, h, ei, True, True, k, thr)
+    assert g.num_edges == ref["ei"].shape[1]
+    assert_close(out, torch.from_numpy(ref["out"]))
+    res = dict(sel_src=torch.from_numpy(ref["sel_src"]), ei=torch.from_numpy(ref["ei"]),
+               s=torch.from_numpy(ref["s"]))
+    assert check_selection(res, sel_src, sel_w, k, thr, strict=False) <= 3
+    # training-mode bookkeeping of the same rows: kept cosines land on the kept edges
+    eid = torch.from_numpy(g.array("eid").astype(np.int64))
+    w_list = torch.empty(g.num_edges)
+    w_list[eid] = wsel.cpu()
+    kept = torch.from_numpy(ref["weight"] != 0) if "weight" in ref else None
+    if kept is not None:
+        assert torch.equal(w_list > -3.0, kept | ((w_list > -3.0) & (torch.from_numpy(ref["s"]) == 0)))
