@@ -92,3 +92,47 @@ def select_split(data: Data, part_id: int) -> Data:
         if kw.get(k) is not None and kw[k].dim() == 2:
             kw[k] = kw[k][part_id]
     return Data(**kw)
+
+
+def _read_csv_gz(path: str, dtype):
+    import gzip
+    with gzip.open(path, "rt") as f:
+        return np.loadtxt(f, delimiter=",", dtype=dtype, ndmin=2)
+
+
+def load_ogb_raw(root: str, split: Optional[str] = None) -> Data:
+    """The on-disk layout ``ogb.nodeproppred.NodePropPredDataset`` unpacks - what
+    ``load_ogb_dataset`` reads through that package (datasets/largescale_datasets.py:804-819;
+    ogb is not vendored, the layout is its published one):
+        <root>/raw/edge.csv.gz          "src,dst" per line (directed, as stored)
+        <root>/raw/node-feat.csv.gz     one feature row per node
+        <root>/raw/node-label.csv.gz    one label per node
+        <root>/raw/num-node-list.csv.gz the node count
+        <root>/split/<type>/{train,valid,test}.csv.gz   node indices
+    The edge list is returned exactly as stored: the reference does not symmetrise it
+    (SURVEY.md 8, config 4).  ``split`` names the split directory (default: the only one).
+    """
+    raw = os.path.join(root, "raw")
+    ei = _read_csv_gz(os.path.join(raw, "edge.csv.gz"), np.int64).T
+    x = _read_csv_gz(os.path.join(raw, "node-feat.csv.gz"), np.float32)
+    y = _read_csv_gz(os.path.join(raw, "node-label.csv.gz"), np.int64).reshape(-1)
+    nfile = os.path.join(raw, "num-node-list.csv.gz")
+    n = int(_read_csv_gz(nfile, np.int64)[0, 0]) if os.path.exists(nfile) else x.shape[0]
+    if x.shape[0] != n or y.shape[0] != n:
+        raise ValueError(f"node-feat / node-label rows ({x.shape[0]}, {y.shape[0]}) != num nodes {n}")
+    if ei.size and (ei.min() < 0 or ei.max() >= n):
+        raise ValueError("edge.csv.gz names a node outside [0, num_nodes)")
+    data = Data(x=torch.from_numpy(x), edge_index=torch.from_numpy(np.ascontiguousarray(ei)),
+                y=torch.from_numpy(y))
+    sroot = os.path.join(root, "split")
+    if os.path.isdir(sroot):
+        kinds = sorted(os.listdir(sroot))
+        kind = split if split is not None else (kinds[0] if len(kinds) == 1 else None)
+        if kind is None:
+            raise ValueError(f"several splits {kinds}: pass split=")
+        for fname, attr in (("train", "train_mask"), ("valid", "val_mask"), ("test", "test_mask")):
+            idx = _read_csv_gz(os.path.join(sroot, kind, fname + ".csv.gz"), np.int64).reshape(-1)
+            mask = torch.zeros(n, dtype=torch.bool)
+            mask[torch.from_numpy(idx)] = True
+            setattr(data, attr, mask)
+    return data

@@ -167,3 +167,40 @@ def test_actor_fixture_statistics():
         d = DS.load_geom_gcn(raw, "film")
         assert np.array_equal(d.edge_index.numpy(), ei) and d.x.shape == (n, f)
         assert np.array_equal(d.y.numpy(), z["y"].astype(np.int64))
+
+
+def test_ogb_raw_layout_loader(tmp_path):
+    """largescale_datasets.py:804-819 without the ogb package: the published raw layout."""
+    import gzip
+    from sngnn_amd import datasets as DS
+    rng = np.random.default_rng(0)
+    n, e, f = 50, 200, 6
+    ei = rng.integers(0, n, size=(e, 2))
+    x = rng.normal(size=(n, f)).astype(np.float32)
+    y = rng.integers(0, 4, size=n)
+    perm = rng.permutation(n)
+    root = tmp_path / "ogbn_toy"
+    (root / "raw").mkdir(parents=True)
+    (root / "split" / "time").mkdir(parents=True)
+
+    def dump(path, arr, fmt):
+        with gzip.open(path, "wt") as fh:
+            np.savetxt(fh, arr, delimiter=",", fmt=fmt)
+    dump(root / "raw" / "edge.csv.gz", ei, "%d")
+    dump(root / "raw" / "node-feat.csv.gz", x, "%.9g")
+    dump(root / "raw" / "node-label.csv.gz", y.reshape(-1, 1), "%d")
+    dump(root / "raw" / "num-node-list.csv.gz", np.array([[n]]), "%d")
+    for name, idx in (("train", perm[:30]), ("valid", perm[30:40]), ("test", perm[40:])):
+        dump(root / "split" / "time" / f"{name}.csv.gz", idx.reshape(-1, 1), "%d")
+    d = DS.load_ogb_raw(str(root))
+    assert d.edge_index.dtype == torch.int64 and d.edge_index.shape == (2, e)
+    assert np.array_equal(d.edge_index.numpy(), ei.T)              # stored order, not symmetrised
+    assert np.array_equal(d.x.numpy(), x) and np.array_equal(d.y.numpy(), y)
+    assert int(d.train_mask.sum()) == 30 and int(d.val_mask.sum()) == 10 and int(d.test_mask.sum()) == 10
+    assert not (d.train_mask & d.val_mask).any() and not (d.train_mask & d.test_mask).any()
+    assert set(torch.nonzero(d.test_mask).flatten().tolist()) == set(perm[40:].tolist())
+    bad = ei.copy()
+    bad[0, 0] = n
+    dump(root / "raw" / "edge.csv.gz", bad, "%d")
+    with pytest.raises(ValueError):
+        DS.load_ogb_raw(str(root))
