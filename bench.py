@@ -100,6 +100,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # SNGNN_BENCH_REHEARSAL=1: the multi-rank code path on however many GPUs there are
+    # (ranks share devices, collectives over gloo) - a functional rehearsal for boxes with
+    # fewer GPUs than ranks; the numbers it prints mean nothing.
+    rehearsal = os.environ.get("SNGNN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -112,7 +118,10 @@ def main():
     part = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device,
                                                  args.channels, args.scale)

@@ -56,9 +56,10 @@ def current_partition() -> Optional[Partition]:
     return _current
 
 
-def _use_fallback(t: torch.Tensor) -> bool:
-    # gloo (CPU tests) lacks reduce_scatter / all_gather_into_tensor on some builds
-    return not t.is_cuda
+def _use_fallback(t: torch.Tensor, group=None) -> bool:
+    # gloo (CPU tests, and multi-rank rehearsals on a box with fewer GPUs than ranks) has no
+    # reduce_scatter: list all-gather + all-reduce instead
+    return (not t.is_cuda) or dist.get_backend(group) == "gloo"
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -67,7 +68,7 @@ class _AllGatherRows(torch.autograd.Function):
         ctx.part = part
         h_local = h_local.contiguous()
         full = h_local.new_empty((part.n_total, h_local.size(1)))
-        if _use_fallback(h_local):
+        if _use_fallback(h_local, part.group):
             chunks = list(full.chunk(part.world, dim=0))
             dist.all_gather(chunks, h_local, group=part.group)
         else:
@@ -78,7 +79,7 @@ class _AllGatherRows(torch.autograd.Function):
     def backward(ctx, grad_full):
         part = ctx.part
         grad_full = grad_full.contiguous()
-        if _use_fallback(grad_full):
+        if _use_fallback(grad_full, part.group):
             dist.all_reduce(grad_full, group=part.group)
             return grad_full[part.row_begin:part.row_end].clone(), None
         out = grad_full.new_empty((part.n_local, grad_full.size(1)))
