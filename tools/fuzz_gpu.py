@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised parity run (not part of the test suite): random graphs (sizes, hubs, self-loop
+modes, partitions), channel counts, top_k / thr regimes through forward + backward of the
+aggregation and of the attention mode, against the oracle.  Stops at the first failure and
+prints the seed.  usage: fuzz_gpu.py [seconds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import sngnn_oracle as O  # noqa: E402
+from sngnn_amd import ops  # noqa: E402
+from sngnn_amd.graph import Graph, LOOPS_REPLACE  # noqa: E402
+from tests.helpers import check_selection, random_graph  # noqa: E402
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t_end = time.time() + budget
+n_cases = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 900))
+    e = int(rng.integers(0, 12 * n))
+    C = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 31, 32, 40, 47, 48, 64, 65, 96, 128, 200, 256, 257, 512]))
+    nh = int(rng.integers(0, 5))
+    hubs = tuple((int(rng.integers(0, n)), int(rng.integers(1, n + 1))) for _ in range(nh))
+    k = rng.choice([None, 0, 1, 2, 3, 8, 16, 31, 32, 33, 50, 129, 1000])
+    k = None if k is None else int(k)
+    thr = float(rng.choice([-1.5, -0.3, 0.0, 0.2, 0.9]))     # (thr <= -2 with an empty row raises in the reference itself)
+    rem = bool(rng.integers(0, 2))
+    ei = random_graph(n, e, seed=seed, hubs=hubs) if e > 0 or hubs else torch.zeros((2, 0), dtype=torch.int64)
+    if rng.integers(0, 2):
+        loops = torch.from_numpy(rng.integers(0, n, size=max(1, n // 7)))
+        ei = torch.unique(torch.cat([ei, torch.stack([loops, loops])], 1), dim=1)
+    gen = torch.Generator().manual_seed(seed)
+    h = torch.randn(n, C, generator=gen)
+    if n > 3:
+        h[1] = h[2]
+        if rng.integers(0, 3) == 0:
+            h[0] = 0.0
+    gout = torch.randn(n, C, generator=gen)
+    tag = f"seed={seed} n={n} e={ei.size(1)} C={C} hubs={hubs} k={k} thr={thr} rem={rem}"
+    try:
+        # --- aggregation
+        hr = h.clone().requires_grad_(True)
+        ref = O.aggregate_reference(hr, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+        (ref["out"] * gout).sum().backward()
+        g = Graph(ei.to(dev), n, True, rem)
+        hg = h.to(dev).requires_grad_(True)
+        out = ops.aggregate(hg, g, k, thr)
+        (out * gout.to(dev)).sum().backward()
+        near = 0
+        if k:
+            _, _, _, ss, sw = ops.aggregate_forward(g, hg.detach(), k, thr, want_selection=True)
+            near = check_selection(ref, ss, sw, k, thr, strict=False)
+        if near == 0 and C > 1:
+            err = (out.detach().cpu() - ref["out"]).abs()
+            assert (err <= 4e-6 + 2e-5 * ref["out"].abs()).all(), f"out err {err.max():.3e}"
+            sc = hr.grad.abs().max().clamp_min(1e-20)
+            ge = (hg.grad.cpu() - hr.grad).abs().max()
+            assert ge <= 5e-5 * sc, f"grad err {ge:.3e} scale {sc:.3e}"
+        # --- partition of the same graph (two ranges) equals the whole
+        if n >= 4:
+            cut = int(rng.integers(1, n))
+            outs = []
+            for r0, r1 in ((0, cut), (cut, n)):
+                gp = Graph(ei.to(dev), n, True, rem, row_range=(r0, r1))
+                outs.append(ops.aggregate_forward(gp, hg.detach(), k, thr)[0])
+            assert torch.equal(torch.cat(outs), out.detach()), "partition != whole"
+        # --- attention mode
+        hr2 = h.clone().requires_grad_(True)
+        ra = O.attention_reference(hr2, ei)
+        (ra["out"] * gout).sum().backward()
+        ga = Graph(ei.to(dev), n, True, LOOPS_REPLACE)
+        ha = h.to(dev).requires_grad_(True)
+        oa = ops.attention(ha, ga)
+        (oa * gout.to(dev)).sum().backward()
+        err = (oa.detach().cpu() - ra["out"]).abs()
+        assert (err <= 4e-6 + 2e-5 * ra["out"].abs()).all(), f"attn out err {err.max():.3e}"
+        if C > 1:      # C == 1: d cos / d h is exactly 0; what is left is rounding noise / |h|
+            sc = hr2.grad.abs().max().clamp_min(1e-20)
+            ge = (ha.grad.cpu() - hr2.grad).abs().max()
+            assert ge <= 5e-5 * sc, f"attn grad err {ge:.3e} scale {sc:.3e}"
+    except Exception as ex:      # noqa: BLE001
+        print("FAIL", tag, "->", repr(ex)[:500], flush=True)
+        sys.exit(1)
+    n_cases += 1
+    seed += 1
+    if n_cases % 50 == 0:
+        print(f"{n_cases} cases ok (last {tag})", flush=True)
+print(f"done: {n_cases} random cases passed, next seed {seed}")

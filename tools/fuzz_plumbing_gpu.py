@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Randomised check (not part of the suite) of the kernels around the aggregation: self.lin
+forward / weight gradient (MFMA paths and fallbacks), the fused head and the blend, on random
+shapes against PyTorch.  usage: fuzz_plumbing_gpu.py [seconds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sngnn_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+cases = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 15, 16, 17, 63, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 5000, 16384, 30001]))
+    if rng.integers(0, 2):
+        n = int(rng.integers(1, 40000))
+    f = int(rng.choice([16, 32, 64, 128, 1, 7, 33, 100, 129, 300]))
+    c = int(rng.integers(1, 65)) if rng.integers(0, 4) else int(rng.choice([65, 70, 128]))
+    tag = f"seed={seed} n={n} f={f} c={c}"
+    try:
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(n, f, generator=gen).to(dev)
+        lin = torch.nn.Linear(f, c).to(dev)
+        gout = torch.randn(n, c, generator=gen).to(dev)
+        ref = lin(x)
+        (ref * gout).sum().backward()
+        gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+        lin.zero_grad()
+        out = ops.linear(x, lin)
+        (out * gout).sum().backward()
+        assert (out - ref).abs().max() <= 3e-6 * max(1.0, float(ref.abs().max())), "linear forward"
+        # sums over n rows of signed terms: judged against fp64 and the size of the terms
+        gd, xd = gout.double(), x.double()
+        tol_w = 2e-6 * (gd.abs().t() @ xd.abs()) + 1e-7
+        assert ((lin.weight.grad.double() - gd.t() @ xd).abs() <= tol_w).all(), "wgrad"
+        assert ((lin.bias.grad.double() - gd.sum(0)).abs() <= 2e-6 * gd.abs().sum(0) + 1e-7).all(), "bias grad"
+        # head
+        z = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
+        y = torch.randint(0, c, (n,), generator=gen).to(dev)
+        mask = (torch.rand(n, generator=gen) < 0.6).to(dev)
+        if int(mask.sum()) > 0:
+            lref = F.nll_loss(F.log_softmax(z, 1)[mask], y[mask])
+            lref.backward()
+            gz = z.grad.clone()
+            z.grad = None
+            loss, corr = ops.head_nll(z, y, mask.to(torch.uint8), int(mask.sum()))
+            loss.backward()
+            assert abs(float(loss) - float(lref)) <= 3e-6 * max(1.0, abs(float(lref))), "head loss"
+            assert int(corr) == int((z.detach()[mask].max(1)[1] == y[mask]).sum()), "head accuracy"
+            assert (z.grad - gz).abs().max() <= 2e-6 * max(1e-3, float(gz.abs().max())) + 1e-9, "head grad"
+        # blend
+        o0 = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
+        o1 = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
+        beta = torch.tensor([float(rng.uniform(-0.5, 1.5))], device=dev, requires_grad=True)
+        rb = beta * o0 + (1 - beta) * o1
+        rb.backward(gout)
+        want = (rb.detach().clone(), o0.grad.clone(), o1.grad.clone(), float(beta.grad))
+        o0.grad = o1.grad = beta.grad = None
+        ob = ops.blend(o0, o1, beta)
+        ob.backward(gout)
+        assert torch.equal(ob, want[0]) and torch.equal(o0.grad, want[1]) and torch.equal(o1.grad, want[2]), "blend"
+        # d beta is a sum of n*c signed terms: judge it against the fp64 value and the terms' size
+        terms = gout.double() * (o0.detach().double() - o1.detach().double())
+        assert abs(float(beta.grad) - float(terms.sum())) <= 2e-6 * float(terms.abs().sum()) + 1e-6, "blend dbeta"
+    except Exception as ex:      # noqa: BLE001
+        print("FAIL", tag, "->", repr(ex)[:400], flush=True)
+        sys.exit(1)
+    cases += 1
+    seed += 1
+    if cases % 100 == 0:
+        print(f"{cases} cases ok (last {tag})", flush=True)
+print(f"done: {cases} random cases passed, next seed {seed}")
