@@ -85,6 +85,24 @@ while time.time() < t_end:
             sc = hr2.grad.abs().max().clamp_min(1e-20)
             ge = (ha.grad.cpu() - hr2.grad).abs().max()
             assert ge <= 5e-5 * sc, f"attn grad err {ge:.3e} scale {sc:.3e}"
+        # --- SNGNN++ adjacency branch (models.py:124-130) on the same edge list
+        eip = O.sn_edge_list(ei, n, True, rem)
+        if eip.size(1) > 0 and C <= 64:
+            W = torch.randn(C, n, generator=gen).requires_grad_(True)
+            bW = torch.randn(C, generator=gen).requires_grad_(True)
+            r0 = O.adj_linear_reference(W, bW, eip, n)
+            (r0 * gout).sum().backward()
+            Wg = torch.nn.Parameter(W.detach().to(dev).t().contiguous().t())      # column-major, as the layer keeps it
+            bg = bW.detach().to(dev).requires_grad_(True)
+            o0 = ops.adj_linear(Wg, bg, g)
+            (o0 * gout.to(dev)).sum().backward()
+            err = (o0.detach().cpu() - r0.detach()).abs()
+            assert (err <= 1e-5 + 2e-5 * r0.detach().abs()).all(), f"adj out err {err.max():.3e}"
+            ge = (Wg.grad.cpu() - W.grad).abs().max()
+            assert ge <= 3e-5 * W.grad.abs().max().clamp_min(1e-6), f"adj dW err {ge:.3e}"
+            # db is a signed sum over all rows: fp64 truth, tolerance from the terms' size
+            ge = (bg.grad.cpu().double() - gout.double().sum(0)).abs()
+            assert (ge <= 2e-6 * gout.double().abs().sum(0) + 1e-7).all(), f"adj db err {ge.max():.3e}"
     except Exception as ex:      # noqa: BLE001
         print("FAIL", tag, "->", repr(ex)[:500], flush=True)
         sys.exit(1)
