@@ -235,3 +235,14 @@ def class_similarity_sparse(x, y, device=None):
     sums = onehot.t() @ sim.double() @ onehot
     cnt = onehot.sum(0)
     return (sums / (cnt[:, None] * cnt[None, :])).to(torch.float32)
+
+
+def edge_index_to_sparse_csc_tensor(x, edge_index):
+    """SimGFAToolbox/utils.py:5-11: the [N, N] adjacency (ones; duplicates add up) as a
+    scipy CSC matrix, N = len(x) - the input ``toolbox-example.py`` hands to the
+    ``*_sparse`` functions.  Host code, as in the reference."""
+    import numpy as np
+    from scipy import sparse as sp
+    n = len(x)
+    ei = edge_index.detach().cpu().numpy()
+    return sp.csc_matrix((np.full(ei.shape[1], 1), (ei[0], ei[1])), shape=(n, n))
