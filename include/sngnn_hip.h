@@ -299,6 +299,20 @@ int sngnn_edge_cosine(const float *x, int64_t N, int64_t F,
                       const int64_t *edge_index_dev, int64_t E, float *sim,
                       void *stream);
 
+/*
+ * kNN similarity graph (the north star's "Node-Similarity build"):
+ * for every node the k most cosine-similar nodes, without storing the N x N similarity
+ * the reference materialises (dense.py:138-141) - tiled exact-fp32 MFMA with a fused
+ * per-row top-k.  Order (cosine desc, node id asc), k <= 32.
+ *   nbr_idx dev i32 [N, k]   neighbour ids in rank order, -1 padded when N - 1 < k
+ *   nbr_sim dev f32 [N, k]   their cosines (0 padded)
+ *   exclude_self             a node is not its own neighbour
+ *   workspace: sngnn_knn_workspace_bytes(N, k)
+ */
+int64_t sngnn_knn_workspace_bytes(int64_t N, int k);
+int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int exclude_self,
+                    int32_t *nbr_idx, float *nbr_sim, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

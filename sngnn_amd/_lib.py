@@ -42,6 +42,8 @@ SIGNATURES = {
     "sngnn_blend_workspace_bytes": (_i64, []),
     "sngnn_blend_forward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sngnn_blend_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_knn_workspace_bytes": (_i64, [_i64, _i32]),
+    "sngnn_knn_graph": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),

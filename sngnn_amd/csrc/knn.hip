@@ -1,0 +1,327 @@
+// kNN similarity-graph builder (gfx950): for every node the k most cosine-similar
+// nodes, straight from the feature table - the N x N similarity is never stored.
+// the producer of edges for the aggregation kernel (the
+// "Node-Similarity build" of the north star; the reference only ever materialises S,
+// SimGFAToolbox/dense.py:138-141, and has no graph builder).
+//
+// Workgroup = 4 waves = 128 rows; it walks ALL column tiles of 128 nodes.  A tile
+// S[128 x 128] = diag(inv) X_rows X_cols^T diag(inv) comes from exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) like sngnn_cosine_dense; each WAVE owns 32 whole rows of it
+// (1 x 4 blocks of 32 x 32), so a row's 128 new similarities sit in one half-wave and
+// its running top-k list (LDS, k 64-bit keys) is private to the wave: no atomics, no
+// workgroup barrier in the selection.  A similarity only enters the selection when it
+// beats the row's current k-th key (one ballot per accumulator register); after the
+// first few tiles that is rare (~k ln(N/k) times per row in total), so the epilogue
+// costs a fraction of the MFMA time.
+//
+// Order: (cosine descending, node id ascending) - the aggregation's tie rule; a node is
+// never its own neighbour when exclude_self is set.
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace sngnn {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int KN_M = 128, KN_K = 32, KN_LD = KN_K + 1, KN_LOADS = KN_M * KN_K / 256;
+constexpr int KNN_MAX_K = 32;
+
+// k-th largest of the (unique, non-zero) keys held two per lane; at least k keys are set
+__device__ __forceinline__ unsigned long long kth_largest(unsigned long long key0, unsigned long long key1, int k)
+{
+    unsigned long long T = 0;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long cand = T | (1ull << b);
+        const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
+        if (c >= k) T = cand;
+    }
+    return T;
+}
+
+// Merge the row's list (k slots, 0 = empty) with cnt candidates (cnt + k <= 128); returns
+// the row's new threshold key (k-th largest, or 0 while the list is not full).
+__device__ __forceinline__ unsigned long long merge_row(unsigned long long *list, const unsigned long long *cand,
+                                                        int cnt, int k)
+{
+    const int lane = lane_id();
+    const int q0 = lane, q1 = lane + 64;
+    auto pick = [&](int q) -> unsigned long long {
+        return q < k ? list[q] : (q - k < cnt ? cand[q - k] : 0ull);
+    };
+    const unsigned long long key0 = pick(q0), key1 = pick(q1);
+    const int total = __popcll(__ballot(key0 != 0ull)) + __popcll(__ballot(key1 != 0ull));
+    unsigned long long T = 0ull;
+    if (total >= k) T = kth_largest(key0, key1, k);
+    const bool k0 = key0 != 0ull && key0 >= T, k1 = key1 != 0ull && key1 >= T;
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+    wave_lds_sync();                       // every lane has read the old list
+    if (k0) list[prefix_popc(m0)] = key0;
+    if (k1) list[n0 + prefix_popc(m1)] = key1;
+    if (lane >= ns && lane < k) list[lane] = 0ull;
+    wave_lds_sync();
+    return T;
+}
+
+// blockIdx.y = column split: this workgroup covers column tiles [y * tiles_per_split, ...) and
+// writes its lists as KEYS to part[y][N][k] (nsplit > 1) or the final idx / sim (nsplit == 1).
+__global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, int64_t N, int64_t F,
+                                                  const float *__restrict__ inv, int k, int exclude_self,
+                                                  int tiles_per_split, unsigned long long *__restrict__ part,
+                                                  int32_t *__restrict__ out_idx, float *__restrict__ out_sim)
+{
+    __shared__ float sA[KN_M * KN_LD];
+    __shared__ float sB[KN_M * KN_LD];
+    __shared__ unsigned long long s_list[4][32][KNN_MAX_K];     // running top-k keys per row
+    __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
+    __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
+    __shared__ unsigned long long s_cand[4][2][128];            // candidates of the two rows of a register
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * KN_M;
+    for (int q = lane; q < 32 * KNN_MAX_K; q += 64) s_list[wave][q / KNN_MAX_K][q % KNN_MAX_K] = 0ull;
+    if (lane < 32) { s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; }
+    const int sc = tid & 31, sr = tid >> 5;
+    const int64_t ncol_tiles = (N + KN_M - 1) / KN_M;
+    const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_split;
+    const int64_t ct_end = min(ncol_tiles, ct_begin + tiles_per_split);
+
+    for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
+        const int64_t col0 = ct * KN_M;
+        f32x16 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        float ra[KN_LOADS], rb[KN_LOADS];
+        auto fetch = [&](int64_t k0) {
+            const int64_t kk = k0 + sc;
+#pragma unroll
+            for (int u = 0; u < KN_LOADS; ++u) {
+                const int64_t r_a = row0 + sr + 8 * u, r_b = col0 + sr + 8 * u;
+                ra[u] = (r_a < N && kk < F) ? x[r_a * F + kk] : 0.f;
+                rb[u] = (r_b < N && kk < F) ? x[r_b * F + kk] : 0.f;
+            }
+        };
+        fetch(0);
+        for (int64_t k0 = 0; k0 < F; k0 += KN_K) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < KN_LOADS; ++u) {
+                sA[(sr + 8 * u) * KN_LD + sc] = ra[u];
+                sB[(sr + 8 * u) * KN_LD + sc] = rb[u];
+            }
+            __syncthreads();
+            if (k0 + KN_K < F) fetch(k0 + KN_K);
+#pragma unroll
+            for (int kk = 0; kk < KN_K; kk += 2) {
+                // 32x32x2: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
+                const float a = sA[(wave * 32 + l32) * KN_LD + kk + half];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float bv = sB[(b * 32 + l32) * KN_LD + kk + half];
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[b], 0, 0, 0);
+                }
+            }
+        }
+        // ---- selection: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        float icol[4];
+        int64_t jcol[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            jcol[b] = col0 + b * 32 + l32;
+            icol[b] = jcol[b] < N ? inv[jcol[b]] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;          // this lane's row within the wave's 32
+            const int64_t i = row0 + wave * 32 + lr;
+            const float irow = i < N ? inv[i] : 0.f;
+            // fast reject on the cosine alone: nothing of this register reaches its row's
+            // k-th value - the common case once the lists have warmed up
+            const float thrf = s_thrf[wave][lr];
+            float sv[4];
+            bool maybe = false;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                sv[b] = acc[b][r] * (irow * icol[b]) + 0.0f;
+                maybe |= sv[b] >= thrf;
+            }
+            if (__ballot(maybe) == 0ull) continue;
+            const unsigned long long thr = s_thr[wave][lr];
+            unsigned long long key[4];
+            bool any = false;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool ok = i < N && jcol[b] < N && !(exclude_self && jcol[b] == i);
+                key[b] = ok ? sel_key(sv[b], (unsigned)jcol[b]) : 0ull;
+                if (key[b] <= thr) key[b] = 0ull;                        // cannot enter the list
+                any |= key[b] != 0ull;
+            }
+            const unsigned long long hot = __ballot(any);
+            if (hot == 0ull) continue;
+            // compact the candidates of the two rows (one per half-wave) into LDS
+            int cnt = 0;                                                 // per half
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned long long m = __ballot(key[b] != 0ull);
+                const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
+                if (key[b] != 0ull) s_cand[wave][half][cnt + __popc(mh & ((1u << l32) - 1u))] = key[b];
+                cnt += __popc(mh);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int c = __builtin_amdgcn_readlane(cnt, h * 32);
+                if (c == 0) continue;
+                const int rowh = (r & 3) + 8 * (r >> 2) + 4 * h;
+                unsigned long long *cand = s_cand[wave][h];
+                if (c + k > 128) {
+                    // too many for one merge (first tiles only): keep the best k candidates
+                    const unsigned long long c0 = lane < c ? cand[lane] : 0ull, c1 = lane + 64 < c ? cand[lane + 64] : 0ull;
+                    const unsigned long long T = kth_largest(c0, c1, k);
+                    const bool k0 = c0 != 0ull && c0 >= T, k1 = c1 != 0ull && c1 >= T;
+                    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+                    wave_lds_sync();
+                    if (k0) cand[prefix_popc(m0)] = c0;
+                    if (k1) cand[__popcll(m0) + prefix_popc(m1)] = c1;
+                    wave_lds_sync();
+                    c = k;
+                }
+                const unsigned long long T = merge_row(s_list[wave][rowh], cand, c, k);
+                if (lane == 0) {
+                    s_thr[wave][rowh] = T;
+                    const unsigned u = (unsigned)(T >> 32);
+                    s_thrf[wave][rowh] = T ? __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) : -INFINITY;
+                }
+            }
+            wave_lds_sync();
+        }
+    }
+    // ---- output: the lists in rank order, or as keys for the merge of the column splits
+    wave_lds_sync();
+    for (int lr = 0; lr < 32; ++lr) {
+        const int64_t i = row0 + wave * 32 + lr;
+        if (i >= N) break;
+        const unsigned long long *list = s_list[wave][lr];
+        if (part != nullptr) {
+            if (lane < k) part[((size_t)blockIdx.y * N + i) * k + lane] = list[lane];
+            continue;
+        }
+        if (lane < k) {
+            const unsigned long long kq = list[lane];
+            int rk = 0, n = 0;
+            for (int q = 0; q < k; ++q) {
+                const unsigned long long o = list[q];
+                rk += o > kq;
+                n += o != 0ull;
+            }
+            if (kq != 0ull) {
+                const unsigned u = (unsigned)(kq >> 32);
+                out_idx[i * k + rk] = (int32_t)(0xFFFFFFFFu - (unsigned)kq);
+                out_sim[i * k + rk] = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+            }
+            if (lane >= n) {               // fewer than k eligible nodes: pad
+                out_idx[i * k + lane] = -1;
+                out_sim[i * k + lane] = 0.f;
+            }
+        }
+    }
+}
+
+// top-k of the column splits' lists of one row (nsplit * k keys, 128 at a time)
+__global__ __launch_bounds__(256) void k_knn_merge(const unsigned long long *__restrict__ part, int64_t N,
+                                                   int k, int nsplit, int32_t *__restrict__ out_idx,
+                                                   float *__restrict__ out_sim)
+{
+    __shared__ unsigned long long s_list[4][KNN_MAX_K];
+    __shared__ unsigned long long s_cand[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= N) return;                                   // wave-uniform
+    if (lane < KNN_MAX_K) s_list[wave][lane] = 0ull;
+    wave_lds_sync();
+    const int per = (128 - k) / k;                        // splits merged per round
+    for (int s0 = 0; s0 < nsplit; s0 += per) {
+        const int ns = min(per, nsplit - s0), cnt = ns * k;
+        for (int q = lane; q < cnt; q += 64)
+            s_cand[wave][q] = part[((size_t)(s0 + q / k) * N + i) * k + q % k];
+        wave_lds_sync();
+        merge_row(s_list[wave], s_cand[wave], cnt, k);    // (zero keys of short lists are ignored)
+    }
+    const unsigned long long *list = s_list[wave];
+    if (lane < k) {
+        const unsigned long long kq = list[lane];
+        int rk = 0, n = 0;
+        for (int q = 0; q < k; ++q) {
+            const unsigned long long o = list[q];
+            rk += o > kq;
+            n += o != 0ull;
+        }
+        if (kq != 0ull) {
+            const unsigned u = (unsigned)(kq >> 32);
+            out_idx[i * k + rk] = (int32_t)(0xFFFFFFFFu - (unsigned)kq);
+            out_sim[i * k + rk] = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+        }
+        if (lane >= n) {
+            out_idx[i * k + lane] = -1;
+            out_sim[i * k + lane] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn_inv_norm(const float *__restrict__ x, int64_t N, int64_t F,
+                                                      float *__restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const float *p = x + row * F;
+    float ss = 0.f;
+    for (int64_t c = lane; c < F; c += 64) ss = fmaf(p[c], p[c], ss);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(ss), EPS_NORM);
+}
+
+}  // namespace sngnn
+
+using namespace sngnn;
+
+// column splits: enough workgroups to fill the chip when there are few row blocks
+static int knn_splits(int64_t N)
+{
+    const int64_t nrb = (N + KN_M - 1) / KN_M;
+    // (every split warms its lists up from empty: only as many as it takes to occupy the CUs)
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nrb, (320 + nrb - 1) / nrb));
+}
+
+extern "C" int64_t sngnn_knn_workspace_bytes(int64_t N, int k)
+{
+    const int ns = knn_splits(N);
+    return (N + 63) / 64 * 256 + (ns > 1 ? (int64_t)ns * N * k * 8 : 0) + 256;
+}
+
+extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int exclude_self,
+                               int32_t *nbr_idx, float *nbr_sim, void *workspace, void *stream)
+{
+    SN_REQUIRE(N >= 0 && F >= 1, SNGNN_EINVAL, "bad shape");
+    SN_REQUIRE(k >= 1 && k <= KNN_MAX_K, SNGNN_EINVAL, "k must be in [1, " + std::to_string(KNN_MAX_K) + "]");
+    SN_REQUIRE(N < ((int64_t)1 << 31), SNGNN_EINVAL, "too many rows");
+    if (N == 0) return SNGNN_OK;
+    SN_REQUIRE(x && nbr_idx && nbr_sim && workspace, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    float *inv = (float *)workspace;
+    unsigned long long *part = (unsigned long long *)((char *)workspace + (N + 63) / 64 * 256);
+    const int ns = knn_splits(N);
+    const int64_t nrb = (N + KN_M - 1) / KN_M;
+    const int tps = (int)((nrb + ns - 1) / ns);
+    const int ns_used = (int)((nrb + tps - 1) / tps);
+    k_knn_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv);
+    dim3 grid((unsigned)nrb, (unsigned)ns_used);
+    k_knn_mfma<<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, ns_used > 1 ? part : nullptr,
+                                     nbr_idx, nbr_sim);
+    if (ns_used > 1) k_knn_merge<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(part, N, k, ns_used, nbr_idx, nbr_sim);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}

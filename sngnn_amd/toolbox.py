@@ -246,3 +246,34 @@ def edge_index_to_sparse_csc_tensor(x, edge_index):
     n = len(x)
     ei = edge_index.detach().cpu().numpy()
     return sp.csc_matrix((np.full(ei.shape[1], 1), (ei[0], ei[1])), shape=(n, n))
+
+
+# ---------------------------------------------------------------------------
+# kNN similarity graph: the edges the aggregation layers consume, straight from x
+# ---------------------------------------------------------------------------
+def knn_graph(x: torch.Tensor, k: int, exclude_self: bool = True):
+    """For every node the ``k`` most cosine-similar nodes (``sngnn_knn_graph``: tiled fp32
+    MFMA with a fused per-row top-k; the [N, N] similarity of dense.py:138-141 is never
+    stored).  Returns (idx int64 [N, k] in rank order, -1 padded; sim fp32 [N, k])."""
+    x = _x(x)
+    n, f = x.shape
+    lib = _lib.load()
+    idx = torch.empty((n, k), dtype=torch.int32, device=x.device)
+    sim = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(int(lib.sngnn_knn_workspace_bytes(n, int(k))), 256), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.sngnn_knn_graph(x.data_ptr(), n, f, int(k), int(bool(exclude_self)), idx.data_ptr(),
+                                 sim.data_ptr(), ws.data_ptr(), _stream(x))
+    _lib.check(rc, "sngnn_knn_graph")
+    return idx.long(), sim
+
+
+def knn_edge_index(x: torch.Tensor, k: int, exclude_self: bool = True) -> torch.Tensor:
+    """The kNN graph as an ``edge_index`` [2, E] for the conv layers: source = neighbour,
+    target = node, targets ascending, a node's in-edges in similarity order."""
+    idx, _ = knn_graph(x, k, exclude_self)
+    n = idx.size(0)
+    dst = torch.arange(n, device=idx.device).repeat_interleave(idx.size(1))
+    src = idx.reshape(-1)
+    keep = src >= 0
+    return torch.stack([src[keep], dst[keep]])

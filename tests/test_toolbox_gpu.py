@@ -145,3 +145,55 @@ def test_signed_edge_attention_ggcn(cuda):
     np.testing.assert_allclose(pos.cpu().numpy(), F.relu(sim).numpy(), atol=2e-6)
     np.testing.assert_allclose(neg.cpu().numpy(), (-F.relu(-sim)).numpy(), atol=2e-6)
     assert (pos >= 0).all() and (neg <= 0).all() and ((pos == 0) | (neg == 0)).all()
+
+
+@pytest.mark.parametrize("n,f,k,excl", [(300, 16, 5, True), (1000, 64, 16, True), (777, 33, 32, False),
+                                        (130, 7, 10, True), (5, 8, 8, True), (1, 4, 3, True),
+                                        (2500, 128, 16, True)])
+def test_knn_graph_matches_dense_topk(cuda, n, f, k, excl):
+    """Fused MFMA cosine + per-row top-k against the materialised similarity (fp64): every
+    returned neighbour's cosine is right, the list is ordered, and nothing clearly better
+    was left out (pairs closer than 2e-6 may swap)."""
+    from sngnn_amd import toolbox as T
+    gen = torch.Generator().manual_seed(n + k)
+    x = torch.randn(n, f, generator=gen)
+    if n > 12:
+        x[7] = x[3]                       # exact duplicates: tie broken by node id
+        x[11] = 0.0                       # a zero row: cosine 0 with everything
+    idx, sim = T.knn_graph(x.to(cuda), k, exclude_self=excl)
+    idx, sim = idx.cpu(), sim.cpu()
+    xn = torch.nn.functional.normalize(x.double(), dim=1)
+    S = xn @ xn.t()
+    if excl:
+        S.fill_diagonal_(-float("inf"))
+    m = min(k, n - (1 if excl else 0))
+    assert (idx[:, m:] == -1).all() and (sim[:, m:] == 0).all()
+    if m == 0:
+        return
+    got, gs = idx[:, :m], sim[:, :m]
+    assert (got >= 0).all() and (got < n).all()
+    assert all(len(set(r.tolist())) == m for r in got)                    # no duplicates
+    if excl:
+        assert (got != torch.arange(n).unsqueeze(1)).all()
+    true = S.gather(1, got)
+    assert (gs.double() - true).abs().max() <= 2e-6
+    assert (gs[:, 1:] <= gs[:, :-1] + 1e-7).all()                          # rank order
+    kth = torch.topk(S, m, dim=1).values[:, -1]
+    assert (true.min(dim=1).values >= kth - 2e-6).all()                    # nothing better missed
+    if n > 12 and excl and k >= 2:
+        # node 3 and node 7 are identical: each is the other's nearest neighbour
+        assert got[3, 0] == 7 and got[7, 0] == 3
+
+
+def test_knn_edge_index_feeds_the_conv_layer(cuda):
+    import sngnn_amd
+    from sngnn_amd import toolbox as T
+    x = torch.randn(400, 24, generator=torch.Generator().manual_seed(1)).to(cuda)
+    ei = T.knn_edge_index(x, 8)
+    assert ei.shape == (2, 400 * 8) and ei.dtype == torch.int64
+    assert torch.equal(ei[1], torch.arange(400, device=cuda).repeat_interleave(8))
+    conv = sngnn_amd.SNConv_plus(24, 16, 400, top_k=4, thr=0.0).to(cuda)
+    out = conv(x, ei)
+    assert out.shape == (400, 16) and torch.isfinite(out).all()
+    with pytest.raises(ValueError):
+        T.knn_graph(x, 33)
