@@ -65,26 +65,45 @@ __device__ __forceinline__ unsigned long long merge_row(unsigned long long *list
 
 // blockIdx.y = column split: this workgroup covers column tiles [y * tiles_per_split, ...) and
 // writes its lists as KEYS to part[y][N][k] (nsplit > 1) or the final idx / sim (nsplit == 1).
+//
+// FH > 0 (F == 2 FH, FH a multiple of 16, F <= 128): the wave's 32 rows never change, so their
+// MFMA operands stay in REGISTERS for the whole scan - the k order of a contraction is free,
+// lane (row, half h) keeps the contiguous half k in [h FH, (h + 1) FH) of its row - and only
+// the column panel streams through LDS (half the staging, 4 LDS reads per 4 MFMAs).
+// FH == 0: any F, both panels through LDS.
+template <int FH>
 __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, int64_t N, int64_t F,
                                                   const float *__restrict__ inv, int k, int exclude_self,
                                                   int tiles_per_split, unsigned long long *__restrict__ part,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_sim)
 {
-    __shared__ float sA[KN_M * KN_LD];
+    __shared__ float sA[FH > 0 ? 1 : KN_M * KN_LD];
     __shared__ float sB[KN_M * KN_LD];
     __shared__ unsigned long long s_list[4][32][KNN_MAX_K];     // running top-k keys per row
     __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
     __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
+    __shared__ int s_pend[4][32];                               // candidates parked in list[k .. KNN_MAX_K)
     __shared__ unsigned long long s_cand[4][2][128];            // candidates of the two rows of a register
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * KN_M;
     for (int q = lane; q < 32 * KNN_MAX_K; q += 64) s_list[wave][q / KNN_MAX_K][q % KNN_MAX_K] = 0ull;
-    if (lane < 32) { s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; }
+    if (lane < 32) { s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; s_pend[wave][lane] = 0; }
+    const int cap = KNN_MAX_K - k;                               // spare slots behind a row's list
     const int sc = tid & 31, sr = tid >> 5;
     const int64_t ncol_tiles = (N + KN_M - 1) / KN_M;
     const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_split;
     const int64_t ct_end = min(ncol_tiles, ct_begin + tiles_per_split);
+
+    float areg[FH > 0 ? FH : 1];
+    if constexpr (FH > 0) {
+        const int64_t ar = min(row0 + wave * 32 + l32, N - 1);          // (rows >= N are never used)
+#pragma unroll
+        for (int q = 0; q < FH / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + ar * F + half * FH + 4 * q);
+            areg[4 * q] = v.x; areg[4 * q + 1] = v.y; areg[4 * q + 2] = v.z; areg[4 * q + 3] = v.w;
+        }
+    }
 
     for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
         const int64_t col0 = ct * KN_M;
@@ -93,6 +112,35 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        if constexpr (FH > 0) {
+            float rb[KN_LOADS];
+            // k-step = 16 steps of each half: columns [s0, s0 + 16) and [FH + s0, FH + s0 + 16)
+            const int kc = sc < 16 ? sc : FH + sc - 16;
+            auto fetchb = [&](int s0) {
+#pragma unroll
+                for (int u = 0; u < KN_LOADS; ++u) {
+                    const int64_t r_b = min(col0 + sr + 8 * u, N - 1);
+                    rb[u] = x[r_b * F + s0 + kc];
+                }
+            };
+            fetchb(0);
+#pragma unroll
+            for (int s0 = 0; s0 < FH; s0 += 16) {
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < KN_LOADS; ++u) sB[(sr + 8 * u) * KN_LD + sc] = rb[u];
+                __syncthreads();
+                if (s0 + 16 < FH) fetchb(s0 + 16);
+#pragma unroll
+                for (int ss = 0; ss < 16; ++ss) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float bv = sB[(b * 32 + l32) * KN_LD + half * 16 + ss];
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + ss], bv, acc[b], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
         float ra[KN_LOADS], rb[KN_LOADS];
         auto fetch = [&](int64_t k0) {
             const int64_t kk = k0 + sc;
@@ -124,6 +172,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                 }
             }
         }
+        }   // FH == 0
         // ---- selection: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
         float icol[4];
         int64_t jcol[4];
@@ -176,7 +225,16 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                 if (c == 0) continue;
                 const int rowh = (r & 3) + 8 * (r >> 2) + 4 * h;
                 unsigned long long *cand = s_cand[wave][h];
-                if (c + k > 128) {
+                unsigned long long *list = s_list[wave][rowh];
+                const int pc = s_pend[wave][rowh];
+                if (pc + c <= cap) {
+                    // park them behind the list: the merge waits until the spare slots are full
+                    // (the row's threshold goes stale meanwhile - it only lets more through)
+                    if (lane < c) list[k + pc + lane] = cand[lane];
+                    if (lane == 0) s_pend[wave][rowh] = pc + c;
+                    continue;
+                }
+                if (c + pc + k > 128) {
                     // too many for one merge (first tiles only): keep the best k candidates
                     const unsigned long long c0 = lane < c ? cand[lane] : 0ull, c1 = lane + 64 < c ? cand[lane + 64] : 0ull;
                     const unsigned long long T = kth_largest(c0, c1, k);
@@ -188,8 +246,11 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     wave_lds_sync();
                     c = k;
                 }
-                const unsigned long long T = merge_row(s_list[wave][rowh], cand, c, k);
+                if (lane < pc) cand[c + lane] = list[k + lane];        // the parked ones join
+                wave_lds_sync();
+                const unsigned long long T = merge_row(list, cand, c + pc, k);
                 if (lane == 0) {
+                    s_pend[wave][rowh] = 0;
                     s_thr[wave][rowh] = T;
                     const unsigned u = (unsigned)(T >> 32);
                     s_thrf[wave][rowh] = T ? __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) : -INFINITY;
@@ -197,6 +258,16 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             }
             wave_lds_sync();
         }
+    }
+    // parked candidates of every row
+    wave_lds_sync();
+    for (int lr = 0; lr < 32; ++lr) {
+        const int pc = s_pend[wave][lr];
+        if (pc == 0) continue;                                           // wave-uniform (LDS value)
+        unsigned long long *cand = s_cand[wave][0];
+        if (lane < pc) cand[lane] = s_list[wave][lr][k + lane];
+        wave_lds_sync();
+        merge_row(s_list[wave][lr], cand, pc, k);
     }
     // ---- output: the lists in rank order, or as keys for the merge of the column splits
     wave_lds_sync();
@@ -319,8 +390,13 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     const int ns_used = (int)((nrb + tps - 1) / tps);
     k_knn_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv);
     dim3 grid((unsigned)nrb, (unsigned)ns_used);
-    k_knn_mfma<<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, ns_used > 1 ? part : nullptr,
-                                     nbr_idx, nbr_sim);
+    unsigned long long *pp = ns_used > 1 ? part : nullptr;
+    const bool areg = (uintptr_t)x % 16 == 0;
+    if (areg && F == 128) k_knn_mfma<64><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (areg && F == 96) k_knn_mfma<48><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (areg && F == 64) k_knn_mfma<32><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (areg && F == 32) k_knn_mfma<16><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else k_knn_mfma<0><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
     if (ns_used > 1) k_knn_merge<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(part, N, k, ns_used, nbr_idx, nbr_sim);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

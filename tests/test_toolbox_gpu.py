@@ -149,7 +149,8 @@ def test_signed_edge_attention_ggcn(cuda):
 
 @pytest.mark.parametrize("n,f,k,excl", [(300, 16, 5, True), (1000, 64, 16, True), (777, 33, 32, False),
                                         (130, 7, 10, True), (5, 8, 8, True), (1, 4, 3, True),
-                                        (2500, 128, 16, True)])
+                                        (2500, 128, 16, True), (900, 96, 7, True), (640, 64, 31, False),
+                                        (513, 32, 1, True)])
 def test_knn_graph_matches_dense_topk(cuda, n, f, k, excl):
     """Fused MFMA cosine + per-row top-k against the materialised similarity (fp64): every
     returned neighbour's cosine is right, the list is ordered, and nothing clearly better
