@@ -322,20 +322,23 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
     int s_cur = seq.next();
     if (s_cur < 0) return;
     int s_nxt = seq.next();
-    int *s_colbuf[2] = {lds_wave, lds_wave + 128};      // [RPW][SMALL_T] each
+    // two [RPW][SMALL_T] column-id buffers at lds_wave + 128 * buf.  (Plain pointer arithmetic:
+    // an array of the two pointers loses the LDS address space and every read of a column
+    // id becomes a FLAT load, which must drain the whole memory pipeline - s_waitcnt
+    // vmcnt(0) - in the middle of a batch of row gathers.)
     int4 d_cur = load_desc(s_cur);
     int4 d_nxt = load_desc(s_nxt);
     int cols[CPL];
     load_cols(d_cur, cols);
-    store_cols(cols, s_colbuf[0]);
+    store_cols(cols, lds_wave);
     int buf = 0;
     while (s_cur >= 0) {
         const int s_n2 = seq.next();
         const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
-        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, s_colbuf[buf]);
-        store_cols(cols, s_colbuf[buf ^ 1]);
+        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, lds_wave + 128 * buf);
+        store_cols(cols, lds_wave + 128 * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
         s_cur = s_nxt;
@@ -348,14 +351,16 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
 // Scoring pass shared by classes A and B: the wave's 64/G groups stride over
 // the edges [e0, e1) of row i (row-local indices).
 //   STREAM: accumulate kept rows into acc (threshold only) and write wsel
-//   sc_out: where to put the scores (LDS or HBM scratch), or nullptr; edge t goes to
-//           sc_out[t - sc_off]  (never form an out-of-range LDS pointer: LDS pointer
+//   sc: where to put the scores (LDS or HBM scratch - every CALL SITE passes one kind only: a
+//           pointer that is LDS on one path and HBM on another becomes FLAT, and FLAT accesses
+//           wait for vmcnt(0), i.e. drain the gathers in flight), or nullptr; edge t goes to
+//           sc[t - sc_off]  (never form an out-of-range LDS pointer: LDS pointer
 //           arithmetic is 32-bit and does not survive the cast to a flat address)
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
 __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int e0, int e1,
                                             const Row<VEC, G, R> &hi, float inv_i, bool stream,
-                                            float *sc_out, int sc_off, Row<VEC, G, R> &acc)
+                                            float *sc, int sc_off, Row<VEC, G, R> &acc)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
@@ -391,7 +396,7 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
         for (int u = 0; u < U; ++u) {
             const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
             if (act[u]) {
-                if (sc_out && lg == 0) sc_out[t[u] - sc_off] = s;
+                if (sc && lg == 0) sc[t[u] - sc_off] = s;
                 if (stream) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
                     if (sel) acc.axpy(s, x[u]);
@@ -692,7 +697,7 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
     RowT acc;
     acc.zero();
     float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
-    float *sc = cand ? s_sc : ((rank || emit) ? a.scores + a.split_soff[p] : nullptr);
+    float *sc_glb = (!cand && (rank || emit)) ? a.scores + a.split_soff[p] : nullptr;   // HBM scratch
     bool dma_done = false;
     if constexpr (SNGNN_ENABLE_DMA && VEC == 4 && R == 1) {
         if (a.use_dma && (cand || (!rank && !emit))) {      // scores (if any) go to LDS in these modes
@@ -704,8 +709,10 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             dma_done = true;
         }
     }
-    if (!dma_done)
-        score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc, cand ? e0 : 0, acc);
+    if (!dma_done) {
+        if (cand) score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, s_sc, e0, acc);          // LDS
+        else score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc_glb, 0, acc);             // HBM / none
+    }
     if (cand) {
         wave_lds_sync();
         const WaveSel ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);

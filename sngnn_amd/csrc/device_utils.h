@@ -98,24 +98,26 @@ template <int VEC, int G, int R> struct Row {
             for (int v = 0; v < VEC; ++v) x[r][v] = 0.f;
     }
 
+    // Lanes whose channels lie beyond C read channel 0 and discard it: the load itself is
+    // unconditional.  (A load under `if (c0 < C)` makes the compiler drain the memory
+    // pipeline - s_waitcnt vmcnt(0) - at every such branch, i.e. between the loads of a
+    // batch of rows that are meant to be in flight together.)
     __device__ __forceinline__ void load(const float *__restrict__ row, int C, int lg)
     {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int c0 = (r * G + lg) * VEC;
-            if (c0 < C) {
-                if constexpr (VEC == 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(row + c0);
-                    x[r][0] = t.x; x[r][1] = t.y; x[r][2] = t.z; x[r][3] = t.w;
-                } else if constexpr (VEC == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(row + c0);
-                    x[r][0] = t.x; x[r][1] = t.y;
-                } else {
-                    x[r][0] = row[c0];
-                }
+            const bool in = c0 < C;
+            const int cc = in ? c0 : 0;
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(row + cc);
+                x[r][0] = in ? t.x : 0.f; x[r][1] = in ? t.y : 0.f; x[r][2] = in ? t.z : 0.f; x[r][3] = in ? t.w : 0.f;
+            } else if constexpr (VEC == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(row + cc);
+                x[r][0] = in ? t.x : 0.f; x[r][1] = in ? t.y : 0.f;
             } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) x[r][v] = 0.f;
+                const float t = row[cc];
+                x[r][0] = in ? t : 0.f;
             }
         }
     }
