@@ -43,6 +43,13 @@ struct BwdArgs {
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
 
+// the G bits of a wave ballot that belong to lane group gid
+template <int G> __device__ __forceinline__ unsigned long long group_bits(unsigned long long m, int gid)
+{
+    if constexpr (G == 64) return m;
+    else return (m >> (gid * G)) & ((1ull << G) - 1ull);
+}
+
 template <int VEC, int G, int R>
 __device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<VEC, G, R> &x)
 {
@@ -57,12 +64,16 @@ __device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<
 // ds_e, its record, and its contribution to dnT_i
 template <int VEC, int G, int R>
 __device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, float wq, const Row<VEC, G, R> &x,
-                                           const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc)
+                                           const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc,
+                                           float live = 1.0f)
 {
+    // live = 0: a padding repeat of the previous edge (odd count) - it rewrites the same
+    // record and adds nothing; keeping it unconditional keeps its row load in flight with
+    // its partner's instead of behind a branch
     const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
     const float d = group_sum<G>(gp.dot_partial(x));
     if (lg == 0) a.wd[e] = make_float2(wq, d);
-    fma_row<VEC, G, R>(acc, d * invj, x);
+    fma_row<VEC, G, R>(acc, d * invj * live, x);
 }
 
 // kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[] with their
@@ -105,28 +116,42 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     const int i = a.rperm[slot];
     const int rs = a.rowptr[i];
     const int deg = a.rowptr[i + 1] - rs;
-    int *s_j = lds_wave + gid * 2 * SMALL_T;                 // [SMALL_T] source id or -1
-    float *s_w = reinterpret_cast<float *>(s_j + SMALL_T);   // [SMALL_T] w_e / deg_i
+    // The kept edges are compacted first (ballot within the group), so the gather loop below
+    // has no `if (kept)` around its loads: a load inside a divergent branch is waited for
+    // right there (s_waitcnt vmcnt(0) before the branch closes), which would serialise the
+    // rows meant to be in flight together.
+    int *s_j = lds_wave + gid * 3 * SMALL_T;                 // [SMALL_T] kept: source id
+    int *s_e = s_j + SMALL_T;                                //                 edge position
+    float *s_w = reinterpret_cast<float *>(s_j + 2 * SMALL_T);   //             w_e / deg_i
     const float invdeg = 1.0f / (float)max(deg, 1);
-    for (int t = lg; t < deg; t += G) {
-        const float w = a.wsel[rs + t];
+    int nk = 0;
+    for (int t0 = 0; t0 < deg; t0 += G) {
+        const int t = t0 + lg;
+        const float w = t < deg ? a.wsel[rs + t] : SNGNN_UNSELECTED;
         const bool kept = is_kept(w);
-        s_j[t] = kept ? a.col[rs + t] : -1;
-        s_w[t] = w * invdeg;
-        if (!kept) a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+        if (t < deg && !kept) a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+        const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
+        if (kept) {
+            const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
+            s_j[pos] = a.col[rs + t];
+            s_e[pos] = t;
+            s_w[pos] = w * invdeg;
+        }
+        nk += __popcll(gm);
     }
     RowT gp, acc;
     gp.load(a.gout + (size_t)i * a.C, a.C, lg);
     gp.scale(invdeg);
     acc.zero();
     wave_lds_sync();
-    for (int t0 = 0; t0 < deg; t0 += 2) {
-        const int j0 = s_j[t0], j1 = (t0 + 1 < deg) ? s_j[t0 + 1] : -1;
+    for (int q0 = 0; q0 < nk; q0 += 2) {
+        const bool two = q0 + 1 < nk;
+        const int q1 = two ? q0 + 1 : q0;
         RowT x0, x1;
-        if (j0 >= 0) x0.load(a.h + (size_t)j0 * a.C, a.C, lg);
-        if (j1 >= 0) x1.load(a.h + (size_t)j1 * a.C, a.C, lg);
-        if (j0 >= 0) t_edge_row<VEC, G, R>(a, rs + t0, s_w[t0], x0, gp, lg, acc);
-        if (j1 >= 0) t_edge_row<VEC, G, R>(a, rs + t0 + 1, s_w[t0 + 1], x1, gp, lg, acc);
+        x0.load(a.h + (size_t)s_j[q0] * a.C, a.C, lg);
+        x1.load(a.h + (size_t)s_j[q1] * a.C, a.C, lg);
+        t_edge_row<VEC, G, R>(a, rs + s_e[q0], s_w[q0], x0, gp, lg, acc);
+        t_edge_row<VEC, G, R>(a, rs + s_e[q1], s_w[q1], x1, gp, lg, acc, two ? 1.0f : 0.0f);
     }
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
@@ -180,7 +205,7 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 {
-    __shared__ __align__(16) int lds[WAVES][256];
+    __shared__ __align__(16) int lds[WAVES][384];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
@@ -283,33 +308,41 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     const int v = a.sperm[slot];
     const int qs = a.cscptr[v];
     const int od = a.cscptr[v + 1] - qs;
-    int *s_i = lds_wave + gid * 3 * SMALL_T;                          // target row or -1
+    int *s_i = lds_wave + gid * 3 * SMALL_T;                          // kept out-edges: target row
     float *s_w = reinterpret_cast<float *>(s_i + SMALL_T);
     float *s_ds = reinterpret_cast<float *>(s_i + 2 * SMALL_T);
-    for (int t = lg; t < od; t += G) {
-        const float2 rec = a.wd[a.csc_eid[qs + t]];
+    int nk = 0;                                                       // (compacted: see t_role_small)
+    for (int t0 = 0; t0 < od; t0 += G) {
+        const int t = t0 + lg;
+        float2 rec = make_float2(SNGNN_UNSELECTED, 0.f);
+        if (t < od) rec = a.wd[a.csc_eid[qs + t]];
         const bool kept = is_kept(rec.x);
-        s_i[t] = kept ? a.csc_dst[qs + t] : -1;
-        s_w[t] = rec.x;
-        s_ds[t] = rec.y;
+        const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
+        if (kept) {
+            const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
+            s_i[pos] = a.csc_dst[qs + t];
+            s_w[pos] = rec.x;
+            s_ds[pos] = rec.y;
+        }
+        nk += __popcll(gm);
     }
     RowT msg, dns;
     msg.zero();
     dns.zero();
     wave_lds_sync();
-    for (int t0 = 0; t0 < od; t0 += 2) {
-        const int i0 = s_i[t0], i1 = (t0 + 1 < od) ? s_i[t0 + 1] : -1;
+    for (int q0 = 0; q0 < nk; q0 += 2) {
+        const bool two = q0 + 1 < nk;
+        const int q1 = two ? q0 + 1 : q0;
+        const int i0 = s_i[q0], i1 = s_i[q1];
         RowT x0, g0, x1, g1;
-        if (i0 >= 0) {
-            x0.load(a.h + (size_t)(i0 + a.row_off) * a.C, a.C, lg);
-            g0.load(a.gout + (size_t)i0 * a.C, a.C, lg);
-        }
-        if (i1 >= 0) {
-            x1.load(a.h + (size_t)(i1 + a.row_off) * a.C, a.C, lg);
-            g1.load(a.gout + (size_t)i1 * a.C, a.C, lg);
-        }
-        if (i0 >= 0) s_edge_rows<VEC, G, R>(x0, g0, s_w[t0], s_ds[t0], msg, dns);
-        if (i1 >= 0) s_edge_rows<VEC, G, R>(x1, g1, s_w[t0 + 1], s_ds[t0 + 1], msg, dns);
+        x0.load(a.h + (size_t)(i0 + a.row_off) * a.C, a.C, lg);
+        g0.load(a.gout + (size_t)i0 * a.C, a.C, lg);
+        x1.load(a.h + (size_t)(i1 + a.row_off) * a.C, a.C, lg);
+        g1.load(a.gout + (size_t)i1 * a.C, a.C, lg);
+        s_edge_rows<VEC, G, R>(x0, g0, s_w[q0], s_ds[q0], msg, dns);
+        // (odd count: the repeat enters with zero weights - unconditional, so that all four row
+        // loads are in flight together)
+        s_edge_rows<VEC, G, R>(x1, g1, two ? s_w[q1] : 0.f, two ? s_ds[q1] : 0.f, msg, dns);
     }
     s_finish<VEC, G, R>(a, v, lg, msg, dns);
 }
