@@ -213,7 +213,9 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
         if (rank) {
             wave_lds_sync();
             // second pass: gather only the kept source rows, in edge order
-            // (group-divergent trip count: no cross-lane operation inside)
+            // (group-divergent trip count: no cross-lane operation inside).  Batching these
+            // loads (compaction + U rows in flight) was measured: +1.5 us at k = 1 where almost
+            // nothing is kept, no gain at k = 16 where small rows never rank - left serial.
             for (int t = 0; t < deg; ++t) {
                 const float w = s_w[t];
                 if (w != SNGNN_UNSELECTED) {
@@ -360,7 +362,8 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
 template <int VEC, int G, int R>
 __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int e0, int e1,
                                             const Row<VEC, G, R> &hi, float inv_i, bool stream,
-                                            float *sc, int sc_off, Row<VEC, G, R> &acc)
+                                            float *sc, int sc_off, Row<VEC, G, R> &acc,
+                                            int *ids_lds = nullptr)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
@@ -397,6 +400,7 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
             const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
             if (act[u]) {
                 if (sc && lg == 0) sc[t[u] - sc_off] = s;
+                if (ids_lds && lg == 0) ids_lds[t[u] - sc_off] = j[u];      // for the re-gather of the kept rows
                 if (stream) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
                     if (sel) acc.axpy(s, x[u]);
@@ -525,7 +529,8 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
         }
     }
     if (!dma_done)
-        score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc);
+        score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc,
+                               rank ? lds_wave + 2 * WAVE_T : nullptr);
 
     if (need_sc) {
         wave_lds_sync();
@@ -554,15 +559,25 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
                 }
             }
         }
-        if (rank) {
-            for (int q0 = 0; q0 < nsel; q0 += NG) {
-                const int q = q0 + gid;
-                if (q < nsel) {
-                    const int idx = s_list[q];
-                    RowT x;
-                    x.load(a.h + (size_t)a.col[rs + idx] * a.C, a.C, lg);
-                    acc.axpy(s_sc[idx], x);
+        if (rank && nsel > 0) {
+            // the kept rows again, U per lane group in flight, unconditionally (a slot past the
+            // end repeats the last kept edge with weight 0): their column ids wait in LDS, so
+            // this is ONE memory round trip instead of a col -> row chain per kept edge
+            constexpr int U = Unroll<R>::U;
+            const int *s_ids = dma_done ? nullptr : lds_wave + 2 * WAVE_T;
+            for (int q0 = 0; q0 < nsel; q0 += U * NG) {
+                RowT x[U];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u * NG + gid;
+                    const int idx = s_list[min(q, nsel - 1)];
+                    const int j = s_ids ? s_ids[idx] : a.col[rs + idx];
+                    w[u] = q < nsel ? s_sc[idx] : 0.f;
+                    x[u].load(a.h + (size_t)j * a.C, a.C, lg);
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc.axpy(w[u], x[u]);
             }
         }
     }
