@@ -513,7 +513,9 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     RowT hi;
     hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
     const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
-    if (lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+    // (inv_norm[i] is stored at the END of the row: a store here would pin the scoring pass's
+    // first column-id loads behind it - the pointers are not restrict - and with them behind
+    // the wait for hi)
 
     RowT acc;
     acc.zero();
@@ -586,6 +588,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
         acc.div((float)deg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
+    if (lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
     wave_lds_sync();            // the wave's LDS scratch is reused by its next item
 }
 
