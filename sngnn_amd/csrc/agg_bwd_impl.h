@@ -80,7 +80,7 @@ __device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, float wq, co
 // record weights w * wscale in wlist[]; unkept edges get their (final) record here.
 // Lanes cover the range 64 at a time.
 __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, float wscale,
-                                         int *list, float *wlist)
+                                         int *list, float *wlist, int *jlist = nullptr)
 {
     const int lane = lane_id();
     int n = 0;
@@ -93,6 +93,7 @@ __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e
             const int o = n + prefix_popc(m);
             list[o] = t;
             wlist[o] = w * wscale;
+            if (jlist) jlist[o] = a.col[rs + t];       // source ids now (coalesced), not per gather
         } else if (t < e1) {
             a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
         }
@@ -184,16 +185,19 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
     gp.scale(invdeg);
     acc.zero();
     float *wlist = reinterpret_cast<float *>(lds_wave + WAVE_T);
-    const int nsel = kept_list(a, rs, e0, e1, invdeg, lds_wave, wlist);
+    int *jlist = lds_wave + 2 * WAVE_T;
+    const int nsel = kept_list(a, rs, e0, e1, invdeg, lds_wave, wlist, jlist);
     wave_lds_sync();
-    for (int q0 = 0; q0 < nsel; q0 += NG) {
-        const int q = q0 + gid;
-        if (q < nsel) {
-            const int e = rs + lds_wave[q];
-            RowT x;
-            x.load(a.h + (size_t)a.col[e] * a.C, a.C, lg);
-            t_edge_row<VEC, G, R>(a, e, wlist[q], x, gp, lg, acc);
-        }
+    // two kept rows per lane group in flight, unconditionally (a slot past the end repeats the
+    // last kept edge with live = 0): no col -> row chain, no load behind a branch.  Matters on
+    // graphs whose rows mostly have 17..128 in-edges (products-like), not at arxiv size.
+    for (int q0 = 0; q0 < nsel; q0 += 2 * NG) {
+        const int qa = min(q0 + gid, nsel - 1), qb = min(q0 + NG + gid, nsel - 1);
+        RowT xa, xb;
+        xa.load(a.h + (size_t)jlist[qa] * a.C, a.C, lg);
+        xb.load(a.h + (size_t)jlist[qb] * a.C, a.C, lg);
+        t_edge_row<VEC, G, R>(a, rs + lds_wave[qa], wlist[qa], xa, gp, lg, acc, q0 + gid < nsel ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(a, rs + lds_wave[qb], wlist[qb], xb, gp, lg, acc, q0 + NG + gid < nsel ? 1.0f : 0.0f);
     }
     acc.reduce_across_groups();
     if (gid == 0) {
@@ -384,9 +388,21 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     RowT msg, dns;
     msg.zero();
     dns.zero();
-    for (int q0 = 0; q0 < nsel; q0 += NG) {
-        const int q = q0 + gid;
-        if (q < nsel) s_edge<VEC, G, R>(a, s_i[q], s_rec[q], lg, msg, dns);
+    // two kept out-edges per lane group per step, unconditionally (a slot past the end repeats
+    // the last one with a zero record): four row loads in flight per group
+    for (int q0 = 0; q0 < nsel; q0 += 2 * NG) {
+        const int qa = min(q0 + gid, nsel - 1), qb = min(q0 + NG + gid, nsel - 1);
+        const int ia = s_i[qa], ib = s_i[qb];
+        float2 ra = s_rec[qa], rb = s_rec[qb];
+        if (q0 + gid >= nsel) ra = make_float2(0.f, 0.f);
+        if (q0 + NG + gid >= nsel) rb = make_float2(0.f, 0.f);
+        RowT xa, ga, xb, gb;
+        xa.load(a.h + (size_t)(ia + a.row_off) * a.C, a.C, lg);
+        ga.load(a.gout + (size_t)ia * a.C, a.C, lg);
+        xb.load(a.h + (size_t)(ib + a.row_off) * a.C, a.C, lg);
+        gb.load(a.gout + (size_t)ib * a.C, a.C, lg);
+        s_edge_rows<VEC, G, R>(xa, ga, ra.x, ra.y, msg, dns);
+        s_edge_rows<VEC, G, R>(xb, gb, rb.x, rb.y, msg, dns);
     }
     msg.reduce_across_groups();
     dns.reduce_across_groups();
