@@ -370,13 +370,14 @@ class _HeadNLL(torch.autograd.Function):
     of correctly classified masked rows (no gradient)."""
 
     @staticmethod
-    def forward(ctx, logits, y, row_mask_u8, n_masked):
+    def forward(ctx, logits, y, row_mask_u8, n_masked, out=None):
         lib = _lib.load()
         z = logits.contiguous()
         n, c = z.shape
         need_grad = ctx.needs_input_grad[0]
         grad = torch.empty_like(z) if need_grad else None
-        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        if out is None:
+            out = torch.empty(2, dtype=torch.float32, device=z.device)
         ws = _workspace("head", lib.sngnn_head_workspace_bytes(n), z.device)
         with torch.cuda.device(z.device):
             rc = lib.sngnn_head_nll(z.data_ptr(), y.data_ptr(), row_mask_u8.data_ptr(), n, c,
@@ -392,14 +393,20 @@ class _HeadNLL(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_correct):
         (grad,) = ctx.saved_tensors
-        return grad * g_loss, None, None, None
+        return grad * g_loss, None, None, None, None
 
 
-def head_nll(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int):
+def head_nll(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int,
+             out: Optional[torch.Tensor] = None):
     """(loss, n_correct) of the masked rows: fused log_softmax + nll_loss + accuracy
-    (models.py:86 + train.py:81-84).  ``row_mask_u8``: uint8 [N]."""
+    (models.py:86 + train.py:81-84).  ``row_mask_u8``: uint8 [N].  ``out``: optional
+    contiguous fp32 [2] the kernel writes (loss, n_correct) into - the returned tensors are
+    views of it (a trainer's metrics buffer, no copy)."""
+    if out is not None and (out.dtype != torch.float32 or out.numel() != 2 or not out.is_contiguous()
+                            or out.device != logits.device):
+        raise ValueError("out must be a contiguous float32 tensor of 2 elements on the logits' device")
     if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
         raise ValueError("logits must be a float32 GPU tensor [N, C]")
     if y.dtype != torch.int64 or row_mask_u8.dtype != torch.uint8:
         raise ValueError("y must be int64 and row_mask uint8")
-    return _HeadNLL.apply(logits, y.contiguous(), row_mask_u8.contiguous(), n_masked)
+    return _HeadNLL.apply(logits, y.contiguous(), row_mask_u8.contiguous(), n_masked, out)

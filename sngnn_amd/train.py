@@ -146,8 +146,10 @@ class GraphedEpoch:
         """(mean NLL, correct count) on one mask: the fused head kernel on the model's
         logits, or the reference expressions for a model without ``forward_logits``."""
         if self.fused:
+            # the kernel writes (loss, correct) straight into this split's slots of the metrics
+            slot = {"train": 0, "val": 2, "test": 4}[which]
             return self._ops.head_nll(self.model.forward_logits(self.data), self.data.y,
-                                      self.mask[which], self.count[which])
+                                      self.mask[which], self.count[which], out=self.metrics[slot:slot + 2])
         out = self.model(self.data)
         m = self.mask[which].bool()
         return (F.nll_loss(out[m], self.data.y[m]),
@@ -166,7 +168,8 @@ class GraphedEpoch:
             self.model.eval()
             vl, vc = self._loss("val")
             tl, tc = self._loss("test")
-            torch.stack([loss.detach(), correct, vl, vc, tl, tc], out=self.metrics)   # one kernel
+            if not self.fused:
+                torch.stack([loss.detach(), correct, vl, vc, tl, tc], out=self.metrics)   # one kernel
 
     def run(self) -> Dict[str, float]:
         """Replay one epoch; returns the metrics (one host read)."""
