@@ -396,6 +396,26 @@ class _HeadNLL(torch.autograd.Function):
         return grad * g_loss, None, None, None, None
 
 
+def head_nll_with_grad(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int,
+                       out: Optional[torch.Tensor] = None):
+    """The head kernel outside autograd: returns ((loss, n_correct) as views of ``out``,
+    d loss / d logits).  A trainer calls ``logits.backward(grad)`` with it - the same
+    gradient ``loss.backward()`` produces through :func:`head_nll`, without the ones-fill and
+    the ``grad * 1`` pass over [N, C] that the generic autograd seam costs."""
+    lib = _lib.load()
+    z = logits.detach().contiguous()
+    n, c = z.shape
+    grad = torch.empty_like(z)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+    ws = _workspace("head", lib.sngnn_head_workspace_bytes(n), z.device)
+    with torch.cuda.device(z.device):
+        rc = lib.sngnn_head_nll(z.data_ptr(), y.data_ptr(), row_mask_u8.data_ptr(), n, c, int(n_masked),
+                                grad.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream(z.device))
+    _lib.check(rc, "sngnn_head_nll")
+    return (out[0], out[1]), grad
+
+
 def head_nll(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int,
              out: Optional[torch.Tensor] = None):
     """(loss, n_correct) of the masked rows: fused log_softmax + nll_loss + accuracy

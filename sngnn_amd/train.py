@@ -161,8 +161,15 @@ class GraphedEpoch:
         # the graph's private pool, same addresses on every replay) instead of zero-filling
         # and accumulating - two small kernels per parameter less
         self.opt.zero_grad(set_to_none=True)
-        loss, correct = self._loss("train")
-        loss.backward()
+        if self.fused:
+            # the head kernel hands back d loss / d logits directly: backward starts at the logits
+            logits = self.model.forward_logits(self.data)
+            (loss, correct), grad = self._ops.head_nll_with_grad(
+                logits, self.data.y, self.mask["train"], self.count["train"], out=self.metrics[0:2])
+            logits.backward(grad)
+        else:
+            loss, correct = self._loss("train")
+            loss.backward()
         self.opt.step()
         with torch.no_grad():
             self.model.eval()
