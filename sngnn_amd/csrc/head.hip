@@ -305,13 +305,21 @@ __global__ __launch_bounds__(256 * WG_SUB) void k_wgrad_partial(const float *__r
 }
 
 // out[j] = sum over chunks of part[chunk][j]: 16 threads per output take every 16th
-// chunk, then their sums are added in fixed order (deterministic).
-__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, int nchunks,
-                                                      int64_t len, float *__restrict__ out)
+// chunk, then their sums are added in fixed order (deterministic).  Two independent sums
+// (weight and bias gradient) share one launch: blocks [0, nbA) do A, the rest B.
+__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ partA, int64_t lenA,
+                                                      float *__restrict__ outA, int nbA,
+                                                      const float *__restrict__ partB, int64_t lenB,
+                                                      float *__restrict__ outB, int nchunks)
 {
     __shared__ float s[16][16];
+    const bool second = (int)blockIdx.x >= nbA;
+    const float *part = second ? partB : partA;
+    float *out = second ? outB : outA;
+    const int64_t len = second ? lenB : lenA;
+    const int blk = second ? blockIdx.x - nbA : blockIdx.x;
     const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
-    const int64_t j = (int64_t)blockIdx.x * 16 + o;
+    const int64_t j = (int64_t)blk * 16 + o;
     float a = 0.f;
     if (j < len)
         for (int k = q; k < nchunks; k += 16) a += part[(size_t)k * len + j];
@@ -391,8 +399,8 @@ extern "C" int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t
         }
     }
     const int64_t len = (int64_t)C * F;
-    k_sum_partials<<<(unsigned)((len + 15) / 16), 256, 0, st>>>(part, chunks, len, grad_weight);
-    if (grad_bias) k_sum_partials<<<(C + 15) / 16, 256, 0, st>>>(part_b, chunks, C, grad_bias);
+    const int nbA = (int)((len + 15) / 16), nbB = grad_bias ? (C + 15) / 16 : 0;
+    k_sum_partials<<<nbA + nbB, 256, 0, st>>>(part, len, grad_weight, nbA, part_b, C, grad_bias, chunks);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
