@@ -207,14 +207,29 @@ __device__ __forceinline__ float inv_norm_of(float sumsq)
 // F.normalize clamps the norm at eps; below it the normalisation is a plain scale
 __device__ __forceinline__ bool norm_clamped(float sumsq) { return sumsq < EPS_NORM * EPS_NORM; }
 
-// cosine of target row a (inverse norm inv_i) and source row x
+// cosine of target row a (inverse norm inv_i) and source row x.
+// SNGNN_IEEE_COSINE=1 (build switch, off): <a, x> / (|a| |x|) with IEEE square roots and
+// division instead of d * (inv_i * inv_j).  Exactly parallel rows with a single non-zero
+// channel (common behind a ReLU; every pair when C == 1) then give EXACTLY +-1, as the
+// reference's normalise-then-dot does, so those ties fall to the edge position on both sides
+// instead of being decided by the last ulp.  Measured: +10 % on the forward kernel (59.5 ->
+// 65.4 us); a recompute only for |s| ~ 1 was slower still (68 us: registers).  All parity
+// tests pass either way; the default keeps the fast form and the near-tie rule of the tests.
+#ifndef SNGNN_IEEE_COSINE
+#define SNGNN_IEEE_COSINE 0
+#endif
 template <int VEC, int G, int R>
 __device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i,
                                             const Row<VEC, G, R> &x)
 {
     float d = group_sum<G>(a.dot_partial(x));
     float q = group_sum<G>(x.dot_partial(x));
-    float s = d * (inv_i * inv_norm_of(q));
+#if SNGNN_IEEE_COSINE
+    const float qi = group_sum<G>(a.dot_partial(a));
+    const float s = d / (fmaxf(sqrtf(qi), EPS_NORM) * fmaxf(sqrtf(q), EPS_NORM));
+#else
+    const float s = d * (inv_i * inv_norm_of(q));
+#endif
     return s + 0.0f;     // -0.0 -> +0.0: the reference orders floats, not bit patterns
 }
 
