@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sngnn_oracle as O  # noqa: E402
 from sngnn_amd import ops  # noqa: E402
 from sngnn_amd.graph import Graph, LOOPS_REPLACE  # noqa: E402

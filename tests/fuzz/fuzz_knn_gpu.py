@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sngnn_amd import toolbox as T  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sngnn_amd  # noqa: E402
 from oracle import sngnn_oracle as O  # noqa: E402
 from sngnn_amd.synth import Data  # noqa: E402
