@@ -322,6 +322,22 @@ def _exact_ties(h):
     h[3] = 0.0
 
 
+def _single_channel(h):
+    """Only the single-non-zero-channel class (plus a zero row): with thr == 1.0 exactly,
+    a cosine reaches the threshold iff it is EXACTLY 1 - in any summation order, because
+    every other product of the dot is an exact zero.  (Multi-channel duplicates give
+    1 +- 1 ulp depending on the order of the sum, in the reference too: not a fixture.)"""
+    n, c = h.shape
+    g = torch.Generator().manual_seed(98)
+    one = torch.randperm(n, generator=g)[: n // 2]
+    ch = torch.randint(0, 4, (one.numel(),), generator=g)          # few channels: many exact ties
+    mag = torch.rand(one.numel(), generator=g) * 3 + 0.1
+    sign = torch.where(torch.rand(one.numel(), generator=g) < 0.3, -1.0, 1.0)
+    h[one] = 0.0
+    h[one, ch] = mag * sign
+    h[3] = 0.0
+
+
 OPERATOR_CASES = {
     # name: shape = (n, e, C, hubs, add_loops, remove_loops, top_k, thr)
     "plus_c40_k16": dict(shape=(600, 6000, 40, ((0, 599), (3, 180), (9, 60)), True, True, 16, 0.0),
@@ -335,7 +351,7 @@ OPERATOR_CASES = {
     # exact-tie classes (new in round 2)
     "ties_c8_k4": dict(shape=(500, 6000, 8, ((0, 400), (7, 150)), True, True, 4, 0.0), seed=4242, edit=_exact_ties),
     "ties_c1_k3": dict(shape=(300, 3000, 1, ((2, 200),), True, False, 3, -0.5), seed=4243, edit=_noop),
-    "ties_c40_k16_thr1": dict(shape=(500, 8000, 40, ((1, 450),), True, True, 16, 1.0), seed=4244, edit=_exact_ties),
+    "ties_c40_k16_thr1": dict(shape=(500, 8000, 40, ((1, 450),), True, True, 16, 1.0), seed=4244, edit=_single_channel),
 }
 
 
