@@ -145,6 +145,28 @@ int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
                       void *stream);
 
 /*
+ * The two halves of sngnn_agg_forward, for a caller that already holds the unit rows
+ * (e.g. produced by the epilogue of its own ``lin``) or wants them.
+ *
+ * sngnn_normalize_rows replaces F.normalize(x, p=2, dim=-1) (models.py:122,238,325):
+ *   n[r, :] = h[r, :] / max(||h[r, :]||_2, 1e-12),  nrm[r] = that clamped norm,
+ * IEEE square root and division, so rows that the reference normalises to the same
+ * bits (duplicates, power-of-two multiples, rows with a single non-zero channel) get the
+ * same bits here and their cosines tie exactly as in the reference.
+ *   h, n  dev f32 [rows, C];  nrm dev f32 [rows]
+ *
+ * sngnn_agg_forward_normalized is sngnn_agg_forward on (n, nrm) of the N_total feature
+ * rows: the per-edge cosine is <n_i, n_j>, a kept message is cosine * nrm_j * n_j
+ * (= cosine * h_j to half an ulp).  Same workspace size and optional outputs.
+ */
+int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm,
+                         void *stream);
+int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                 int C, int top_k, float thr, float *out, float *wsel,
+                                 float *inv_norm, int32_t *sel_src, float *sel_w,
+                                 void *workspace, void *stream);
+
+/*
  * Replaces: autograd through the op list above (triggered at train.py:86).
  * Deterministic: no floating-point atomics; every sum has a fixed order.
  *
@@ -213,11 +235,13 @@ int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, flo
 /*
  * Measurement aid (no reference counterpart): while enabled, sngnn_agg_forward
  * records HIP events on the caller's stream around its launches;
- * sngnn_profile_last_forward waits for the last call and returns the device
- * time of the main kernel and of the split-row finalize kernel (ms).
+ * sngnn_profile_last_forward waits for the last call and returns the device time (ms)
+ * of the normalisation pass, of the main kernel and of what follows it on the caller's
+ * stream (the split-row finalize launches), and of an EMPTY interval between two events -
+ * what an event pair itself adds to each of the three figures on this stack.
  */
 int sngnn_profile_enable(int on);
-int sngnn_profile_last_forward(float *main_ms, float *fin_ms);
+int sngnn_profile_last_forward(float *norm_ms, float *main_ms, float *fin_ms, float *empty_ms);
 
 /* ------------------------------------------------------------------------
  * SNGNN++ adjacency-linear branch and blend.

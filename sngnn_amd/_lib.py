@@ -36,6 +36,9 @@ SIGNATURES = {
     "sngnn_graph_copy_array": (_i32, [_vp, _i32, _vp]),
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
     "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_normalize_rows": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "sngnn_agg_forward_normalized": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -47,7 +50,7 @@ SIGNATURES = {
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),
-    "sngnn_profile_last_forward": (_i32, [C.POINTER(_f32), C.POINTER(_f32)]),
+    "sngnn_profile_last_forward": (_i32, [C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)]),
     "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_head_workspace_bytes": (_i64, [_i64]),

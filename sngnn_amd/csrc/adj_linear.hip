@@ -1,6 +1,5 @@
 // C-ABI entries of the SNGNN++ adjacency-linear branch (kernels: adj_linear_impl.h).
 #include "adj_linear_impl.h"
-#include "agg_fwd_impl.h"   // SNGNN_DISPATCH_GR
 
 using namespace sngnn;
 

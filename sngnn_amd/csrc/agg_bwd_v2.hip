@@ -1,6 +1,5 @@
 // Instantiates the aggregation backward for rows read 2 float(s) per lane.
 #include "agg_bwd_impl.h"
-#include "agg_fwd_impl.h"   // SNGNN_DISPATCH_GR
 
 namespace sngnn {
 

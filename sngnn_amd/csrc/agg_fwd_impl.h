@@ -1,16 +1,30 @@
 // Fused forward of the similarity-navigated aggregation (gfx950).
 //
-// One launch computes, for every target row i of the CSR-by-target graph,
-//     s_e   = <h_i, h_j> / (max(|h_i|,eps) * max(|h_j|,eps))      per in-edge e = (j -> i)
+// A normalisation pass and the gather kernels compute, for every target row i of the
+// CSR-by-target graph,
+//     n_j   = h_j / nrm_j,  nrm_j = max(|h_j|_2, eps)      (F.normalize; k_normalize_rows)
+//     s_e   = <n_i, n_j>                               per in-edge e = (j -> i)
 //     keep  = top_k by (s desc, edge position asc) AND s >= thr    (or all, top_k < 0)
 //     out_i = (1 / max(deg_i, 1)) * sum_{e kept} s_e * h_j
 // i.e. models/models.py:122+132+139-158, :238-239+244-263, :325-326+331-334 of the
 // reference without materialising any per-edge [E', C] tensor.
 //
+// Normalise-then-dot, in the reference's order (F.normalize first, then
+// (norm_i * norm_j).sum(-1)), with IEEE square root and division per ROW: whenever two
+// source rows normalise to the same bits in the reference (duplicates, power-of-two
+// multiples, rows with one non-zero channel: exactly +-1 there) they do here, their
+// cosines are the same bits, and the tie falls to the edge position, as in the reference.
+// The gather reads the unit row n_j (4C bytes) and, for a kept edge, its 4-byte norm
+// (h_j = n_j * nrm_j to half an ulp).  Measured alternatives: dividing each
+// gathered h_j by its norm inside the gather (no unit-row table) costs the kernel 17 us of
+// vector arithmetic; it is at its balance point between the vector pipes and the line rate
+// of the memory system.
+//
 // Rows are processed in order of descending in-degree (graph.rperm) in three
-// classes, each a block range of the same launch:
+// classes, all work items of one persistent launch:
 //   A  split rows  (deg > WAVE_T): one wave per CHUNK-edge task scores its edges
-//      (edge-balanced); a second launch (k_agg_fin) selects and sums per row;
+//      (edge-balanced) and keeps its chunk-local top-k as candidates; a finalize launch
+//      merges the candidates per row and gathers the winners;
 //   B  wave rows   (SMALL_T < deg <= WAVE_T): one wave per row, its 64/G lane
 //      groups stride over the row's edges;
 //   C  small rows  (deg <= SMALL_T): one G-lane group per row, 64/G rows per wave.
@@ -27,9 +41,10 @@
 namespace sngnn {
 
 struct FwdArgs {
-    const float *h;
-    int C, N;         // N = owned target rows
-    int row_off;      // row i's own feature row is h[row_off + i] (node-range partition)
+    const float *n;       // [Ntot, C] unit rows (k_normalize_rows)
+    const float *nrm;     // [Ntot]    max(|h|_2, eps)
+    int C, N;             // N = owned target rows
+    int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
     const int4 *rdesc;     // per degree-sorted slot: {row, first edge, in-degree, 0}
     int k;            // < 0: no selection
@@ -40,40 +55,84 @@ struct FwdArgs {
     int n_split, n_med_end;     // slots [0,n_split) split, [n_split,n_med_end) wave, rest small
     int n_tasks;
     const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
-    const int32_t *xtask_list, *xtask_ptr;   // tasks grouped by source-range eighth (XCD affinity)
-    int xcd_affinity;
-    int dynamic;                // wave rows and small-row sets are handed out by atomic counters
-    int32_t *dyn_ctr;           // [2 classes][DYN_SHARDS] counters, 128 bytes apart, zero at launch
     float *scores, *partial;    // workspace
-    unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows (k <= CAND_MAX_K)
+    unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows
     int32_t *cand_src;              // [n_tasks, k]  their source ids (saves the finalize a dependent load)
+    int use_cand;                   // split rows keep chunk-local candidates (k <= CAND_MAX_K and they fit LDS)
     int lowbits;                    // bits needed for a row-local edge index
-    int32_t *split_cnt;             // [n_split] groups arrived (in-kernel finalize)
-    int32_t *grp_cnt;               // [n_groups] tasks arrived per group of FIN_GT tasks
-    const int32_t *split_grp0;      // [n_split+1] first group of each split row
-    unsigned long long *cand2;      // [n_groups, k] champions of each group
-    int nbA, nbB, nbC;          // (unused by the persistent kernel)
-    int dbg_classes;            // tuning aid: bit 0 tasks, bit 1 wave rows, bit 2 small rows
-    int dbg_blocks_per_cu;      // tuning aid: persistent grid size override (0 = default)
-    int inkernel_fin;           // split rows finalized by their last-arriving task (experimental)
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
-    int use_dma;                // classes A/B stream source rows through LDS-DMA (C % 4 == 0, C <= 256)
 };
 
-// The switches below compile measured-but-unprofitable variants into the
-// main kernel; off by default so they cost the shipped kernel no registers.
-#ifndef SNGNN_EXPERIMENTAL
-#define SNGNN_EXPERIMENTAL 0         // in-kernel finalize, dynamic work counters, XCD-affine tasks
-#endif
-#ifndef SNGNN_ENABLE_DMA
-#define SNGNN_ENABLE_DMA 0           // LDS-DMA scoring path: measured no faster than register staging
-#endif
-constexpr int DMA_NI = 2;            // LDS-DMA instructions (1 KiB each) per batch of source rows
-constexpr int LDS_DMA_OFF = 384;     // words: [0,128) scores | [128,256) kept list | [256,384) column ids
-constexpr int LDS_PER_WAVE = SNGNN_ENABLE_DMA ? LDS_DMA_OFF + 2 * DMA_NI * 256 : 512;   // + two DMA buffers
 constexpr int FWD_WAVES_PER_SIMD = 6;   // register budget of the main kernel (<= 80 VGPRs)
 
-template <int R> struct Unroll { static constexpr int U = (R >= 4) ? 1 : (R == 2 ? 2 : 4); };
+// source rows in flight per lane group (x 64/G groups per wave): ~16 registers of row data
+template <int R> struct Unroll { static constexpr int U = (R == 1) ? 4 : (R == 2 ? 2 : 1); };
+
+// words of LDS per wave of the main kernel: 4 regions of SETW words
+//   small rows: column ids (two buffers) | scores | kept weights      [64/G rows][SMALL_T] each
+//   wave rows / tasks: scores [128] | kept list [128] | column ids [128]
+template <int G> struct WaveLds {
+    static constexpr int RPW = 64 / G;
+    static constexpr int SETW = (RPW * SMALL_T > 128) ? RPW * SMALL_T : 128;
+    static constexpr int WORDS = 4 * SETW;
+};
+
+// ---------------------------------------------------------------------------
+// F.normalize (models.py:122,238,325): n = h / max(|h|_2, eps), one lane group per row.
+// IEEE sqrt and division: a row with a single non-zero channel becomes exactly +-1 there.
+// ---------------------------------------------------------------------------
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_normalize_rows(const float *__restrict__ h, int64_t rows, int C,
+                                                          float *__restrict__ n, float *__restrict__ nrm)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    constexpr int U = Unroll<R>::U;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    const int64_t w0 = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    for (int64_t base = w0 * RPW * U; base < rows; base += nw * RPW * U) {
+        RowT x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = base + u * RPW + gid;
+            x[u].load(h + (r < rows ? r : rows - 1) * C, C, lg);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = base + u * RPW + gid;
+            const float q = group_sum<G>(x[u].dot_partial(x[u]));
+            const float d = fmaxf(ieee_sqrt(q), EPS_NORM);
+            x[u].div_rn(d);
+            if (r < rows) {
+                x[u].store(n + r * C, C, lg);
+                if (lg == 0) nrm[r] = d;
+            }
+        }
+    }
+}
+
+template <int VEC, int G, int R>
+int launch_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    constexpr int U = Unroll<R>::U;
+    if (rows <= 0) return SNGNN_OK;
+    const int64_t sets = (rows + RPW * U - 1) / (RPW * U);
+    const int grid = (int)std::min<int64_t>(ceil_div(sets, WAVES), 256 * 8);
+    k_normalize_rows<VEC, G, R><<<grid, BLOCK, 0, st>>>(h, rows, C, n, nrm);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+// per-edge cosine of two unit rows (fma chain over the lane's channels, fixed-order
+// group sum); -0.0 -> +0.0: the reference orders floats, not bit patterns
+template <int VEC, int G, int R>
+__device__ __forceinline__ float unit_dot(const Row<VEC, G, R> &a, const Row<VEC, G, R> &x)
+{
+    return group_sum<G>(a.dot_partial(x)) + 0.0f;
+}
 
 // ---------------------------------------------------------------------------
 // Wave-level top-k of up to 128 selection keys, two per lane (0 = no key).
@@ -148,49 +207,48 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 {
     using RowT = Row<VEC, G, R>;
     constexpr int U = Unroll<R>::U;
+    constexpr int SETW = WaveLds<G>::SETW;
     const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
     const int i = d.x, rs = d.y, deg = d.z;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
     const bool need_sc = rank || emit;
+    const int self = i + a.row_off;
 
     const int *s_col = s_col_set + gid * SMALL_T;
-    float *s_sc = reinterpret_cast<float *>(lds_wave + 256) + gid * SMALL_T;
-    float *s_w = reinterpret_cast<float *>(lds_wave + 384) + gid * SMALL_T;
+    float *s_sc = reinterpret_cast<float *>(lds_wave + 2 * SETW) + gid * SMALL_T;
+    float *s_w = reinterpret_cast<float *>(lds_wave + 3 * SETW) + gid * SMALL_T;
 
-    RowT hi;
-    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
+    RowT ni;
+    ni.load(a.n + (size_t)self * a.C, a.C, lg);
     const int dmax = wave_max_i(deg);
 
     RowT acc;
     acc.zero();
-    float inv_i = 0.f;
     for (int t0 = 0; t0 < dmax; t0 += U) {
         RowT x[U];
+        float nj[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int j = (t0 + u) < deg ? s_col[t0 + u] : i + a.row_off;
-            x[u].load(a.h + (size_t)j * a.C, a.C, lg);
+            const int j = (t0 + u) < deg ? s_col[t0 + u] : self;
+            x[u].load(a.n + (size_t)j * a.C, a.C, lg);
+            nj[u] = rank ? 0.f : a.nrm[j];        // a streaming row weighs the row it has just scored
         }
-        if (t0 == 0) inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
+            const float s = unit_dot<VEC, G, R>(ni, x[u]);
             if (t0 + u < deg) {
                 if (need_sc && lg == 0) s_sc[t0 + u] = s;
                 if (!rank) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
-                    if (sel) acc.axpy(s, x[u]);
+                    if (sel) acc.axpy(s * nj[u], x[u]);
                     if (a.wsel && lg == 0) a.wsel[rs + t0 + u] = sel ? s : SNGNN_UNSELECTED;
                 }
             }
         }
     }
-    if (a.inv_norm) {      // isolated rows never enter the loop
-        if (dmax == 0) inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
-        if (valid && lg == 0) a.inv_norm[i] = inv_i;
-    }
+    if (a.inv_norm && valid && lg == 0) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
 
     if (need_sc) {
         wave_lds_sync();
@@ -213,15 +271,14 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
         if (rank) {
             wave_lds_sync();
             // second pass: gather only the kept source rows, in edge order
-            // (group-divergent trip count: no cross-lane operation inside).  Batching these
-            // loads (compaction + U rows in flight) was measured: +1.5 us at k = 1 where almost
-            // nothing is kept, no gain at k = 16 where small rows never rank - left serial.
+            // (group-divergent trip count: no cross-lane operation inside)
             for (int t = 0; t < deg; ++t) {
                 const float w = s_w[t];
                 if (w != SNGNN_UNSELECTED) {
+                    const int j = s_col[t];
                     RowT xr;
-                    xr.load(a.h + (size_t)s_col[t] * a.C, a.C, lg);
-                    acc.axpy(w, xr);
+                    xr.load(a.n + (size_t)j * a.C, a.C, lg);
+                    acc.axpy(w * a.nrm[j], xr);
                 }
             }
         }
@@ -234,73 +291,23 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 }
 
 // ---------------------------------------------------------------------------
-// Class C: deg <= SMALL_T, one G-lane group per row, 64/G rows per set.  Waves
-// are persistent: each walks sets wave_id, wave_id + n_waves, ... and keeps the
-// NEXT set's descriptors and column ids in flight while it works on the current
-// one, so a set costs one memory round trip (its feature rows) instead of a
+// Class C driver: waves are persistent, each walks sets wave_id, wave_id + n_waves, ...
+// and keeps the NEXT set's descriptors and column ids in flight while it works on the
+// current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-// Hands a wave its small-row sets.  Static: set0, set0 + stride, ...  Dynamic: chunks of
-// DYN_SETS consecutive sets taken from a per-shard atomic counter (shard = workgroup id
-// mod #shards; chunk c of shard x covers sets (x + #shards c) * DYN_SETS ...), the next chunk is
-// requested as soon as the current one is entered so the atomic's latency is hidden.
-constexpr int DYN_SETS = 2;
-constexpr int DYN_SHARDS = 64;          // counters per class (workgroup id mod DYN_SHARDS)
-constexpr int DYN_CTR_STRIDE = 32;      // ints (128 bytes) between counters
-
-__device__ __forceinline__ int dyn_fetch(int32_t *ctr)
-{
-    int v = 0;
-    if (lane_id() == 0) v = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;      // lane 0 holds the value: readfirstlane at the point of use
-}
-
-struct SetSeq {
-    int pos, end, stride, nsets;        // static: pos advances by stride; dynamic: [pos, end) is a chunk
-    int nxt_raw;                        // dynamic: result of the pending dequeue (lane 0)
-    int32_t *ctr;                       // nullptr = static
-    int shard, nsh;                     // this wave's shard and the number of shards
-
-    __device__ __forceinline__ void init_static(int set0, int st, int n)
-    { pos = set0; stride = st; nsets = n; end = n; ctr = nullptr; nxt_raw = 0; shard = 0; nsh = 1; }
-
-    __device__ __forceinline__ void init_dynamic(int32_t *c, int sh, int nshards, int n)
-    {
-        ctr = c; shard = sh; nsh = nshards; nsets = n; stride = 1;
-        const int c0 = __builtin_amdgcn_readfirstlane(dyn_fetch(ctr));
-        pos = (shard + nsh * c0) * DYN_SETS;
-        end = min(pos + DYN_SETS, nsets);
-        nxt_raw = pos < nsets ? dyn_fetch(ctr) : 0;
-    }
-
-    // next set id, or -1 when the wave's share is exhausted
-    __device__ __forceinline__ int next()
-    {
-        if (pos >= nsets) return -1;
-        const int s = pos;
-        pos += stride;
-        if (ctr != nullptr && pos >= end) {             // enter the chunk requested earlier
-            const int c = __builtin_amdgcn_readfirstlane(nxt_raw);
-            pos = (shard + nsh * c) * DYN_SETS;
-            end = min(pos + DYN_SETS, nsets);
-            if (pos < nsets) nxt_raw = dyn_fetch(ctr); else pos = nsets;
-        }
-        return s;
-    }
-};
-
 template <int VEC, int G, int R>
-__device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *lds_wave)
+__device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
     constexpr int CPL = (RPW * SMALL_T + 63) / 64;      // column ids per lane per set
+    constexpr int SETW = WaveLds<G>::SETW;
     const int lane = lane_id();
     const int gid = lane / G;
-    const int nsets = seq.nsets;
 
     auto load_desc = [&](int st) -> int4 {
         const int slot = a.n_med_end + st * RPW + gid;
-        return (st >= 0 && st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
+        return (st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
     };
     // lane l fetches column ids q = l + 64 m of the set: row q / SMALL_T, edge q % SMALL_T
     auto load_cols = [&](const int4 d, int (&c)[CPL]) {
@@ -321,10 +328,10 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
         }
     };
 
-    int s_cur = seq.next();
-    if (s_cur < 0) return;
-    int s_nxt = seq.next();
-    // two [RPW][SMALL_T] column-id buffers at lds_wave + 128 * buf.  (Plain pointer arithmetic:
+    int s_cur = set0;
+    if (s_cur >= nsets) return;
+    int s_nxt = s_cur + stride;
+    // two [RPW][SMALL_T] column-id buffers at lds_wave + SETW * buf.  (Plain pointer arithmetic:
     // an array of the two pointers loses the LDS address space and every read of a column
     // id becomes a FLAT load, which must drain the whole memory pipeline - s_waitcnt
     // vmcnt(0) - in the middle of a batch of row gathers.)
@@ -334,13 +341,13 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
     load_cols(d_cur, cols);
     store_cols(cols, lds_wave);
     int buf = 0;
-    while (s_cur >= 0) {
-        const int s_n2 = seq.next();
+    while (s_cur < nsets) {
+        const int s_n2 = s_nxt + stride;
         const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
-        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, lds_wave + 128 * buf);
-        store_cols(cols, lds_wave + 128 * (buf ^ 1));
+        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, lds_wave + SETW * buf);
+        store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
         s_cur = s_nxt;
@@ -360,8 +367,8 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, SetSeq &seq, int *l
 //           arithmetic is 32-bit and does not survive the cast to a flat address)
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
-__device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int e0, int e1,
-                                            const Row<VEC, G, R> &hi, float inv_i, bool stream,
+__device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, int e0, int e1,
+                                            const Row<VEC, G, R> &ni, bool stream,
                                             float *sc, int sc_off, Row<VEC, G, R> &acc,
                                             int *ids_lds = nullptr)
 {
@@ -376,12 +383,13 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int t = e0 + u * NG + gid;
-        jn[u] = t < e1 ? a.col[rs + t] : i + a.row_off;
+        jn[u] = t < e1 ? a.col[rs + t] : self;
     }
     for (int base = e0; base < e1; base += NG * U) {
         int t[U], j[U];
         bool act[U];
         RowT x[U];
+        float nj[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             t[u] = base + u * NG + gid;
@@ -389,104 +397,28 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int i, int rs, int
             j[u] = jn[u];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u].load(a.h + (size_t)j[u] * a.C, a.C, lg);
-#pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int tn = t[u] + NG * U;
-            jn[u] = tn < e1 ? a.col[rs + tn] : i + a.row_off;
+            x[u].load(a.n + (size_t)j[u] * a.C, a.C, lg);
+            nj[u] = stream ? a.nrm[j[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = edge_score<VEC, G, R>(hi, inv_i, x[u]);
+            const int tn = t[u] + NG * U;
+            jn[u] = tn < e1 ? a.col[rs + tn] : self;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float s = unit_dot<VEC, G, R>(ni, x[u]);
             if (act[u]) {
                 if (sc && lg == 0) sc[t[u] - sc_off] = s;
                 if (ids_lds && lg == 0) ids_lds[t[u] - sc_off] = j[u];      // for the re-gather of the kept rows
                 if (stream) {
                     const bool sel = (a.k < 0) || (s >= a.thr);
-                    if (sel) acc.axpy(s, x[u]);
+                    if (sel) acc.axpy(s * nj[u], x[u]);
                     if (a.wsel && lg == 0) a.wsel[rs + t[u]] = sel ? s : SNGNN_UNSELECTED;
                 }
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Scoring pass of classes A and B with the source rows streamed through LDS-DMA
-// (global_load_lds_dwordx4: per-lane source address, wave-contiguous 1 KiB LDS
-// destination, no VGPR destination).  One DMA instruction gathers 64 / (C/4) whole
-// rows; a batch is DMA_NI instructions; two batches ping-pong, so the next batch is
-// in flight while the current one is scored and the number of rows in flight does
-// not depend on the register budget.  The column ids were put in LDS (s_ids) with
-// ordinary loads BEFORE the first DMA: beside an LDS-DMA in flight hipcc waits
-// vmcnt(0) for any VGPR-destination load, which would drain the queue.
-// Edges are [e0, e0 + n), n <= 128.  Same arithmetic and order as score_edges.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmcnt_upto(int n)      // n wave-uniform, 0..DMA_NI
-{
-    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-}
-static_assert(DMA_NI == 2, "wait_vmcnt_upto covers 0..2");
-
-template <int VEC, int G, int R>
-__device__ __forceinline__ void score_edges_dma(const FwdArgs &a, int rs, int e0, int n,
-                                                const Row<VEC, G, R> &hi, float inv_i, bool stream,
-                                                float *s_sc, const int *s_ids, float *dma,
-                                                Row<VEC, G, R> &acc)
-{
-    using RowT = Row<VEC, G, R>;
-    constexpr int NG = 64 / G;
-    const int lane = lane_id();
-    const int gid = lane / G, lg = lane % G;
-    const int CH = a.C >> 2;                      // 16-byte chunks per row (<= G)
-    const int RPI = 64 / CH;                      // rows per DMA instruction
-    const int BR = DMA_NI * RPI;                  // rows per batch
-    const int r_in = lane / CH, c_in = lane - r_in * CH;
-    const bool dlane = r_in < RPI;
-    const int nb = (n + BR - 1) / BR;
-    auto issue = [&](int b, int buf) {
-#pragma unroll
-        for (int q = 0; q < DMA_NI; ++q) {
-            const int e = b * BR + q * RPI + r_in;
-            if (dlane && e < n) {
-                const int j = s_ids[e];
-                __builtin_amdgcn_global_load_lds(
-                    a.h + (size_t)j * a.C + c_in * 4,
-                    (__attribute__((address_space(3))) void *)(dma + (buf * DMA_NI + q) * 256), 16, 0, 0);
-            }
-        }
-    };
-    auto n_instr = [&](int b) {                   // DMA instructions of batch b with an active lane
-        const int rows = min(BR, n - b * BR);
-        return rows <= 0 ? 0 : (rows + RPI - 1) / RPI;
-    };
-    issue(0, 0);
-    if (nb > 1) issue(1, 1);
-    for (int b = 0; b < nb; ++b) {
-        wait_vmcnt_upto(b + 1 < nb ? n_instr(b + 1) : 0);     // batch b has landed
-        const float *buf = dma + (b & 1) * DMA_NI * 256;
-        const int rows = min(BR, n - b * BR);
-        for (int r0 = 0; r0 < rows; r0 += NG) {
-            const int r = r0 + gid;
-            const bool act = r < rows;
-            const int rr = act ? r : 0;
-            RowT x;
-            x.load(buf + (rr / RPI) * 256 + (rr % RPI) * CH * 4, a.C, lg);
-            const float s = edge_score<VEC, G, R>(hi, inv_i, x);
-            if (act) {
-                const int t = b * BR + r;             // chunk-local edge index
-                if (s_sc && lg == 0) s_sc[t] = s;
-                if (stream) {
-                    const bool sel = (a.k < 0) || (s >= a.thr);
-                    if (sel) acc.axpy(s, x);
-                    if (a.wsel && lg == 0) a.wsel[rs + e0 + t] = sel ? s : SNGNN_UNSELECTED;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this buffer's reads are done
-        if (b + 2 < nb) issue(b + 2, b & 1);
     }
 }
 
@@ -503,36 +435,22 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     const int slot = a.n_split + item;
     const int4 d = a.rdesc[slot];
     const int i = d.x, rs = d.y, deg = d.z;
+    const int self = i + a.row_off;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
     const bool need_sc = rank || emit;
 
     float *s_sc = reinterpret_cast<float *>(lds_wave);     // [WAVE_T]
     int *s_list = lds_wave + WAVE_T;                         // [WAVE_T]
+    int *s_ids = lds_wave + 2 * WAVE_T;                      // [WAVE_T]
 
-    RowT hi;
-    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
-    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
-    // (inv_norm[i] is stored at the END of the row: a store here would pin the scoring pass's
-    // first column-id loads behind it - the pointers are not restrict - and with them behind
-    // the wait for hi)
+    RowT ni;
+    ni.load(a.n + (size_t)self * a.C, a.C, lg);
 
     RowT acc;
     acc.zero();
-    bool dma_done = false;
-    if constexpr (SNGNN_ENABLE_DMA && VEC == 4 && R == 1) {
-        if (a.use_dma) {
-            int *s_ids = lds_wave + 2 * WAVE_T;
-            for (int t = lane; t < deg; t += 64) s_ids[t] = a.col[rs + t];
-            wave_lds_sync();
-            score_edges_dma<VEC, G, R>(a, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, s_ids,
-                                       reinterpret_cast<float *>(lds_wave + LDS_DMA_OFF), acc);
-            dma_done = true;
-        }
-    }
-    if (!dma_done)
-        score_edges<VEC, G, R>(a, i, rs, 0, deg, hi, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc,
-                               rank ? lds_wave + 2 * WAVE_T : nullptr);
+    score_edges<VEC, G, R>(a, self, rs, 0, deg, ni, !rank, need_sc ? s_sc : nullptr, 0, acc,
+                           rank ? s_ids : nullptr);
 
     if (need_sc) {
         wave_lds_sync();
@@ -566,20 +484,20 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
             // end repeats the last kept edge with weight 0): their column ids wait in LDS, so
             // this is ONE memory round trip instead of a col -> row chain per kept edge
             constexpr int U = Unroll<R>::U;
-            const int *s_ids = dma_done ? nullptr : lds_wave + 2 * WAVE_T;
             for (int q0 = 0; q0 < nsel; q0 += U * NG) {
                 RowT x[U];
-                float w[U];
+                float w[U], nj[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int q = q0 + u * NG + gid;
                     const int idx = s_list[min(q, nsel - 1)];
-                    const int j = s_ids ? s_ids[idx] : a.col[rs + idx];
+                    const int j = s_ids[idx];
                     w[u] = q < nsel ? s_sc[idx] : 0.f;
-                    x[u].load(a.h + (size_t)j * a.C, a.C, lg);
+                    x[u].load(a.n + (size_t)j * a.C, a.C, lg);
+                    nj[u] = a.nrm[j];
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc.axpy(w[u], x[u]);
+                for (int u = 0; u < U; ++u) acc.axpy(w[u] * nj[u], x[u]);
             }
         }
     }
@@ -588,106 +506,10 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
         acc.div((float)deg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
-    if (lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+    // (stored at the END of the row: a store up front would pin the scoring pass's first
+    // column-id loads behind it - the pointers are not restrict)
+    if (lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
     wave_lds_sync();            // the wave's LDS scratch is reused by its next item
-}
-
-// ---------------------------------------------------------------------------
-// In-kernel finalize of split rows (top_k <= CAND_MAX_K), two levels, no waiting:
-//   * the tasks of a row form groups of FIN_GT; the wave whose task is the LAST of its
-//     group to arrive merges the group's candidate keys into <= k champions;
-//   * the wave whose group is the last of the ROW to arrive merges the groups'
-//     champions, gathers the <= k winners and writes the row.
-// Nobody spins: a wave only ever waits for its own stores.  Hand-off (guide G16):
-// producers store keys write-through (sc1) and drain vmcnt before their relaxed
-// agent-scope counter add; a last arriver takes an agent-scope acquire and reads the
-// keys with sc1 loads.  Counters are reset by the last arriver (0 between launches).
-// ---------------------------------------------------------------------------
-constexpr int FIN_GT = 6;      // tasks per group: 6 * 16 keys fill one merge step beside 32 champions
-static_assert(FIN_GT == FIN_GT_HOST, "keep graph.hip in sync");
-
-// merge n keys at ck (sc1 loads) into champ[] (LDS, <= k keys); returns their number
-__device__ __forceinline__ int merge_keys(const unsigned long long *ck, int n, int k, int lowbits,
-                                          unsigned long long *champ)
-{
-    const int lane = lane_id();
-    int nchamp = 0;
-    for (int base = 0; base < n; base += 96) {
-        // lanes 0..31 of slot 0: champions so far; the other 96 slots: new keys
-        const int q0 = base + lane - 32, q1 = base + 32 + lane;
-        unsigned long long key0, key1;
-        if (lane < 32) key0 = lane < nchamp ? champ[lane] : 0ull;
-        else key0 = q0 < n ? __hip_atomic_load(ck + q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        key1 = q1 < n ? __hip_atomic_load(ck + q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        bool k0, k1;
-        wave_topk_keys(key0, key1, k, lowbits, k0, k1);
-        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-        const int n0 = __popcll(m0);
-        wave_lds_sync();                    // every lane has read its champion
-        if (k0) champ[prefix_popc(m0)] = key0;
-        if (k1) champ[n0 + prefix_popc(m1)] = key1;
-        nchamp = n0 + __popcll(m1);
-        wave_lds_sync();
-    }
-    return nchamp;
-}
-
-// kept edges of a split row from its champion keys: weights for backward, rank-ordered
-// selection, weighted sum
-template <int VEC, int G, int R>
-__device__ __forceinline__ void finalize_split_row(const FwdArgs &a, const int4 d,
-                                                   const unsigned long long *champ, int nchamp)
-{
-    using RowT = Row<VEC, G, R>;
-    constexpr int NG = 64 / G;
-    const int lane = lane_id();
-    const int gid = lane / G, lg = lane % G;
-    const int i = d.x, rs = d.y, deg = d.z;
-    const bool emit = a.sel_src != nullptr;
-    if (lane < nchamp) {
-        const unsigned long long kq = champ[lane];
-        const int idx = key_index(kq);
-        const float sq = key_score(kq);
-        if (a.wsel) a.wsel[rs + idx] = sq;
-        if (emit) {
-            int rk = 0;
-            for (int r = 0; r < nchamp; ++r) rk += champ[r] > kq;
-            a.sel_src[(size_t)i * a.k + rk] = a.col[rs + idx];
-            a.sel_w[(size_t)i * a.k + rk] = sq;
-        }
-    }
-    RowT acc;
-    acc.zero();
-    for (int q0 = 0; q0 < nchamp; q0 += NG) {
-        const int q = q0 + gid;
-        if (q < nchamp) {
-            const unsigned long long kq = champ[q];
-            RowT x;
-            x.load(a.h + (size_t)a.col[rs + key_index(kq)] * a.C, a.C, lg);
-            acc.axpy(key_score(kq), x);
-        }
-    }
-    acc.reduce_across_groups();
-    if (gid == 0) {
-        acc.div((float)deg);
-        acc.store(a.out + (size_t)i * a.C, a.C, lg);
-    }
-}
-
-// my stores are out -> count me in; true for the last of `total` arrivers, which
-// then also holds an acquire and has reset the counter
-__device__ __forceinline__ bool arrive_last(int32_t *cnt, int total)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int arrived = 0;
-    if (lane_id() == 0)
-        arrived = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    arrived = __builtin_amdgcn_readfirstlane(arrived);
-    if (arrived != total - 1) return false;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane_id() == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -702,78 +524,38 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
     const int p = a.task_slot[tq], c = a.task_chunk[tq];
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
+    const int self = i + a.row_off;
     const int e0 = c * CHUNK, e1 = min(deg, e0 + CHUNK);
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
-    const bool cand = rank && a.k <= CAND_MAX_K;        // chunk-local top-k -> candidates
+    const bool cand = rank && a.use_cand;        // chunk-local top-k -> candidates
 
-    RowT hi;
-    hi.load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
-    const float inv_i = inv_norm_of(group_sum<G>(hi.dot_partial(hi)));
-    if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = inv_i;
+    RowT ni;
+    ni.load(a.n + (size_t)self * a.C, a.C, lg);
+    if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
 
     RowT acc;
     acc.zero();
     float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
     float *sc_glb = (!cand && (rank || emit)) ? a.scores + a.split_soff[p] : nullptr;   // HBM scratch
-    bool dma_done = false;
-    if constexpr (SNGNN_ENABLE_DMA && VEC == 4 && R == 1) {
-        if (a.use_dma && (cand || (!rank && !emit))) {      // scores (if any) go to LDS in these modes
-            int *s_ids = lds_wave + 2 * WAVE_T;
-            for (int t = lane; t < e1 - e0; t += 64) s_ids[t] = a.col[rs + e0 + t];
-            wave_lds_sync();
-            score_edges_dma<VEC, G, R>(a, rs, e0, e1 - e0, hi, inv_i, !rank, cand ? s_sc : nullptr, s_ids,
-                                       reinterpret_cast<float *>(lds_wave + LDS_DMA_OFF), acc);
-            dma_done = true;
-        }
-    }
-    if (!dma_done) {
-        if (cand) score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, s_sc, e0, acc);          // LDS
-        else score_edges<VEC, G, R>(a, i, rs, e0, e1, hi, inv_i, !rank, sc_glb, 0, acc);             // HBM / none
-    }
+    if (cand) score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, s_sc, e0, acc);          // LDS
+    else score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, sc_glb, 0, acc);             // HBM / none
     if (cand) {
         wave_lds_sync();
         const WaveSel ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
-        unsigned long long *ck = a.cand_key + (size_t)tq * a.k;
+        unsigned long long *ck = a.cand_key + (size_t)tq * CAND_MAX_K;
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
         const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-        // write-through (sc1) stores: the row's last-arriving wave reads these keys
-        if (ws.kept0) __hip_atomic_store(ck + prefix_popc(m0), ws.key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ws.kept1) __hip_atomic_store(ck + n0 + prefix_popc(m1), ws.key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int32_t *cs = a.cand_src + (size_t)tq * a.k;
+        if (ws.kept0) ck[prefix_popc(m0)] = ws.key0;
+        if (ws.kept1) ck[n0 + prefix_popc(m1)] = ws.key1;
+        if (lane >= nsel && lane < a.k) ck[lane] = 0ull;          // empty slots (k <= 32 < 64)
+        int32_t *cs = a.cand_src + (size_t)tq * CAND_MAX_K;       // saves the finalize a dependent load
         if (ws.kept0) cs[prefix_popc(m0)] = a.col[rs + e0 + lane];
         if (ws.kept1) cs[n0 + prefix_popc(m1)] = a.col[rs + e0 + 64 + lane];
-        if (lane >= nsel && lane < a.k)           // empty slots (k <= 32 < 64)
-            __hip_atomic_store(ck + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.wsel) {     // the finalize overwrites the kept edges of the row
             float *w = a.wsel + rs + e0;
-            if (lane < e1 - e0) __hip_atomic_store(w + lane, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane + 64 < e1 - e0) __hip_atomic_store(w + lane + 64, SNGNN_UNSELECTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (SNGNN_EXPERIMENTAL && a.inkernel_fin) {
-            unsigned long long *champ = reinterpret_cast<unsigned long long *>(lds_wave);   // [32]
-            const int t0 = a.split_task0[p], nt = a.split_task0[p + 1] - t0;
-            const int gl = c / FIN_GT;                                  // my group inside the row
-            const int g0 = a.split_grp0[p], ng = a.split_grp0[p + 1] - g0;
-            const int gsize = min(FIN_GT, nt - gl * FIN_GT);
-            if (arrive_last(a.grp_cnt + g0 + gl, gsize)) {              // wave-uniform
-                wave_lds_sync();
-                int nchamp = merge_keys(a.cand_key + (size_t)(t0 + gl * FIN_GT) * a.k, gsize * a.k, a.k,
-                                        a.lowbits, champ);
-                bool mine = ng == 1;
-                if (!mine) {
-                    unsigned long long *c2 = a.cand2 + (size_t)(g0 + gl) * a.k;
-                    if (lane < a.k)
-                        __hip_atomic_store(c2 + lane, lane < nchamp ? champ[lane] : 0ull, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    if (arrive_last(a.split_cnt + p, ng)) {
-                        wave_lds_sync();
-                        nchamp = merge_keys(a.cand2 + (size_t)g0 * a.k, ng * a.k, a.k, a.lowbits, champ);
-                        mine = true;
-                    }
-                }
-                if (mine) finalize_split_row<VEC, G, R>(a, d, champ, nchamp);
-            }
+            if (lane < e1 - e0) w[lane] = SNGNN_UNSELECTED;
+            if (lane + 64 < e1 - e0) w[lane + 64] = SNGNN_UNSELECTED;
         }
     } else if (!rank) {
         acc.reduce_across_groups();
@@ -788,56 +570,24 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
-    __shared__ int lds[WAVES][LDS_PER_WAVE];
+    __shared__ int lds[WAVES][WaveLds<G>::WORDS];
     const int wave = threadIdx.x >> 6;
     int *lw = lds[wave];
     const int nw = gridDim.x * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
-    if (SNGNN_EXPERIMENTAL && a.xcd_affinity && (gridDim.x & 7) == 0) {
-        // Workgroups b and b + 8 share an XCD (observed round-robin placement; speed
-        // only, never correctness).  XCD group x takes the tasks whose sources lie in
-        // the x-th eighth of the node range: ~1/8 of the feature table per L2.
-        const int x = blockIdx.x & 7;
-        const int j = (blockIdx.x >> 3) * WAVES + wave, nwx = (gridDim.x >> 3) * WAVES;
-        const int q1 = a.xtask_ptr[x + 1];
-        if (a.dbg_classes & 1)
-            for (int q = a.xtask_ptr[x] + j; q < q1; q += nwx) role_task<VEC, G, R>(a, a.xtask_list[q], lw);
-        // waves without a task (high j) start with the biggest wave rows
-        it = (nwx - 1 - j) * 8 + x;
-    } else {
-        for (; it < a.n_tasks; it += nw)
-            if (a.dbg_classes & 1) role_task<VEC, G, R>(a, it, lw);
-        it -= a.n_tasks;
-    }
+    for (; it < a.n_tasks; it += nw) role_task<VEC, G, R>(a, it, lw);
+    it -= a.n_tasks;
+    for (; it < n_wave_rows; it += nw) role_wave<VEC, G, R>(a, it, lw);
+    it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    SetSeq seq;
-    if (SNGNN_EXPERIMENTAL && a.dynamic) {
-        // after its (static) tasks a wave asks for work: waves that also finalized a
-        // split row simply come back later and take less
-        const int nsh = min(DYN_SHARDS, (int)gridDim.x);     // every shard must have a workgroup
-        const int shard = blockIdx.x % nsh;
-        int32_t *ctr_b = a.dyn_ctr + shard * DYN_CTR_STRIDE;
-        int raw = dyn_fetch(ctr_b);
-        for (;;) {
-            const int row = shard + nsh * __builtin_amdgcn_readfirstlane(raw);
-            if (row >= n_wave_rows) break;
-            raw = dyn_fetch(ctr_b);             // requested before the row is processed
-            if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, row, lw);
-        }
-        seq.init_dynamic(a.dyn_ctr + (DYN_SHARDS + shard) * DYN_CTR_STRIDE, shard, nsh, nsets);
-    } else {
-        for (; it < n_wave_rows; it += nw)
-            if (a.dbg_classes & 2) role_wave<VEC, G, R>(a, it, lw);
-        it -= n_wave_rows;
-        seq.init_static(it, nw, nsets);
-    }
-    if (a.dbg_classes & 4) role_small<VEC, G, R>(a, seq, lw);
+    role_small<VEC, G, R>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------
-// Finalize of split rows: one FIN_BLOCK-thread workgroup per row.
+// Finalize of split rows from scores in HBM scratch (top_k > CAND_MAX_K, or a hub whose
+// candidates do not fit LDS): one FIN_BLOCK-thread workgroup per row, any degree.
 // ---------------------------------------------------------------------------
 struct __align__(16) FinShared {
     int red[2][FIN_BLOCK / 64];
@@ -846,7 +596,7 @@ struct __align__(16) FinShared {
     int pad[3];
 };
 static_assert(sizeof(FinShared) % 16 == 0, "keep the dynamic LDS base 16-byte aligned");
-static_assert(WAVE_T == 128 && SMALL_T == 16, "wave_select / role_small LDS layouts assume these");
+static_assert(WAVE_T == 128 && SMALL_T == 16 && CHUNK == 128, "LDS layouts of the main kernel assume these");
 
 __device__ __forceinline__ int block_count(int c, FinShared &sh, int &parity)
 {
@@ -877,12 +627,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
     const int deg = a.rowptr[i + 1] - rs;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
-    const int kk = a.k < 0 ? 0 : min(a.k, deg);
 
-    // dynamic LDS: [C * NW] partial rows | [kk] kept list | [lds_scores] scores
+    // dynamic LDS: [C * NW] partial rows | [k] kept list | [lds_scores] scores
     float *s_part = reinterpret_cast<float *>(dyn);
     int *s_list = reinterpret_cast<int *>(s_part + (size_t)a.C * NW);
-    float *s_scl = reinterpret_cast<float *>(s_list + (a.k < 0 ? 0 : a.k));
+    float *s_scl = reinterpret_cast<float *>(s_list + (a.k < 0 ? 0 : min(a.k, deg)));
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
 
     if (!rank && !emit) {
@@ -965,9 +714,10 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
             const int q = q0 + wave * NG + gid;
             if (q < nsel) {
                 const int idx = s_list[q];
+                const int j = a.col[rs + idx];
                 RowT x;
-                x.load(a.h + (size_t)a.col[rs + idx] * a.C, a.C, lg);
-                acc.axpy(sc[idx], x);
+                x.load(a.n + (size_t)j * a.C, a.C, lg);
+                acc.axpy(sc[idx] * a.nrm[j], x);
             }
         }
         acc.reduce_across_groups();
@@ -986,16 +736,18 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
             a.out[(size_t)i * a.C + ch] = s / (float)deg;
         }
     }
-    (void)kk;
 }
 
 // ---------------------------------------------------------------------------
 // Finalize of split rows from chunk-local candidates (top_k <= CAND_MAX_K):
-// one 256-thread workgroup per row merges the tasks' candidate keys 128 at a
+// one 1024-thread workgroup per row merges the tasks' candidate keys 128 at a
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
 constexpr int FIN_WAVE_MIN_ROWS = 2048;   // fewer moderate split rows than this: one launch (k_agg_fin_cand) for all
-constexpr int FINC_BLOCK = 1024, FINC_WAVES = FINC_BLOCK / 64;   // 8 waves: the tournament's first level runs wide
+constexpr int FINC_BLOCK = 1024, FINC_WAVES = FINC_BLOCK / 64;   // 16 waves: the tournament's first level runs wide
+constexpr size_t FINC_LDS_BUDGET = 150 * 1024;
+
+inline size_t finc_lds_bytes(int C, int max_slots) { return ((size_t)FINC_WAVES * C + 1) * 4 + (size_t)max_slots * 24 + 16; }
 
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
@@ -1045,8 +797,8 @@ __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, in
 
     int n = (t1 - t0) * a.k;
     for (int q = tid; q < n; q += FINC_BLOCK) {
-        kA[q] = a.cand_key[(size_t)t0 * a.k + q];
-        sA[q] = a.cand_src[(size_t)t0 * a.k + q];
+        kA[q] = a.cand_key[(size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k];
+        sA[q] = a.cand_src[(size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k];
     }
     __syncthreads();
     while (n > 128) {
@@ -1089,9 +841,10 @@ __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, in
     for (int q0 = 0; q0 < nsel; q0 += FINC_WAVES * NG) {
         const int q = q0 + wave * NG + gid;
         if (q < nsel) {
+            const int j = wsrc[q];
             RowT x;
-            x.load(a.h + (size_t)wsrc[q] * a.C, a.C, lg);
-            acc.axpy(key_score(win[q]), x);
+            x.load(a.n + (size_t)j * a.C, a.C, lg);
+            acc.axpy(key_score(win[q]) * a.nrm[j], x);
         }
     }
     for (int q = tid; q < nsel; q += FINC_BLOCK) {
@@ -1144,11 +897,11 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     }
     const bool emit = a.sel_src != nullptr;
     const int n = (t1 - t0) * a.k;                            // <= 128 by the launch split
-    const size_t c0 = (size_t)t0 * a.k;
-    const unsigned long long key0 = lane < n ? a.cand_key[c0 + lane] : 0ull;
-    const unsigned long long key1 = lane + 64 < n ? a.cand_key[c0 + lane + 64] : 0ull;
-    const int src0 = lane < n ? a.cand_src[c0 + lane] : 0;
-    const int src1 = lane + 64 < n ? a.cand_src[c0 + lane + 64] : 0;
+    auto slot = [&](int q) { return (size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k; };
+    const unsigned long long key0 = lane < n ? a.cand_key[slot(lane)] : 0ull;
+    const unsigned long long key1 = lane + 64 < n ? a.cand_key[slot(lane + 64)] : 0ull;
+    const int src0 = lane < n ? a.cand_src[slot(lane)] : 0;
+    const int src1 = lane + 64 < n ? a.cand_src[slot(lane + 64)] : 0;
     bool k0, k1;
     wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
@@ -1158,18 +911,21 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     wave_lds_sync();
     RowT acc;
     acc.zero();
-    constexpr int GU = R >= 4 ? 2 : 4;                        // winner rows in flight per lane group
+    constexpr int GU = R >= 3 ? 2 : 4;                        // winner rows in flight per lane group
     for (int w0 = 0; w0 < nsel; w0 += GU * NG) {
         RowT x[GU];
+        float nj[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
-            const int w = w0 + u * NG + gid;
-            if (w < nsel) x[u].load(a.h + (size_t)s_src[wave][w] * a.C, a.C, lg);
+            const int w = min(w0 + u * NG + gid, nsel - 1);
+            const int j = s_src[wave][w];
+            x[u].load(a.n + (size_t)j * a.C, a.C, lg);
+            nj[u] = a.nrm[j];
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int w = w0 + u * NG + gid;
-            if (w < nsel) acc.axpy(key_score(s_key[wave][w]), x[u]);
+            if (w < nsel) acc.axpy(key_score(s_key[wave][w]) * nj[u], x[u]);
         }
     }
     if (lane < nsel) {
@@ -1188,29 +944,25 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
 }
 
-template <int VEC, int G, int R>
-int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+// whether split rows keep chunk-local candidates (else: scores to HBM scratch + k_agg_fin)
+inline bool fwd_use_candidates(int top_k, int C, int max_split_deg)
 {
-    constexpr int RPW = 64 / G;
-    FwdArgs a = a0;
-    const int n_small = a.N - a.n_med_end;
-    const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
-    // persistent grid: what the chip holds at the kernel's occupancy, or less
-    const int bpc = a.dbg_blocks_per_cu > 0 ? a.dbg_blocks_per_cu : FWD_WAVES_PER_SIMD;
-    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * bpc);
-    if (SNGNN_EXPERIMENTAL && a.dynamic) SN_HIP(hipMemsetAsync(a.dyn_ctr, 0, 2 * DYN_SHARDS * DYN_CTR_STRIDE * sizeof(int32_t), st));
-    if (ev) SN_HIP(hipEventRecord(ev[0], st));
-    if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
-    if (ev) SN_HIP(hipEventRecord(ev[1], st));
-    const bool any_streaming_split = a.k < 0 || a.k > WAVE_T;   // split rows have deg > WAVE_T
-    if (SNGNN_EXPERIMENTAL && a.n_split > 0 && a.k <= CAND_MAX_K && !any_streaming_split && a.inkernel_fin) {
-        // every split row is finalized inside k_agg_fwd by its last-arriving task
-    } else if (a.n_split > 0 && (a.k < 0 || a.k <= CAND_MAX_K)) {
+    if (top_k < 0) return true;                 // no selection: partial rows, candidate launch shape
+    if (top_k > CAND_MAX_K) return false;
+    const int max_slots = std::max(1, ceil_div(max_split_deg, CHUNK) * std::max(top_k, 0));
+    return finc_lds_bytes(C, max_slots) <= FINC_LDS_BUDGET;
+}
+
+// launches of the split rows' finalize (after their tasks, same stream)
+template <int VEC, int G, int R>
+int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
+{
+    if (a.n_split > 0 && a.use_cand) {
         // streaming rows and candidate tournament
         const int max_tasks = ceil_div(max_split_deg, CHUNK);
         const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
-        const size_t dyn = ((size_t)FINC_WAVES * a.C + 1) * 4 + (size_t)max_slots * 24 + 16;
-        if (dyn > 150 * 1024) { set_error("in-degree too large for the split-row finalize"); return SNGNN_EINVAL; }
+        const size_t dyn = finc_lds_bytes(a.C, max_slots);
+        if (dyn > FINC_LDS_BUDGET) { set_error("internal: candidate finalize does not fit LDS"); return SNGNN_EINVAL; }
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
@@ -1224,18 +976,36 @@ int launch_agg_fwd(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStre
         if (a.n_split > n_big)
             k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
     } else if (a.n_split > 0) {
-        const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)(a.k < 0 ? 0 : a.k) * 4;
+        const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)std::min(std::max(a.k, 0), max_split_deg) * 4;
         const size_t budget = 120 * 1024;
+        if (fixed > 150 * 1024) { set_error("top_k too large for the split-row finalize"); return SNGNN_EINVAL; }
         int lds_scores = 0;
         if (fixed < budget) lds_scores = (int)std::min<size_t>((budget - fixed) / 4, (size_t)max_split_deg);
         const size_t dyn = fixed + (size_t)lds_scores * 4;
-        if (dyn > 150 * 1024) { set_error("top_k too large for the split-row finalize"); return SNGNN_EINVAL; }
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         k_agg_fin<VEC, G, R><<<a.n_split, FIN_BLOCK, dyn, st>>>(a, lds_scores);
     }
-    if (ev) SN_HIP(hipEventRecord(ev[2], st));
+    return SNGNN_OK;
+}
+
+template <int VEC, int G, int R>
+int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+{
+    constexpr int RPW = 64 / G;
+    const int n_small = a.N - a.n_med_end;
+    const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
+    // persistent grid: what the chip holds at the kernel's occupancy, or less
+    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
+    if (ev) SN_HIP(hipEventRecord(ev[0], st));
+    if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
+    if (ev) SN_HIP(hipEventRecord(ev[1], st));
+    if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;
+    if (ev) {
+        SN_HIP(hipEventRecord(ev[2], st));
+        SN_HIP(hipEventRecord(ev[3], st));       // empty interval: the cost of an event pair
+    }
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
@@ -1247,17 +1017,8 @@ int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hi
                       hipStream_t st);
 int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
                       hipStream_t st);
-
-#define SNGNN_DISPATCH_GR(FN, VEC, cfg, ...)                                   \
-    switch ((cfg).g * 100 + (cfg).r) {                                         \
-    case 801: return FN<VEC, 8, 1>(__VA_ARGS__);                               \
-    case 1601: return FN<VEC, 16, 1>(__VA_ARGS__);                             \
-    case 3201: return FN<VEC, 32, 1>(__VA_ARGS__);                             \
-    case 6401: return FN<VEC, 64, 1>(__VA_ARGS__);                             \
-    case 6402: return FN<VEC, 64, 2>(__VA_ARGS__);                             \
-    case 6404: return FN<VEC, 64, 4>(__VA_ARGS__);                             \
-    case 6408: return FN<VEC, 64, 8>(__VA_ARGS__);                             \
-    default: sngnn::set_error("unsupported channel layout"); return SNGNN_EINVAL; \
-    }
+int launch_normalize_v1(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
+int launch_normalize_v2(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
+int launch_normalize_v4(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
 
 }  // namespace sngnn

@@ -9,4 +9,10 @@ int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hi
     SNGNN_DISPATCH_GR(launch_agg_fwd, 2, cfg, a, max_split_deg, ev, st)
 }
 
+int launch_normalize_v2(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm,
+                        hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_normalize_rows, 2, cfg, h, rows, C, n, nrm, st)
+}
+
 }  // namespace sngnn

@@ -1,6 +1,5 @@
 // Instantiates the cosine-attention kernels for rows read 2 float(s) per lane.
 #include "attn_impl.h"
-#include "agg_fwd_impl.h"   // SNGNN_DISPATCH_GR
 
 namespace sngnn {
 

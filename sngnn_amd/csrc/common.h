@@ -16,7 +16,6 @@ constexpr int CHUNK = 128;     // deg >  WAVE_T  : split into CHUNK-edge wave ta
 constexpr int BLOCK = 256;     // threads per workgroup of the main kernels
 constexpr int WAVES = BLOCK / 64;
 constexpr int FIN_BLOCK = 1024;   // threads per workgroup of the split-row finalize
-constexpr int FIN_GT_HOST = 6;    // == FIN_GT (agg_fwd_impl.h): tasks per in-kernel finalize group
 constexpr float EPS_NORM = 1e-12f;   // F.normalize eps (models.py:122,238,325)
 
 void set_error(const std::string &msg);
@@ -44,6 +43,8 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Lane layout of one node row for C channels:
 //   VEC floats per lane per step, G lanes per group, R steps  (C <= VEC*G*R).
 struct RowCfg { int vec, g, r; };
+// (the forward, backward, attention and adjacency kernels are instantiated for the layouts
+// this function can return: SNGNN_DISPATCH_GR below)
 inline bool row_cfg(int C, RowCfg &cfg)
 {
     if (C < 1 || C > SNGNN_MAX_CHANNELS) return false;
@@ -59,7 +60,26 @@ inline bool row_cfg(int C, RowCfg &cfg)
     return true;
 }
 
+// bytes of the forward's unit-row table + norms in front of its scratch inside the workspace
+// (256-byte aligned regions)
+inline int64_t fwd_table_bytes(int64_t Ntot, int C)
+{
+    return (Ntot * (int64_t)C * 4 + 255) / 256 * 256 + (Ntot * 4 + 255) / 256 * 256;
+}
+
 }  // namespace sngnn
+
+#define SNGNN_DISPATCH_GR(FN, VEC, cfg, ...)                                   \
+    switch ((cfg).g * 100 + (cfg).r) {                                         \
+    case 801: return FN<VEC, 8, 1>(__VA_ARGS__);                               \
+    case 1601: return FN<VEC, 16, 1>(__VA_ARGS__);                             \
+    case 3201: return FN<VEC, 32, 1>(__VA_ARGS__);                             \
+    case 6401: return FN<VEC, 64, 1>(__VA_ARGS__);                             \
+    case 6402: return FN<VEC, 64, 2>(__VA_ARGS__);                             \
+    case 6404: return FN<VEC, 64, 4>(__VA_ARGS__);                             \
+    case 6408: return FN<VEC, 64, 8>(__VA_ARGS__);                             \
+    default: sngnn::set_error("unsupported channel layout"); return SNGNN_EINVAL; \
+    }
 
 // The graph object behind the opaque handle.
 struct sngnn_graph {
@@ -74,14 +94,7 @@ struct sngnn_graph {
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
-    int32_t *xtask_list = nullptr;    // [n_tasks] task ids grouped by the eighth of the node range their
-    int32_t *xtask_ptr = nullptr;     // [9]       sources fall in (one group per XCD: L2 affinity)
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
-    int32_t *dyn_ctr = nullptr;       // [16 * 32] work counters of the forward kernel (zeroed per launch)
-    int32_t *split_cnt = nullptr;     // [n_split] groups arrived (in-kernel finalize); 0 between launches
-    int32_t *grp_cnt = nullptr;       // [n_groups] tasks arrived per group of FIN_GT tasks
-    int32_t *split_grp0 = nullptr;    // [n_split+1] first group of each split row
-    int n_groups = 0;
     // split sources (out-degree > WAVE_T) = the first n_ssplit slots of sperm
     int32_t *stask_slot = nullptr, *stask_chunk = nullptr;  // [n_stasks]
     int32_t *ssplit_task0 = nullptr;  // [n_ssplit+1]

@@ -21,10 +21,10 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
 // with ds_swizzle / bpermute.  The order is fixed and identical in every kernel.
 template <int G> __device__ __forceinline__ float group_sum(float v)
 {
-    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group width");
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group width");
     v = dpp_add<0xB1>(v);      // xor 1
     v = dpp_add<0x4E>(v);      // xor 2
-    v = dpp_add<0x141>(v);     // other quad of the 8
+    if constexpr (G >= 8) v = dpp_add<0x141>(v);      // other quad of the 8
     if constexpr (G >= 16) v = dpp_add<0x140>(v);     // other half of the 16
     if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
     if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
@@ -84,6 +84,13 @@ __device__ __forceinline__ unsigned long long sel_key(float s, unsigned idx)
 {
     return ((unsigned long long)f2key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
+
+// Correctly rounded fp32 square root and division.  Plain sqrtf() and `/` ARE that under
+// hipcc's defaults (-fhip-fp32-correctly-rounded-divide-sqrt; the build passes no fast-math
+// flag) - unlike HIP's __fsqrt_rn(), which ROCm 7.2's headers map to the approximate
+// __ocml_native_sqrt_f32 unless OCML_BASIC_ROUNDED_OPERATIONS is defined.
+__device__ __forceinline__ float ieee_sqrt(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float ieee_div(float a, float b) { return a / b; }
 
 // One node row spread over the G lanes of a group: lane lg holds VEC consecutive
 // channels per step, R steps.  Channels beyond C read as zero.
@@ -184,6 +191,15 @@ template <int VEC, int G, int R> struct Row {
             for (int v = 0; v < VEC; ++v) x[r][v] = x[r][v] / d;
     }
 
+    // x / d, correctly rounded (F.normalize's division)
+    __device__ __forceinline__ void div_rn(float d)
+    {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[r][v] = ieee_div(x[r][v], d);
+    }
+
     // sum the per-group rows of a wave (all lanes end with the total)
     __device__ __forceinline__ void reduce_across_groups()
     {
@@ -207,29 +223,17 @@ __device__ __forceinline__ float inv_norm_of(float sumsq)
 // F.normalize clamps the norm at eps; below it the normalisation is a plain scale
 __device__ __forceinline__ bool norm_clamped(float sumsq) { return sumsq < EPS_NORM * EPS_NORM; }
 
-// cosine of target row a (inverse norm inv_i) and source row x.
-// SNGNN_IEEE_COSINE=1 (build switch, off): <a, x> / (|a| |x|) with IEEE square roots and
-// division instead of d * (inv_i * inv_j).  Exactly parallel rows with a single non-zero
-// channel (common behind a ReLU; every pair when C == 1) then give EXACTLY +-1, as the
-// reference's normalise-then-dot does, so those ties fall to the edge position on both sides
-// instead of being decided by the last ulp.  Measured: +10 % on the forward kernel (59.5 ->
-// 65.4 us); a recompute only for |s| ~ 1 was slower still (68 us: registers).  All parity
-// tests pass either way; the default keeps the fast form and the near-tie rule of the tests.
-#ifndef SNGNN_IEEE_COSINE
-#define SNGNN_IEEE_COSINE 0
-#endif
+// cosine of target row a (inverse norm inv_i) and source row x from the UN-normalised rows:
+// <a, x> * (inv_i * inv_j).  Used by the backward and the attention mode, where the value
+// only has to be accurate; the selecting forward scores unit rows instead (agg_fwd_impl.h:
+// normalise-then-dot, so that equal unit rows give equal bits).
 template <int VEC, int G, int R>
 __device__ __forceinline__ float edge_score(const Row<VEC, G, R> &a, float inv_i,
                                             const Row<VEC, G, R> &x)
 {
     float d = group_sum<G>(a.dot_partial(x));
     float q = group_sum<G>(x.dot_partial(x));
-#if SNGNN_IEEE_COSINE
-    const float qi = group_sum<G>(a.dot_partial(a));
-    const float s = d / (fmaxf(sqrtf(qi), EPS_NORM) * fmaxf(sqrtf(q), EPS_NORM));
-#else
     const float s = d * (inv_i * inv_norm_of(q));
-#endif
     return s + 0.0f;     // -0.0 -> +0.0: the reference orders floats, not bit patterns
 }
 

@@ -95,20 +95,6 @@ __global__ void k_row_desc(const int32_t *__restrict__ rperm, const int32_t *__r
     desc[p] = make_int4(i, rs, rowptr[i + 1] - rs, 0);
 }
 
-// eighth of the source-id range that the middle edge of each split-row task reads
-// (edges of a row are sorted by source, so a task's sources are a narrow band)
-__global__ void k_task_bucket(const int32_t *__restrict__ task_slot, const int32_t *__restrict__ task_chunk,
-                              const int4 *__restrict__ rdesc, const int32_t *__restrict__ col,
-                              int64_t Ntot, int n_tasks, int32_t *__restrict__ bucket)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tasks) return;
-    const int4 d = rdesc[task_slot[t]];
-    const int e0 = task_chunk[t] * CHUNK, e1 = min(d.z, e0 + CHUNK);
-    const int64_t mid = col[d.y + (e0 + e1) / 2];
-    bucket[t] = (int32_t)min<int64_t>(7, mid * 8 / max<int64_t>(Ntot, 1));
-}
-
 __global__ void k_degree(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ deg)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,39 +291,6 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if ((rc = build_tasks(g->rdeg, g->n_split, &g->task_slot, &g->task_chunk, &g->split_task0,
                           &g->split_soff, &g->n_tasks, &g->split_edges)))
         return rc;
-    if ((rc = dev_alloc(&g->dyn_ctr, 2 * 64 * 32))) return rc;     // 2 classes x DYN_SHARDS x 128 B
-    {   // split-row tasks grouped by the XCD whose L2 should hold their source rows
-        std::vector<int32_t> bucket((size_t)g->n_tasks, 0), list((size_t)g->n_tasks, 0), ptr(9, 0);
-        if (g->n_tasks > 0) {
-            DevBuf db;
-            if (db.alloc((size_t)g->n_tasks * 4)) { set_error("out of device memory (graph build)"); return SNGNN_ENOMEM; }
-            k_task_bucket<<<grid1(g->n_tasks), 256, 0, st>>>(g->task_slot, g->task_chunk, g->rdesc, g->col,
-                                                            Ntot, g->n_tasks, db.as<int32_t>());
-            SN_HIP(hipMemcpy(bucket.data(), db.p, (size_t)g->n_tasks * 4, hipMemcpyDeviceToHost));
-        }
-        for (int t = 0; t < g->n_tasks; ++t) ptr[bucket[t] + 1]++;
-        for (int x = 0; x < 8; ++x) ptr[x + 1] += ptr[x];
-        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-        for (int t = 0; t < g->n_tasks; ++t) list[fill[bucket[t]]++] = t;      // stable: big rows first
-        if ((rc = dev_alloc(&g->xtask_list, g->n_tasks)) || (rc = dev_alloc(&g->xtask_ptr, 9))) return rc;
-        if (g->n_tasks > 0)
-            SN_HIP(hipMemcpy(g->xtask_list, list.data(), (size_t)g->n_tasks * 4, hipMemcpyHostToDevice));
-        SN_HIP(hipMemcpy(g->xtask_ptr, ptr.data(), 9 * 4, hipMemcpyHostToDevice));
-    }
-    {   // groups of FIN_GT tasks for the in-kernel finalize
-        std::vector<int32_t> g0((size_t)g->n_split + 1, 0);
-        for (int p = 0; p < g->n_split; ++p) {
-            const int nt = (g->rdeg[p] + CHUNK - 1) / CHUNK;
-            g0[p + 1] = g0[p] + (nt + FIN_GT_HOST - 1) / FIN_GT_HOST;
-        }
-        g->n_groups = g0[g->n_split];
-        if ((rc = dev_alloc(&g->split_grp0, g->n_split + 1)) || (rc = dev_alloc(&g->grp_cnt, g->n_groups)) ||
-            (rc = dev_alloc(&g->split_cnt, g->n_split)))
-            return rc;
-        SN_HIP(hipMemcpy(g->split_grp0, g0.data(), g0.size() * 4, hipMemcpyHostToDevice));
-        SN_HIP(hipMemsetAsync(g->split_cnt, 0, (size_t)std::max(g->n_split, 1) * 4, st));
-        SN_HIP(hipMemsetAsync(g->grp_cnt, 0, (size_t)std::max(g->n_groups, 1) * 4, st));
-    }
     g->n_ssplit = g->srcs_gt(WAVE_T);
     if ((rc = build_tasks(g->sdeg, g->n_ssplit, &g->stask_slot, &g->stask_chunk, &g->ssplit_task0,
                           nullptr, &g->n_stasks, nullptr)))
@@ -393,7 +346,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
-                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->split_cnt, g->grp_cnt, g->split_grp0, g->xtask_list, g->xtask_ptr, g->dyn_ctr,
+                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
@@ -409,11 +362,11 @@ int64_t sngnn_graph_src_min(const sngnn_graph_t *g) { return g ? g->src_min : -1
 int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {
     if (!g || C < 1) return -1;
-    // forward: scores of split rows | one partial row per split task
-    int64_t fwd = (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
-                  (int64_t)g->n_tasks * 32 * 8 +     // + CAND_MAX_K candidate keys per task
-                  (int64_t)g->n_groups * 32 * 8 +    // + champions per finalize group
-                  (int64_t)g->n_tasks * 32 * 4;      // + candidate source ids
+    // forward: unit rows | norms | scores of split rows | one partial row per split task |
+    //          CAND_MAX_K candidate keys and source ids per task
+    int64_t fwd = sngnn::fwd_table_bytes(g->Ntot, C) +
+                  (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
+                  (int64_t)g->n_tasks * 32 * 8 + (int64_t)g->n_tasks * 32 * 4;
     // backward: {w, ds} record per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     //           (attention mode: 2 rows + 4 scalars) | partS (2 rows) per split-source task

@@ -53,20 +53,23 @@ class Graph:
         self.num_edges = int(lib.sngnn_graph_num_edges(handle))
         self.max_in_degree = int(lib.sngnn_graph_max_in_degree(handle))
         self.src_min = int(lib.sngnn_graph_src_min(handle))
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
 
     @property
     def handle(self):
         return self._h
 
     def workspace(self, channels: int) -> torch.Tensor:
-        """Scratch for forward/backward at ``channels`` (cached per width; calls on
-        one graph are expected on one stream at a time)."""
-        ws = self._ws.get(channels)
+        """Scratch for forward/backward at ``channels``: one buffer per (width, stream), so
+        calls on the same graph from different streams never share scratch (the entry
+        points are re-entrant per stream).  Allocated on first use, i.e. outside any capture
+        that later replays the call (``GraphedEpoch`` runs an eager pass first)."""
+        key = (channels, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
             nbytes = int(_lib.load().sngnn_graph_workspace_bytes(self._h, channels))
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            self._ws[channels] = ws
+            self._ws[key] = ws
         return ws
 
     def array(self, name: str) -> np.ndarray:

@@ -61,6 +61,44 @@ def aggregate_forward(graph: Graph, h: torch.Tensor, top_k: Optional[int], thr: 
     return out, wsel, inv, sel_src, sel_w
 
 
+def normalize_rows(h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``sngnn_normalize_rows``: F.normalize(h, p=2, dim=-1) (models.py:122,238,325) with IEEE
+    square root and division.  Returns (unit rows [rows, C], clamped norms [rows])."""
+    h = _check_rows(h, h.size(0), "h")
+    n = torch.empty_like(h)
+    nrm = torch.empty(h.size(0), dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        rc = _lib.load().sngnn_normalize_rows(h.data_ptr(), h.size(0), h.size(1), n.data_ptr(),
+                                              nrm.data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_normalize_rows")
+    return n, nrm
+
+
+def aggregate_forward_normalized(graph: Graph, n: torch.Tensor, nrm: torch.Tensor,
+                                 top_k: Optional[int], thr: float, *, want_selection: bool = False):
+    """``sngnn_agg_forward_normalized``: the aggregation on unit rows + norms that the caller
+    already holds.  Returns (out, sel_src, sel_w)."""
+    lib = _lib.load()
+    n = _check_rows(n, graph.num_total_nodes, "n")
+    if nrm.dtype != torch.float32 or nrm.numel() != graph.num_total_nodes or not nrm.is_cuda:
+        raise ValueError("nrm must be a float32 GPU tensor with one entry per feature row")
+    nrm = nrm.contiguous()
+    c = n.size(1)
+    k = -1 if top_k is None else int(top_k)
+    out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=n.device)
+    sel_src = sel_w = None
+    if want_selection:
+        sel_src = torch.empty((graph.num_nodes, k), dtype=torch.int32, device=n.device)
+        sel_w = torch.empty((graph.num_nodes, k), dtype=torch.float32, device=n.device)
+    ws = graph.workspace(c)
+    with torch.cuda.device(n.device):
+        rc = lib.sngnn_agg_forward_normalized(graph.handle, n.data_ptr(), nrm.data_ptr(), c, k, float(thr),
+                                              out.data_ptr(), None, None, _lib.ptr(sel_src),
+                                              _lib.ptr(sel_w), ws.data_ptr(), _stream(n.device))
+    _lib.check(rc, "sngnn_agg_forward_normalized")
+    return out, sel_src, sel_w
+
+
 def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
                        wsel: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()

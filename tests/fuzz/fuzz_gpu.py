@@ -56,7 +56,7 @@ while time.time() < t_end:
         near = 0
         if k:
             _, _, _, ss, sw = ops.aggregate_forward(g, hg.detach(), k, thr, want_selection=True)
-            near = check_selection(ref, ss, sw, k, thr, strict=False)
+            near = check_selection(ref, ss, sw, k, thr, strict=(C == 1), h=h)
         if near == 0 and C > 1:
             err = (out.detach().cpu() - ref["out"]).abs()
             assert (err <= 4e-6 + 2e-5 * ref["out"].abs()).all(), f"out err {err.max():.3e}"

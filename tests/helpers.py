@@ -25,13 +25,17 @@ def random_graph(n, e, seed, hubs=()):
     return torch.from_numpy(np.stack([key // n, key % n]))
 
 
-def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict):
+def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None):
     """Compare the GPU's per-row selection with the oracle's.
 
     Rows that agree exactly pass.  A row that differs is accepted only when the
     difference is explained by a near tie (oracle cosines within TIE_TOL of each
-    other or of thr) - and never when ``strict``.  Returns the number of rows that
-    needed the near-tie rule."""
+    other or of thr) - and never when ``strict``.  With ``h`` (the operator's input rows) a
+    differing row must not involve a structural exact tie either.  Returns the number of rows
+    that needed the near-tie rule."""
+    unit = None
+    if h is not None:
+        unit = torch.nn.functional.normalize(torch.as_tensor(h).detach().cpu().float(), p=2., dim=-1).numpy()
     sel_o = res["sel_src"].numpy()
     sel_g = sel_src_gpu.cpu().numpy().astype(np.int64)
     diff_rows = np.flatnonzero((sel_o != sel_g).any(axis=1))
@@ -60,6 +64,20 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict):
             picked.append(sc[c])
         picked = np.asarray(picked, np.float32)
         assert picked.size <= top_k
+        # A STRUCTURAL exact tie - the two sources' products with the target's unit row are
+        # the same bits channel by channel (duplicate rows, power-of-two multiples, rows with
+        # one non-zero channel, C == 1), so the cosines are equal in ANY summation order - is
+        # decided by the edge position on both sides: the kernel scores normalise-then-dot
+        # like the reference.  (Two unrelated cosines that merely round to the same float in
+        # one summation order are an ordinary near tie.)
+        if unit is not None:
+            want = sel_o[i][sel_o[i] >= 0]
+            for r in range(min(want.size, got.size)):
+                if want[r] != got[r]:
+                    pw, pg = unit[i] * unit[int(want[r])], unit[i] * unit[int(got[r])]
+                    assert not np.array_equal(pw, pg), \
+                        f"row {i} rank {r}: structural tie between sources {want[r]} and {got[r]} " \
+                        "broken differently from the reference"
         assert (picked >= thr32 - TIE_TOL).all(), f"row {i}: kept an edge below thr"
         assert (np.diff(picked) <= TIE_TOL).all(), f"row {i}: not in rank order"
         rest = sc[~used]

@@ -48,10 +48,10 @@ def test_forward_backward_sweep(cuda, C, k, thr):
     near = 0
     if k:
         _, _, _, sel_src, sel_w = ops.aggregate_forward(g, hg.detach(), k, thr, want_selection=True)
-        near = check_selection(ref, sel_src, sel_w, k, thr, strict=False)
-        # C == 1: every cosine is exactly +-1 in the reference (ties broken by position),
-        # +-1 within an ulp here - any valid top-k under the near-tie rule is accepted
-        assert near <= 3 or C == 1
+        # C == 1: every cosine is exactly +-1 in the reference and the ties fall to the edge
+        # position - the selection must be identical, no near-tie rule
+        near = check_selection(ref, sel_src, sel_w, k, thr, strict=(C == 1), h=h)
+        assert near <= 3
     if near == 0:
         assert_close(out, ref["out"], rtol=2e-5, atol=4e-6)
         scale = h_ref.grad.abs().max().clamp_min(1e-20)

@@ -7,6 +7,12 @@
 #include <cstdlib>
 #include <vector>
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_nt(const float4 *p)
+{
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 constexpr int C = 40, CH = C / 4, RPI = 64 / CH;   // 10 chunks per row, 6 rows per DMA instruction
@@ -76,6 +82,87 @@ __global__ __launch_bounds__(256) void k_c32(const float *__restrict__ ha, const
             const int e = base + u * 8 + gid;
             const int j = e < E ? ids[e] : 0;
             x[u] = *reinterpret_cast<const float4 *>(ha + (size_t)j * 32 + lg * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+
+// rows of C floats at a padded stride of STRIDE floats (alignment / sector experiments)
+template <int U, int STRIDE, bool NT>
+__global__ __launch_bounds__(256) void k_stride(const float *__restrict__ h, const int *__restrict__ ids,
+                                                int E, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, gid = lane >> 4, lg = lane & 15;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * 4 * U; base < E; base += nw * 4 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 4 + gid;
+            const int j = e < E ? ids[e] : 0;
+            const float4 *p = reinterpret_cast<const float4 *>(h + (size_t)j * STRIDE + (lg < CH ? lg : 0) * 4);
+            x[u] = NT ? ld_nt(p) : *p;
+            if (lg >= CH) x[u] = make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+// W-float rows (W = 16: 64 B, W = 32: 128 B, W = 8: 32 B), W/4 lanes per row, 256/W rows per instruction
+template <int U, int W, bool NT>
+__global__ __launch_bounds__(256) void k_narrow(const float *__restrict__ ha, const int *__restrict__ ids,
+                                                int E, float *__restrict__ out)
+{
+    constexpr int G = W / 4, RPI_ = 64 / G;
+    const int lane = threadIdx.x & 63, gid = lane / G, lg = lane % G;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * RPI_ * U; base < E; base += nw * RPI_ * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * RPI_ + gid;
+            const int j = e < E ? ids[e] : 0;
+            const float4 *p = reinterpret_cast<const float4 *>(ha + (size_t)j * W + lg * 4);
+            x[u] = NT ? ld_nt(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[wave] = s;
+}
+
+// split layout with the A stream non-temporal (so that it does not evict the small B table from L2)
+template <int U, bool NTA>
+__global__ __launch_bounds__(256) void k_split2(const float *__restrict__ ha, const float *__restrict__ hb,
+                                                const int *__restrict__ ids, int E, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, gid = lane >> 4, lg = lane & 15;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = gridDim.x * 4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int base = wave * 4 * U; base < E; base += nw * 4 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * 4 + gid;
+            const int j = e < E ? ids[e] : 0;
+            const float4 *pa = reinterpret_cast<const float4 *>(ha + (size_t)j * 32 + (lg & 7) * 4);
+            const float4 *pb = reinterpret_cast<const float4 *>(hb + (size_t)j * 8 + (lg & 1) * 4);
+            if (lg < 8) x[u] = NTA ? ld_nt(pa) : *pa;
+            else if (lg < 10) x[u] = *pb;
+            else x[u] = make_float4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
@@ -181,18 +268,30 @@ int main()
                (double)E * C * 4 / (best * 1e-3) / 1e9, sum);
         fflush(stdout);
     };
-    for (int bpc : {4, 6, 8}) {
+    // padded tables for the stride experiments (same row contents)
+    float *dh192, *dh256;
+    {
+        std::vector<float> p192((size_t)N * 48, 0.f), p256((size_t)N * 64, 0.f);
+        for (int i = 0; i < N; ++i)
+            for (int c = 0; c < C; ++c) { p192[(size_t)i * 48 + c] = hh[(size_t)i * C + c]; p256[(size_t)i * 64 + c] = hh[(size_t)i * C + c]; }
+        CK(hipMalloc(&dh192, p192.size() * 4)); CK(hipMalloc(&dh256, p256.size() * 4));
+        CK(hipMemcpy(dh192, p192.data(), p192.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dh256, p256.data(), p256.size() * 4, hipMemcpyHostToDevice));
+    }
+    for (int bpc : {6, 8}) {
         const int grid = 256 * bpc;
         printf("-- %d blocks/CU\n", bpc);
-        run("reg U=4", [&] { k_reg<4><<<grid, 256>>>(dh, di, E, dout); });
-        run("split 128+32 U=4", [&] { k_split<4><<<grid, 256>>>(dha, dhb, di, E, dout); });
-        run("split 128+32 U=8", [&] { k_split<8><<<grid, 256>>>(dha, dhb, di, E, dout); });
-        run("C=32 only (128-B rows) U=4", [&] { k_c32<4><<<grid, 256>>>(dha, di, E, dout); });
-        run("reg U=8", [&] { k_reg<8><<<grid, 256>>>(dh, di, E, dout); });
-        run("reg U=16", [&] { k_reg<16><<<grid, 256>>>(dh, di, E, dout); });
-        run("dma NI=2 (12 rows/batch)", [&] { k_dma<2><<<grid, 256>>>(dh, di, E, dout); });
-        run("dma NI=4 (24 rows/batch)", [&] { k_dma<4><<<grid, 256>>>(dh, di, E, dout); });
-        if (bpc <= 6) run("dma NI=6 (36 rows/batch)", [&] { k_dma<6><<<grid, 256>>>(dh, di, E, dout); });
+        run("reg U=4 (stride 160)", [&] { k_reg<4><<<grid, 256>>>(dh, di, E, dout); });
+        run("stride 160 nt", [&] { k_stride<4, 40, true><<<grid, 256>>>(dh, di, E, dout); });
+        run("stride 192", [&] { k_stride<4, 48, false><<<grid, 256>>>(dh192, di, E, dout); });
+        run("stride 256", [&] { k_stride<4, 64, false><<<grid, 256>>>(dh256, di, E, dout); });
+        run("128-B rows (8 rows/instr)", [&] { k_narrow<4, 32, false><<<grid, 256>>>(dha, di, E, dout); });
+        run("128-B rows nt", [&] { k_narrow<4, 32, true><<<grid, 256>>>(dha, di, E, dout); });
+        run("64-B rows (16 rows/instr)", [&] { k_narrow<4, 16, false><<<grid, 256>>>(dha, di, E, dout); });
+        run("64-B rows U=8", [&] { k_narrow<8, 16, false><<<grid, 256>>>(dha, di, E, dout); });
+        run("32-B rows (32 rows/instr)", [&] { k_narrow<4, 8, false><<<grid, 256>>>(dhb, di, E, dout); });
+        run("split 128+32", [&] { k_split2<4, false><<<grid, 256>>>(dha, dhb, di, E, dout); });
+        run("split 128(nt)+32", [&] { k_split2<4, true><<<grid, 256>>>(dha, dhb, di, E, dout); });
     }
     return 0;
 }

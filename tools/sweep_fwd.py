@@ -1,46 +1,44 @@
 #!/usr/bin/env python3
-"""Tuning aid: time the forward's main kernel per row class and per grid size
-(HIP events inside the library).  Run on the GPU box."""
+"""Measurement aid: device time of the forward's launches (HIP events inside the library,
+event-pair overhead taken off) and the wall time per call of a back-to-back loop, per
+(top_k, thr) regime.  Run on the GPU box:  python tools/sweep_fwd.py [workload] [channels]"""
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SNGNN_DEBUG_LIVE"] = "1"
 import bench  # noqa: E402
 from sngnn_amd import _lib, ops  # noqa: E402
 from sngnn_amd.graph import Graph  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
-n, c, ei, x, h, lin = bench.make_rank_inputs("arxiv", 0, 1, 1234, dev)
+workload = sys.argv[1] if len(sys.argv) > 1 else "arxiv"
+channels = int(sys.argv[2]) if len(sys.argv) > 2 else None
+n, c, ei, x, h, lin = bench.make_rank_inputs(workload, 0, 1, 1234, dev, channels)
 g = Graph(ei, n, True, True)
-k, thr = int(os.environ.get("K", 16)), float(os.environ.get("THR", 0.0))
-
-
-def timeit(reps=60):
-    lib.sngnn_profile_enable(1)
-    m, f = C.c_float(), C.c_float()
-    ms, fs = [], []
-    for _ in range(reps):
-        ops.aggregate_forward(g, h, k, thr)
-        lib.sngnn_profile_last_forward(C.byref(m), C.byref(f))
-        ms.append(m.value)
-        fs.append(f.value)
-    lib.sngnn_profile_enable(0)
-    return float(np.median(ms[10:])) * 1e3, float(np.median(fs[10:])) * 1e3
-
-
-os.environ["SNGNN_XCD_AFFINITY"] = "0"
-for dyn, fin in ((0, 0), (1, 0), (1, 1)):
-    os.environ["SNGNN_DYNAMIC"] = str(dyn)
-    os.environ["SNGNN_INKERNEL_FIN"] = str(fin)
-    for bpc in (5, 6, 7):
-        os.environ["SNGNN_DEBUG_BLOCKS_PER_CU"] = str(bpc)
-        os.environ["SNGNN_DEBUG_CLASSES"] = "7"
-        med, fm = timeit()
-        print(f"dynamic={dyn} inkernel_fin={fin} blocks/CU={bpc}: main {med:7.1f} us  "
-              f"separate finalize {fm:6.1f} us  total {med + fm:7.1f}", flush=True)
+print(f"workload {workload} C={c} E'={g.num_edges}")
+m, f, z, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
+    res, wall = [], []
+    for rnd in range(int(os.environ.get("ROUNDS", 4))):
+        lib.sngnn_profile_enable(1)
+        for rep in range(12):
+            ops.aggregate_forward(g, h, k, thr)
+            lib.sngnn_profile_last_forward(C.byref(z), C.byref(m), C.byref(f), C.byref(e0))
+            if rep >= 2:
+                res.append(((z.value - e0.value) * 1e3, (m.value - e0.value) * 1e3, (f.value - e0.value) * 1e3))
+        lib.sngnn_profile_enable(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rep in range(50):
+            ops.aggregate_forward(g, h, k, thr)
+        torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) / 50 * 1e6)
+    med = np.median(np.array(res), axis=0)
+    print(f"top_k={k} thr={thr}: normalize {med[0]:6.1f}  main {med[1]:6.1f}  finalize {med[2]:5.1f} us (events)   "
+          f"wall per call {np.median(wall):6.1f} us", flush=True)
