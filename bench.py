@@ -11,7 +11,15 @@ removed, C=40 (the config BASELINE.md quotes the roofline target on).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - every
 rank owns an arxiv-sized node range of an N-times larger graph whose sources are
-global, and a step adds the RCCL all-gather of the [n_local, C] feature shards.
+global, and a step adds the RCCL exchange of the feature rows: the halo exchange
+(all-to-all-v of the rows the rank's in-edges reference; default) or the full all-gather
+of the [n_local, C] shards (--exchange allgather).  --locality p draws a fraction p of
+every row's sources from the rank's own range (0 = uniform over all ranks, the worst case
+for a node-range partition); the line reports the bytes each exchange form moves.
+
+--workload products: BASELINE config 5's graph (ogbn-products size) through one
+SNGNN_Plus_Plus layer - adjacency branch (Linear(num_nodes, C) on the sparse adjacency) +
+aggregation + blend - at C = 48 (47 classes padded to 16-byte rows).
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,20 +41,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def algorithmic_bytes(e_prime: int, n: int, c: int) -> int:
+def algorithmic_bytes(e_prime: int, n: int, c: int, plus_plus: bool = False) -> int:
     """per edge one source row (4C) + column index (4) + source
     inverse norm (4); per node row pointer (4) + own row (4C) + own inverse norm (4)
-    + output row (4C)."""
-    return e_prime * (4 * c + 8) + n * (8 * c + 8)
+    + output row (4C).  SNGNN++ adds the adjacency branch: per edge one W^T row (4C) +
+    its index (4), per node one more output row (4C)."""
+    b = e_prime * (4 * c + 8) + n * (8 * c + 8)
+    if plus_plus:
+        b += e_prime * (4 * c + 4) + n * 4 * c
+    return b
 
 
-def make_rank_inputs(name, rank, world, seed, device, channels=None, scale=1.0):
+def backward_bytes(e_prime: int, n_sel: int, n: int, c: int) -> int:
+    """SURVEY.md 8(d), secondary accounting model of the backward (selected-edge formulation):
+    per edge of the static CSC weight + id (8); per kept edge the rows h_src, g'_dst, n_dst
+    (12C) + 8; per node G, h, n, grad_h rows (16C)."""
+    return e_prime * 8 + n_sel * (12 * c + 8) + n * 16 * c
+
+
+def make_rank_inputs(name, rank, world, seed, device, channels=None, scale=1.0, locality=0.0):
     from sngnn_amd import synth
     n, e, f, classes, max_deg, kind, dens = synth.SHAPES[name]
     if scale != 1.0:
         n, e = int(n * scale), int(e * scale)
     rng = np.random.default_rng(seed + 7919 * rank)
     ei = synth.make_edges(rng, n, e, max_deg, n_src=n * world, dst_offset=rank * n)
+    if locality > 0.0 and world > 1:
+        # a fraction of every row's sources comes from the rank's own node range (graphs that
+        # are partitioned by a locality-preserving order look like this); re-coalesced
+        local = rng.random(ei.shape[1]) < locality
+        src = np.where(local, rng.integers(rank * n, (rank + 1) * n, size=ei.shape[1]), ei[0])
+        key = np.unique(src * (n * world + 1) + ei[1])
+        ei = np.stack([key // (n * world + 1), key % (n * world + 1)])
     x = synth.make_features(rng, n, f, kind, dens)
     torch.manual_seed(seed)                     # same lin on every rank
     classes = channels or classes               # conv output width (default: #classes, 1 layer)
@@ -86,10 +112,17 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (exploration only)")
     ap.add_argument("--channels", type=int, default=None,
                     help="conv output width C (default: the dataset's class count, 40 for arxiv)")
+    ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
+                    help="N > 1: how the feature rows reach the ranks that reference them")
+    ap.add_argument("--locality", type=float, default=0.0,
+                    help="N > 1: fraction of a row's sources drawn from the rank's own node range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true")
     args = ap.parse_args()
 
+    # (before anything initialises the HIP runtime, which reads it once: the host driver only
+    # supports dmabuf IPC, and RCCL fails with hipIpcGetMemHandle otherwise)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,29 +150,76 @@ def main():
 
     part = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    plus_plus = args.workload == "products"          # config 5: one SNGNN_Plus_Plus layer
+    if plus_plus and args.channels is None:
+        args.channels = 48                           # 47 classes, rows padded to 16 bytes
+    strong = plus_plus and world > 1                 # config 5 partitions ONE products graph
     n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device,
-                                                 args.channels, args.scale)
+                                                 args.channels, args.scale / world if strong else args.scale,
+                                                 args.locality)
     n_total = n * world
+    plan = plan_f = None
     if world > 1:
-        part = sn_dist.Partition(rank, world, n)
-    graph = Graph(ei, n_total, True, True, row_range=(rank * n, (rank + 1) * n))
+        part = sn_dist.Partition(rank, world, n, exchange=args.exchange)
+    if world > 1 and args.exchange == "halo":
+        plan = sn_dist.HaloPlan(ei, part)
+        graph = Graph(plan.edge_index, plan.table_rows, True, True, row_range=(0, n))
+        table = torch.empty((plan.table_rows, c), dtype=torch.float32, device=device)
+        table[:n] = h_local                          # the rank's own rows: resident, not exchanged
+    elif world > 1:
+        graph = Graph(ei, n_total, True, True, row_range=(rank * n, (rank + 1) * n))
+        table = torch.empty((n_total, c), dtype=torch.float32, device=device)
+    else:
+        graph = Graph(ei, n, True, True)
+        table = h_local
     e_prime = graph.num_edges
 
-    h_full = torch.empty((n_total, c), dtype=torch.float32, device=device) if world > 1 else None
+    def exchange_rows(rows_local, plan_, table_):
+        """rows the rank's edges reference arrive in table_ (RCCL; P2P over gloo in a rehearsal)"""
+        if plan_ is None:
+            dist.all_gather_into_tensor(table_, rows_local)
+        elif rehearsal:
+            table_[n:] = sn_dist._all_to_all_rows(rows_local.index_select(0, plan_.send_idx), plan_.send_counts,
+                                                  plan_.recv_counts, part)
+        else:
+            dist.all_to_all_single(table_[n:], rows_local.index_select(0, plan_.send_idx),
+                                   output_split_sizes=plan_.recv_counts, input_split_sizes=plan_.send_counts)
 
+    if plus_plus:
+        # the adjacency branch: W^T rows [n, C] of Linear(num_nodes, C), sharded by node range
+        gen = torch.Generator(device="cpu").manual_seed(args.seed + 1)
+        wt_local = (torch.randn(n, c, generator=gen) * 0.01).to(device)
+        w_bias = torch.zeros(c, device=device)
+        beta = torch.full((1,), 0.3, device=device)
+        if world > 1:
+            ei_f = ei.flip(0).contiguous()
+            if args.exchange == "halo":
+                plan_f = sn_dist.HaloPlan(ei_f, part)
+                graph_f = Graph(plan_f.edge_index, plan_f.table_rows, True, True, row_range=(0, n))
+                table_w = torch.empty((plan_f.table_rows, c), dtype=torch.float32, device=device)
+                table_w[:n] = wt_local
+            else:
+                graph_f = Graph(ei_f, n_total, True, True, row_range=(rank * n, (rank + 1) * n))
+                table_w = torch.empty((n_total, c), dtype=torch.float32, device=device)
+
+    @torch.no_grad()
     def step():
         if world > 1:
-            dist.all_gather_into_tensor(h_full, h_local)
-            src = h_full
+            exchange_rows(h_local, plan, table)
+        out1 = ops.aggregate_forward(graph, table, args.top_k, args.thr)[0]
+        if not plus_plus:
+            return out1
+        if world > 1:
+            exchange_rows(wt_local, plan_f, table_w)
+            out0 = ops.gather_sum(table_w, w_bias, graph_f)
         else:
-            src = h_local
-        return ops.aggregate_forward(graph, src, args.top_k, args.thr)[0]
+            out0 = ops.adj_linear_forward(graph, wt_local, w_bias)
+        return ops.blend(out0, out1, beta)
 
     def sync_all():
         if world > 1:
@@ -155,15 +235,16 @@ def main():
     torch.cuda.synchronize()
     sync_all()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(e_prime)], dtype=torch.float64, device=device)
+    halo_rows = (plan.n_halo if plan is not None else n_total - n) if world > 1 else 0
+    tt = torch.tensor([dt, float(e_prime), float(halo_rows)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = tt[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         esum = tt[1:].clone()
         dist.all_reduce(esum)
-        dt, e_all = float(tmax.item()), int(esum.item())
+        dt, e_all, halo_all = float(tmax.item()), int(esum[0].item()), int(esum[1].item())
     else:
-        e_all = e_prime
+        e_all, halo_all = e_prime, 0
     ms_per_step = dt / args.steps * 1e3
 
     result = None
@@ -171,10 +252,9 @@ def main():
         # --- roofline leg: device time of the dominant kernel, HIP events on its stream
         lib.sngnn_profile_enable(1)
         norms, mains, fins, empties = [], [], [], []
-        src = h_full if world > 1 else h_local
         z, m, f, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
         for _ in range(min(args.steps, 100)):
-            ops.aggregate_forward(graph, src, args.top_k, args.thr)
+            ops.aggregate_forward(graph, table, args.top_k, args.thr)
             _lib.check(lib.sngnn_profile_last_forward(C.byref(z), C.byref(m), C.byref(f), C.byref(e0)),
                        "profile")
             norms.append(z.value)
@@ -195,20 +275,26 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{args.workload}_k{args.top_k}")
             except Exception:
                 traffic = None
+        layer = ("one SNGNN_Plus_Plus layer forward (adjacency branch + aggregation + blend)" if plus_plus
+                 else "SNGNN_Plus aggregation forward")
+        if world == 1:
+            parallelism = "single GPU"
+        else:
+            parallelism = ("node-range partition + RCCL " +
+                           ("halo exchange (all-to-all-v of the referenced rows)" if plan is not None
+                            else "all-gather of h") + (", w sharded by node range" if plus_plus else ""))
         result = {
             "metric": "similarity-aggregation edges/sec",
             "value": e_all / (dt / args.steps),
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ogbn-{args.workload}-sized synthetic graph, SNGNN_Plus "
-                                   f"aggregation forward, top_k={args.top_k}, thr={args.thr}, "
-                                   "self-loops removed",
+            "config": {"workload": f"ogbn-{args.workload}-sized synthetic graph, {layer}, "
+                                   f"top_k={args.top_k}, thr={args.thr}, self-loops removed",
                        "nodes_per_gpu": n, "edges_per_gpu": e_prime, "channels": c,
-                       "parallelism": "node-range partition + RCCL all-gather of h"
-                                      if world > 1 else "single GPU"},
+                       "parallelism": parallelism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_agg_fwd", "kernel_ms": main_ms,
@@ -218,9 +304,23 @@ def main():
                                   f"({pair_ms * 1e3:.1f} us) recorded behind the last launch",
                          "algorithmic_bytes": b_alg},
         }
+        if plus_plus:
+            # the whole ++ layer against its own byte model ("++ branch extra")
+            b_pp = algorithmic_bytes(e_prime, n, c, plus_plus=True)
+            result["roofline_layer"] = {"bound": "hbm", "algorithmic_bytes": b_pp,
+                                        "achieved": b_pp / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": b_pp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "what": "adjacency branch + aggregation + blend over the wall time of a step"}
+        if world > 1:
+            full = (n_total - n) * c * 4
+            result["exchange"] = {"form": args.exchange, "locality": args.locality,
+                                  "rows_received_per_rank": halo_all / world,
+                                  "bytes_received_per_rank": halo_all / world * c * 4,
+                                  "full_allgather_bytes_per_rank": full,
+                                  "fraction_of_allgather": halo_all / world * c * 4 / max(full, 1)}
 
     # --- extras on one GPU: training-mode forward+backward and a full epoch
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not plus_plus:
         hg = h_local.clone().requires_grad_(True)
         gout = torch.randn_like(h_local)
         for _ in range(5):
@@ -233,6 +333,26 @@ def main():
             ops.aggregate(hg, graph, args.top_k, args.thr).backward(gout)
         torch.cuda.synchronize()
         result["fwd_bwd_ms"] = (time.perf_counter() - t0) / reps * 1e3
+        # --- backward roofline (SURVEY.md 8d's B_bwd over the device time of the backward's
+        # launches: torch events on the launch stream, empty-pair overhead taken off)
+        _, wsel, *_ = ops.aggregate_forward(graph, h_local, args.top_k, args.thr, save_for_backward=True)
+        n_sel = int((wsel > -3.0).sum())
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        bw, emp = [], []
+        for _ in range(30):
+            ev[0].record()
+            ops.aggregate_backward(graph, h_local, gout, wsel)
+            ev[1].record()
+            ev[2].record()
+            ev[2].synchronize()
+            bw.append(ev[0].elapsed_time(ev[1]))
+            emp.append(ev[1].elapsed_time(ev[2]))
+        bwd_ms = max(float(np.mean(bw[5:])) - float(np.mean(emp[5:])), 1e-6)
+        b_bwd = backward_bytes(e_prime, n_sel, n, c)
+        result["roofline_bwd"] = {"bound": "hbm", "kernels": "k_bwd_t + k_bwd_s (+ split-row sums)",
+                                  "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd,
+                                  "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if not args.no_epoch:
             from sngnn_amd.train import epoch_time_ms
             # reference-style eager loop (train.py:73-143) and the same epoch replayed

@@ -20,37 +20,73 @@ from . import ops
 from .graph import GLOBAL_CACHE, LOOPS_REPLACE
 
 
+class _Shard:
+    """What a conv layer needs on one rank of a node-range partition: the local graph and
+    how to turn the rank's feature rows into the table that graph's columns address."""
+
+    def __init__(self, edge_index, part, add_loops, remove_loops):
+        self.part = part
+        if part.exchange == "halo":
+            self.plan = sn_dist.HaloPlan(edge_index, part)
+            self.graph = GLOBAL_CACHE.get(self.plan.edge_index, self.plan.table_rows, add_loops, remove_loops,
+                                          row_range=(0, part.n_local))
+        else:
+            self.plan = None
+            self.graph = GLOBAL_CACHE.get(edge_index, part.n_total, add_loops, remove_loops,
+                                          row_range=(part.row_begin, part.row_end))
+
+    def table(self, rows_local: torch.Tensor) -> torch.Tensor:
+        if self.plan is not None:
+            return sn_dist.halo_exchange(rows_local, self.plan)
+        return sn_dist.all_gather_rows(rows_local, self.part)
+
+
+_SHARDS = {}
+
+
+def _shard_for(edge_index, part, add_loops, remove_loops) -> _Shard:
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, str(edge_index.device),
+           id(part), part.exchange, bool(add_loops), int(remove_loops))
+    hit = _SHARDS.get(key)
+    if hit is None:
+        if len(_SHARDS) >= 16:
+            _SHARDS.pop(next(iter(_SHARDS)))
+        hit = (_Shard(edge_index, part, add_loops, remove_loops), edge_index, part)   # keeps the key's objects alive
+        _SHARDS[key] = hit
+    return hit[0]
+
+
 def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remove_loops: bool):
+    """(graph, shard): shard is None on one GPU."""
     if edge_index.device != x.device:
         raise ValueError("x and edge_index must be on the same device")
     part = sn_dist.current_partition()
     if part is None:
-        return GLOBAL_CACHE.get(edge_index, x.size(0), add_loops, remove_loops)
-    return GLOBAL_CACHE.get(edge_index, part.n_total, add_loops, remove_loops,
-                            row_range=(part.row_begin, part.row_end))
+        return GLOBAL_CACHE.get(edge_index, x.size(0), add_loops, remove_loops), None
+    if x.size(0) != part.n_local:
+        raise ValueError(f"under a partition x must be the rank's {part.n_local} rows, got {x.size(0)}")
+    shard = _shard_for(edge_index, part, add_loops, remove_loops)
+    return shard.graph, shard
 
 
 def _lin_aligned(x: torch.Tensor, lin: nn.Linear):
     """``h = lin(x)`` with the channel count rounded up to a multiple of 4 by zero
     weights (returns h and the true width).  Rows of 4k floats are 16-byte aligned, so
     the kernels read them with 16-byte lane loads (2.5x faster than the dword path at
-    C = 47); zero channels change neither a cosine nor a weighted sum, and autograd
-    slices their (zero) gradients away."""
+    C = 47); zero channels change neither a cosine nor a weighted sum, and their (zero)
+    gradients are dropped (ops._Linear: persistent padded buffers, no per-forward cat)."""
     c = lin.out_features
     cp = (c + 3) // 4 * 4
     if cp == c or c < 16 or not x.is_cuda:
         return ops.linear(x, lin), c
-    w = torch.cat([lin.weight, lin.weight.new_zeros(cp - c, lin.in_features)], dim=0)
-    b = None if lin.bias is None else torch.cat([lin.bias, lin.bias.new_zeros(cp - c)])
-    return ops._Linear.apply(x, w, b), c
+    return ops._Linear.apply(x, lin.weight, lin.bias, cp), c
 
 
-def _aggregate(h: torch.Tensor, graph, top_k, thr: float) -> torch.Tensor:
-    """Fused aggregation of the local rows; under a node-range partition the
-    feature shards are all-gathered first (RCCL), see sngnn_amd/dist.py."""
-    part = sn_dist.current_partition()
-    if part is not None:
-        h = sn_dist.all_gather_rows(h, part)
+def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float) -> torch.Tensor:
+    """Fused aggregation of the local rows; under a node-range partition the feature rows
+    the rank's in-edges reference are exchanged first (RCCL), see sngnn_amd/dist.py."""
+    if shard is not None:
+        h = shard.table(h)
     return ops.aggregate(h, graph, top_k, thr)
 
 
@@ -75,9 +111,9 @@ class SNConv(nn.Module):
             self.bias.data.fill_(0)
 
     def forward(self, x, edge_index):
-        graph = _graph_for(x, edge_index, True, False)
+        graph, shard = _graph_for(x, edge_index, True, False)
         h, c = _lin_aligned(x, self.lin)
-        out = _aggregate(h, graph, None, 0.0)[:, :c]
+        out = _aggregate(h, graph, shard, None, 0.0)[:, :c]
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -100,11 +136,10 @@ class AGNNConv(nn.Module):
         self.lin.reset_parameters()
 
     def forward(self, x, edge_index):
-        graph = _graph_for(x, edge_index, True, LOOPS_REPLACE)
+        graph, shard = _graph_for(x, edge_index, True, LOOPS_REPLACE)
         h, c = _lin_aligned(x, self.lin)
-        part = sn_dist.current_partition()
-        if part is not None:
-            h = sn_dist.all_gather_rows(h, part)
+        if shard is not None:
+            h = shard.table(h)
         return ops.attention(h, graph)[:, :c]
 
 
@@ -134,9 +169,9 @@ class SNConv_plus(nn.Module):
             self.bias.data.fill_(0)
 
     def forward(self, x, edge_index):
-        graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
+        graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h, c = _lin_aligned(x, self.lin)
-        out = _aggregate(h, graph, int(self.top_k), float(self.thr))[:, :c]
+        out = _aggregate(h, graph, shard, int(self.top_k), float(self.thr))[:, :c]
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -147,12 +182,25 @@ class _AdjLinearParams(nn.Module):
     (models.py:95).  The weight is stored column-major - ``weight.t()`` is a
     contiguous [N, C] table - so the adjacency branch gathers whole rows; its
     shape, ``state_dict`` key and initial values (same RNG stream as
-    ``nn.Linear(num_nodes, C).reset_parameters()``) are the reference's."""
+    ``nn.Linear(num_nodes, C).reset_parameters()``) are the reference's.
+
+    Built while a node-range partition is active (``sngnn_amd.dist.set_partition``), the
+    module holds only the columns of the rank's own nodes, [C, n_local] - the same values
+    the full initialisation gives those columns - and marks the parameter as sharded."""
 
     def __init__(self, num_nodes: int, out_channels: int):
         super().__init__()
         self.in_features, self.out_features = num_nodes, out_channels
-        self.weight = Parameter(torch.empty(num_nodes, out_channels).t())
+        part = sn_dist.current_partition()
+        self.shard_range = None
+        if part is not None:
+            if part.n_total != num_nodes:
+                raise ValueError("num_nodes must be the partition's N_total")
+            self.shard_range = (part.row_begin, part.row_end)
+        n_cols = num_nodes if self.shard_range is None else part.n_local
+        self.weight = Parameter(torch.empty(n_cols, out_channels).t())
+        if self.shard_range is not None:
+            sn_dist.mark_sharded(self.weight)
         self.bias = Parameter(torch.empty(out_channels))
         self.reset_parameters()
 
@@ -160,7 +208,10 @@ class _AdjLinearParams(nn.Module):
         w = torch.empty(self.out_features, self.in_features, device=self.weight.device)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # nn.Linear.reset_parameters
         with torch.no_grad():
-            self.weight.copy_(w)
+            if self.shard_range is None:
+                self.weight.copy_(w)
+            else:
+                self.weight.copy_(w[:, self.shard_range[0]:self.shard_range[1]])
         bound = 1 / math.sqrt(self.in_features) if self.in_features > 0 else 0
         nn.init.uniform_(self.bias, -bound, bound)
 
@@ -172,6 +223,10 @@ class _AdjLinearParams(nn.Module):
             with torch.no_grad():
                 fixed = w.data.t().contiguous().t()
             self.weight = Parameter(fixed, requires_grad=w.requires_grad)
+            if self.shard_range is not None:
+                sn_dist.mark_sharded(self.weight)
+        elif self.shard_range is not None:
+            sn_dist.mark_sharded(self.weight)
         return self
 
 
@@ -215,27 +270,56 @@ class SNConv_plus_plus(nn.Module):
             self._flip_cache = hit
         return hit[1]
 
+    def _global_src_min(self, edge_index):
+        """models.py:125's ``row - row.min()`` over the post-loop-handling edge list (cached per
+        edge_index): 0 whenever loops are appended and kept."""
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+        hit = getattr(self, "_src_min_cache", None)
+        if hit is None or hit[0] != key:
+            if not self.is_remove_self_loops:
+                m = 0
+            else:
+                keep = edge_index[0] != edge_index[1]
+                m = int(edge_index[0][keep].min()) if bool(keep.any()) else 0
+            hit = (key, m)
+            self._src_min_cache = hit
+        return hit[1]
+
     def forward(self, x, edge_index):
         part = sn_dist.current_partition()
         if part is None and x.size(0) != self.num_nodes:
             raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
                              "(the adjacency branch is Linear(num_nodes, C))")
-        graph = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
+        if part is None and self.w.shard_range is not None:
+            raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
+        graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h, c = _lin_aligned(x, self.lin)
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:
             # multi-GPU: edge_index must hold every edge incident to the owned nodes (the
-            # full list is fine); the out-edges come from the partition of the flipped
-            # list.  w.weight is replicated ([C, N_total]); its gradient is each rank's
-            # partial sum, all-reduced with the other parameters (dist.allreduce_grads).
+            # full list is fine); a node's out-edges come from the partition of the FLIPPED list.
             if part.n_total != self.num_nodes:
                 raise ValueError("num_nodes must be the partition's N_total")
+            if self._global_src_min(edge_index) != 0:
+                raise ValueError("the partitioned adjacency branch needs node 0 to have an out-edge "
+                                 "(models.py:125's row shift would cross the node ranges otherwise)")
             flipped = self._flipped(edge_index)
-            graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
-                                         row_range=(part.row_begin, part.row_end))
-            out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
-        out_1 = _aggregate(h, graph, int(self.top_k), float(self.thr))[:, :c]
+            if self.w.shard_range is not None:
+                # w sharded by node range: W^T rows travel like feature rows, over the flipped list
+                if self.w.shard_range != (part.row_begin, part.row_end):
+                    raise ValueError("w was sharded for a different node range")
+                shard_f = _shard_for(flipped, part, True, bool(self.is_remove_self_loops))
+                wt = self.w.weight.t()
+                table = shard_f.table(wt if wt.is_contiguous() else wt.contiguous())
+                out_0 = ops.gather_sum(table, self.w.bias, shard_f.graph)
+            else:
+                # w.weight replicated ([C, N_total]): its gradient is each rank's partial sum,
+                # all-reduced with the other parameters (dist.allreduce_grads)
+                graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
+                                             row_range=(part.row_begin, part.row_end))
+                out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
+        out_1 = _aggregate(h, graph, shard, int(self.top_k), float(self.thr))[:, :c]
         out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias

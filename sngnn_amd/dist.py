@@ -1,22 +1,33 @@
 """Node-range partitioning over one process per GPU (RCCL over xGMI).
 
-The reference is single-process / single-device; this is new
-design work for graphs that exceed one GPU.  Rank r owns the target nodes
-[r * n_local, (r + 1) * n_local): its rows of x, of the CSR-by-target structure
-(column ids stay global) and of the output.  One exchange per conv layer:
+The reference is single-process / single-device; this is new design work
+for graphs that exceed one GPU (BASELINE config 5).  Rank r owns the target nodes
+[bounds[r], bounds[r + 1]) - any split of [0, N): equal rows (``Partition.even``) or equal
+in-edges (``Partition.edge_balanced``) - i.e. its rows of x, of the CSR-by-target structure
+and of the output.  One exchange per conv layer, two forms:
 
-    forward   h_full = all_gather(h_local)            [P * n_local, C]
-    backward  grad_h_local = reduce_scatter(grad_h_full partials, sum)
+halo (default)   only the feature rows a rank's in-edges actually reference travel.
+                 ``HaloPlan`` (built once per edge list) remaps the rank's columns to a
+                 local table [own rows | halo rows, grouped by owner rank, ascending id];
+                 forward = all-to-all-v of the requested rows, backward = its transpose
+                 (the gradient of a halo row goes back to its owner and is added there in
+                 rank order: deterministic).  RCCL: ``all_to_all_single`` with split sizes;
+                 every peer is one xGMI hop away, so each pair's rows use their own link.
+all-gather       the whole table on every rank (``all_gather_rows``): what the halo form
+                 degenerates to on a graph without locality; kept as the simple baseline
+                 and for the comparison bench.py prints.
 
-Every peer is one xGMI hop away, so RCCL's all-gather moves each shard over its
-own link; shard sizes here are n_local * C * 4 bytes.  Parameter gradients
-(lin.weight / bias, conv bias) are tiny and all-reduced by the caller
-(``allreduce_grads``).
+SNGNN++'s ``Linear(num_nodes, C)`` is sharded by the same node ranges (the rank holds the
+columns of ``w.weight`` of its own nodes): its rows are exchanged like feature rows over
+the FLIPPED edge list, so neither the 460 MB table of products nor its dense gradient is
+ever replicated or all-reduced.  Parameter gradients of the replicated parameters
+(lin.weight / bias, conv bias, beta, batch-norm affine) are tiny and all-reduced by the
+caller (``allreduce_grads``); batch statistics are reduced over the ranks (``sync_batch_norm``).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Optional
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -24,22 +35,77 @@ import torch.distributed as dist
 
 @dataclass
 class Partition:
+    """``Partition(rank, world, n_local)`` (equal shards) or ``Partition(rank, world,
+    bounds=[0, ..., N])`` (any contiguous split)."""
     rank: int
     world: int
-    n_local: int
+    n_local: Optional[int] = None
     group: Optional[object] = None
+    bounds: Optional[Sequence[int]] = None
+    exchange: str = "halo"              # "halo" | "allgather"
+
+    def __post_init__(self):
+        if self.bounds is None:
+            if self.n_local is None:
+                raise ValueError("give n_local (equal shards) or bounds")
+            self.bounds = tuple(r * int(self.n_local) for r in range(self.world + 1))
+        self.bounds = tuple(int(b) for b in self.bounds)
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or \
+                any(a > b for a, b in zip(self.bounds, self.bounds[1:])):
+            raise ValueError("bounds must be world + 1 non-decreasing offsets starting at 0")
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank out of range")
+        if self.exchange not in ("halo", "allgather"):
+            raise ValueError("exchange must be 'halo' or 'allgather'")
+        self.n_local = self.bounds[self.rank + 1] - self.bounds[self.rank]
 
     @property
     def n_total(self) -> int:
-        return self.n_local * self.world
+        return self.bounds[-1]
 
     @property
     def row_begin(self) -> int:
-        return self.rank * self.n_local
+        return self.bounds[self.rank]
 
     @property
     def row_end(self) -> int:
-        return (self.rank + 1) * self.n_local
+        return self.bounds[self.rank + 1]
+
+    @property
+    def sizes(self) -> List[int]:
+        return [b - a for a, b in zip(self.bounds, self.bounds[1:])]
+
+    @staticmethod
+    def even_bounds(n_total: int, world: int) -> Tuple[int, ...]:
+        """Rows split as evenly as possible (the first n_total % world ranks get one more)."""
+        q, r = divmod(int(n_total), world)
+        out = [0]
+        for k in range(world):
+            out.append(out[-1] + q + (1 if k < r else 0))
+        return tuple(out)
+
+    @staticmethod
+    def edge_balanced_bounds(in_degree: torch.Tensor, world: int) -> Tuple[int, ...]:
+        """Contiguous ranges with (nearly) equal numbers of in-edges + rows: rank k ends at
+        the first node where the running cost reaches k / world of the total.  Cost of a
+        node = its in-degree + 1 (the row itself is work too, and empty ranges are avoided)."""
+        cost = in_degree.to(torch.int64).cpu() + 1
+        run = torch.cumsum(cost, 0)
+        total = int(run[-1]) if run.numel() else 0
+        out = [0]
+        for k in range(1, world):
+            target = (total * k + world - 1) // world
+            out.append(max(out[-1], int(torch.searchsorted(run, torch.tensor(target)))))
+        out.append(int(in_degree.numel()))
+        return tuple(out)
+
+    @classmethod
+    def even(cls, rank, world, n_total, **kw):
+        return cls(rank, world, bounds=cls.even_bounds(n_total, world), **kw)
+
+    @classmethod
+    def edge_balanced(cls, rank, world, in_degree, **kw):
+        return cls(rank, world, bounds=cls.edge_balanced_bounds(in_degree, world), **kw)
 
 
 _current: Optional[Partition] = None
@@ -56,30 +122,159 @@ def current_partition() -> Optional[Partition]:
     return _current
 
 
-def _use_fallback(t: torch.Tensor, group=None) -> bool:
-    # gloo (CPU tests, and multi-rank rehearsals on a box with fewer GPUs than ranks) has no
-    # reduce_scatter: list all-gather + all-reduce instead
+def _is_gloo(t: torch.Tensor, group=None) -> bool:
+    # gloo (CPU tests, and multi-rank rehearsals on a box with fewer GPUs than ranks) has neither
+    # reduce_scatter nor all_to_all: point-to-point / list all-gather forms instead
     return (not t.is_cuda) or dist.get_backend(group) == "gloo"
 
 
+# ---------------------------------------------------------------------------
+# all-to-all-v of row blocks
+# ---------------------------------------------------------------------------
+def _all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int],
+                     part: Partition) -> torch.Tensor:
+    """``send`` = [sum(send_counts), C] row blocks ordered by destination rank; returns the
+    [sum(recv_counts), C] blocks ordered by source rank."""
+    c = send.size(1)
+    recv = send.new_empty((int(sum(recv_counts)), c))
+    if not _is_gloo(send, part.group):
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(map(int, recv_counts)),
+                               input_split_sizes=list(map(int, send_counts)), group=part.group)
+        return recv
+    # gloo: point-to-point, staged through host memory for GPU tensors
+    dev = send.device
+    s_host = send.detach().cpu().contiguous() if send.is_cuda else send.contiguous()
+    r_host = torch.empty(recv.shape, dtype=recv.dtype) if send.is_cuda else recv
+    s_off = [0]
+    for n in send_counts:
+        s_off.append(s_off[-1] + int(n))
+    r_off = [0]
+    for n in recv_counts:
+        r_off.append(r_off[-1] + int(n))
+    r_host[r_off[part.rank]:r_off[part.rank + 1]] = s_host[s_off[part.rank]:s_off[part.rank + 1]]
+    ops = []
+    for p in range(part.world):
+        if p == part.rank:
+            continue
+        if send_counts[p]:
+            ops.append(dist.P2POp(dist.isend, s_host[s_off[p]:s_off[p + 1]], p, part.group))
+        if recv_counts[p]:
+            ops.append(dist.P2POp(dist.irecv, r_host[r_off[p]:r_off[p + 1]], p, part.group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return r_host.to(dev) if send.is_cuda else r_host
+
+
+def _exchange_counts(counts: torch.Tensor, part: Partition) -> torch.Tensor:
+    """counts[p] = what I send to p  ->  what p sends to me (int64 [world])."""
+    mine = counts.to(torch.int64)
+    if _is_gloo(mine, part.group):
+        mine = mine.cpu()
+    gathered = [torch.empty_like(mine) for _ in range(part.world)]
+    dist.all_gather(gathered, mine, group=part.group)
+    return torch.stack([g[part.rank] for g in gathered]).cpu()
+
+
+class HaloPlan:
+    """Which remote feature rows this rank's in-edges reference, and who wants which of its
+    own.  Built once per (edge list, partition); the edge list it returns addresses the local
+    table [own rows | halo rows] and keeps the original relative order of the edges (the
+    reference's tie-break is the edge position)."""
+
+    def __init__(self, edge_index: torch.Tensor, part: Partition):
+        r0, r1 = part.row_begin, part.row_end
+        dev = edge_index.device
+        src, dst = edge_index[0], edge_index[1]
+        mine = (dst >= r0) & (dst < r1)
+        src_g = src[mine]
+        own = (src_g >= r0) & (src_g < r1)
+        need = torch.unique(src_g[~own])                       # sorted global ids: grouped by owner
+        b = torch.tensor(part.bounds, dtype=torch.int64, device=dev)
+        owner = torch.searchsorted(b, need, right=True) - 1
+        need_counts = torch.bincount(owner, minlength=part.world)[:part.world]
+        self.part = part
+        self.n_local = part.n_local
+        self.n_halo = int(need.numel())
+        self.recv_counts = [int(v) for v in need_counts.tolist()]           # rows I receive per peer
+        self.send_counts = [int(v) for v in _exchange_counts(need_counts, part).tolist()]
+        # tell every owner which of its rows I need (ids relative to the owner's range)
+        req = (need - b[owner]).to(torch.int64).view(-1, 1).to(torch.float64)   # exact below 2^53
+        got = _all_to_all_rows(req, self.recv_counts, self.send_counts, part)
+        self.send_idx = got.view(-1).to(torch.int64).to(dev)                   # my local rows, by peer
+        if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
+            raise RuntimeError("halo plan: a peer asked for a row outside this rank's range")
+        # local edge list: targets -> [0, n_local), sources -> own id or n_local + halo position
+        src_l = torch.where(own, src_g - r0, self.n_local + torch.searchsorted(need, src_g))
+        self.edge_index = torch.stack([src_l, dst[mine] - r0]).contiguous()
+        self.halo_ids = need
+
+    @property
+    def table_rows(self) -> int:
+        return self.n_local + self.n_halo
+
+    def exchanged_bytes(self, channels: int) -> int:
+        """bytes this rank receives per forward exchange"""
+        return self.n_halo * channels * 4
+
+
+class _HaloExchange(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows_local, plan: HaloPlan):
+        ctx.plan = plan
+        rows_local = rows_local.contiguous()
+        send = rows_local.index_select(0, plan.send_idx)
+        halo = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.part)
+        return torch.cat([rows_local, halo], dim=0)
+
+    @staticmethod
+    def backward(ctx, grad_table):
+        plan = ctx.plan
+        grad_table = grad_table.contiguous()
+        g_own = grad_table[:plan.n_local].clone()
+        back = _all_to_all_rows(grad_table[plan.n_local:], plan.recv_counts, plan.send_counts, plan.part)
+        # peers' contributions in rank order; inside one peer's block the rows are distinct
+        off = 0
+        for n in plan.send_counts:
+            if n:
+                g_own.index_add_(0, plan.send_idx[off:off + n], back[off:off + n])
+            off += n
+        return g_own, None
+
+
+def halo_exchange(rows_local: torch.Tensor, plan: HaloPlan) -> torch.Tensor:
+    """Differentiable: [n_local, C] -> [n_local + n_halo, C] (own rows, then the halo)."""
+    if rows_local.size(0) != plan.n_local:
+        raise ValueError(f"local shard has {rows_local.size(0)} rows, plan says {plan.n_local}")
+    return _HaloExchange.apply(rows_local, plan)
+
+
+# ---------------------------------------------------------------------------
+# full all-gather (baseline)
+# ---------------------------------------------------------------------------
 class _AllGatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_local, part: Partition):
         ctx.part = part
         h_local = h_local.contiguous()
-        full = h_local.new_empty((part.n_total, h_local.size(1)))
-        if _use_fallback(h_local, part.group):
-            chunks = list(full.chunk(part.world, dim=0))
-            dist.all_gather(chunks, h_local, group=part.group)
-        else:
-            dist.all_gather_into_tensor(full, h_local, group=part.group)
+        sizes, c = part.sizes, h_local.size(1)
+        if _is_gloo(h_local, part.group) or len(set(sizes)) > 1:
+            # uneven shards (or gloo): pad to the largest shard, gather, drop the padding
+            mx = max(sizes)
+            pad = h_local.new_zeros((mx, c))
+            pad[:part.n_local] = h_local
+            chunks = [torch.empty_like(pad) for _ in range(part.world)]
+            dist.all_gather(chunks, pad, group=part.group)
+            return torch.cat([ch[:n] for ch, n in zip(chunks, sizes)], dim=0)
+        full = h_local.new_empty((part.n_total, c))
+        dist.all_gather_into_tensor(full, h_local, group=part.group)
         return full
 
     @staticmethod
     def backward(ctx, grad_full):
         part = ctx.part
         grad_full = grad_full.contiguous()
-        if _use_fallback(grad_full, part.group):
+        if _is_gloo(grad_full, part.group) or len(set(part.sizes)) > 1:
             dist.all_reduce(grad_full, group=part.group)
             return grad_full[part.row_begin:part.row_end].clone(), None
         out = grad_full.new_empty((part.n_local, grad_full.size(1)))
@@ -88,23 +283,85 @@ class _AllGatherRows(torch.autograd.Function):
 
 
 def all_gather_rows(h_local: torch.Tensor, part: Partition) -> torch.Tensor:
-    """Differentiable all-gather of equal row shards: [n_local, C] -> [n_total, C]."""
+    """Differentiable all-gather of the row shards: [n_local, C] -> [n_total, C]."""
     if h_local.size(0) != part.n_local:
         raise ValueError(f"local shard has {h_local.size(0)} rows, partition says {part.n_local}")
     return _AllGatherRows.apply(h_local, part)
 
 
+# ---------------------------------------------------------------------------
+# parameters and batch statistics
+# ---------------------------------------------------------------------------
+def mark_sharded(p: torch.nn.Parameter) -> torch.nn.Parameter:
+    """A parameter that is split over the ranks (SNGNN++'s w.weight): its gradient is
+    already complete on its owner and must not be all-reduced."""
+    p._sngnn_sharded = True
+    return p
+
+
 def allreduce_grads(module: torch.nn.Module, part: Partition) -> None:
-    """Sum the (replicated) parameters' gradients over the ranks."""
+    """Sum the REPLICATED parameters' gradients over the ranks."""
     for p in module.parameters():
         g = p.grad
-        if g is None:
+        if g is None or getattr(p, "_sngnn_sharded", False):
             continue
         if g.is_contiguous():
             dist.all_reduce(g, group=part.group)
-        elif g.dim() == 2 and g.t().is_contiguous():      # SNGNN++'s column-major w.weight
+        elif g.dim() == 2 and g.t().is_contiguous():      # SNGNN++'s column-major w.weight (replicated form)
             dist.all_reduce(g.t(), group=part.group)
         else:
             tmp = g.contiguous()
             dist.all_reduce(tmp, group=part.group)
             g.copy_(tmp)
+
+
+class _SyncBatchNorm(torch.autograd.Function):
+    """nn.BatchNorm1d's training-mode forward over the rows of ALL ranks: per-channel sum, sum
+    of squares and row count are all-reduced (one [2C + 1] message), so the statistics, the
+    running estimates and the gradients are those of the single-process batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, part: Partition):
+        c = x.size(1)
+        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.size(0))])])
+        dist.all_reduce(stats, group=part.group)
+        n = stats[-1]
+        mean = stats[:c] / n
+        var = (stats[c:2 * c] / n - mean * mean).clamp_min_(0)            # biased, as BN normalises
+        invstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * invstd
+        if running_mean is not None:
+            with torch.no_grad():
+                unbiased = var * (n / (n - 1).clamp_min(1))
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(unbiased, alpha=momentum)
+        ctx.save_for_backward(xhat, invstd, weight)
+        ctx.part, ctx.n = part, n
+        out = xhat if weight is None else xhat * weight
+        return out if bias is None else out + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, invstd, weight = ctx.saved_tensors
+        gx = g if weight is None else g * weight
+        c = g.size(1)
+        sums = torch.cat([gx.sum(0), (gx * xhat).sum(0)])
+        dist.all_reduce(sums, group=ctx.part.group)
+        dx = (gx - sums[:c] / ctx.n - xhat * (sums[c:] / ctx.n)) * invstd
+        # weight / bias gradients are this rank's partial sums: allreduce_grads completes them
+        gw = (g * xhat).sum(0) if weight is not None else None
+        gb = g.sum(0)
+        return dx, gw, gb, None, None, None, None, None
+
+
+def sync_batch_norm(bn: torch.nn.BatchNorm1d, x: torch.Tensor, part: Partition) -> torch.Tensor:
+    """``bn(x)`` with batch statistics over every rank's rows (training mode); eval mode uses
+    the running estimates and needs no communication."""
+    if not bn.training:
+        return bn(x)
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average batch norm (momentum=None) under a partition")
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _SyncBatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                bn.momentum, part)

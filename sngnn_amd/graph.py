@@ -114,6 +114,12 @@ class GraphCache:
             self._entries[key] = hit
         return hit[0]
 
+    def snapshot(self):
+        """The Graph objects currently cached.  Whoever captured raw pointers of them (a HIP
+        graph holds the CSR arrays and the workspaces of the graphs its kernels were launched
+        on) keeps this list, so eviction from the cache cannot free them under the capture."""
+        return [g for g, _ in self._entries.values()]
+
     def clear(self):
         self._entries.clear()
 

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import dist as sn_dist
 from .conv import AGNNConv, SNConv, SNConv_plus, SNConv_plus_plus
 
 
@@ -27,7 +28,9 @@ class _Stack(nn.Module):
             x = lin(x, edge_index)
             x = F.relu(x, inplace=True)
             if self.bn:
-                x = self.bns[i](x)
+                part = sn_dist.current_partition()
+                # batch statistics over every rank's rows, as the single-process batch has them
+                x = self.bns[i](x) if part is None else sn_dist.sync_batch_norm(self.bns[i], x, part)
             x = self.dropout(x)
         return self.lins[-1](x, edge_index)
 

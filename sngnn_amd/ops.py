@@ -296,6 +296,47 @@ def adj_linear_partition(weight, bias, graph_out: Graph) -> torch.Tensor:
     return _AdjLinearPartition.apply(weight, bias, graph_out)
 
 
+class _GatherSum(torch.autograd.Function):
+    """``out[i] = bias + sum_{q in row i} table[col_q]`` over a graph's CSR rows and its
+    transpose as the gradient (``sngnn_gather_sum_rows`` / ``sngnn_scatter_sum_rows``): the
+    adjacency branch of SNGNN++ on one rank when ``w`` is sharded - ``table`` is then the
+    rank's own rows of W^T followed by the halo rows (sngnn_amd/dist.py), ``graph`` the local
+    form of the flipped edge list."""
+
+    @staticmethod
+    def forward(ctx, table, bias, graph):
+        lib = _lib.load()
+        table = _check_rows(table, graph.num_total_nodes, "table")
+        c = table.size(1)
+        out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=table.device)
+        b = None if bias is None else bias.contiguous()
+        with torch.cuda.device(table.device):
+            rc = lib.sngnn_gather_sum_rows(graph.handle, table.data_ptr(), _lib.ptr(b), c, out.data_ptr(),
+                                           graph.workspace(c).data_ptr(), _stream(table.device))
+        _lib.check(rc, "sngnn_gather_sum_rows")
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g0):
+        lib = _lib.load()
+        g0 = g0.contiguous()
+        gr = ctx.graph
+        c = g0.size(1)
+        dtab = torch.empty((gr.num_total_nodes, c), dtype=torch.float32, device=g0.device)
+        with torch.cuda.device(g0.device):
+            rc = lib.sngnn_scatter_sum_rows(gr.handle, g0.data_ptr(), c, dtab.data_ptr(),
+                                            gr.workspace(c).data_ptr(), _stream(g0.device))
+        _lib.check(rc, "sngnn_scatter_sum_rows")
+        db = g0.sum(dim=0) if ctx.has_bias else None
+        return dtab, db, None
+
+
+def gather_sum(table: torch.Tensor, bias: Optional[torch.Tensor], graph: Graph) -> torch.Tensor:
+    return _GatherSum.apply(table, bias, graph)
+
+
 # ---------------------------------------------------------------------------
 # Callers on either side of the aggregation (SURVEY.md 8f rank 1)
 # ---------------------------------------------------------------------------
@@ -317,11 +358,26 @@ class _Linear(torch.autograd.Function):
     handles poorly), grad_x through rocBLAS only when x needs it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, pad_to=None):
+        """``pad_to``: produce [N, pad_to] with zero channels behind the layer's own (16-byte
+        rows for the aggregation kernels).  The padded weight / bias live in two persistent
+        buffers attached to the weight and are refreshed by two small copies - no
+        concatenation, no allocation and no autograd node per forward."""
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         n, f = x.shape
         c = weight.size(0)
+        ctx.c = c
+        if pad_to is not None and pad_to > c:
+            pad = getattr(weight, "_sngnn_pad", None)
+            if pad is None or pad[0].size(0) != pad_to or pad[0].device != weight.device:
+                pad = (weight.new_zeros((pad_to, f)), weight.new_zeros(pad_to))
+                weight._sngnn_pad = pad
+            pad[0][:c].copy_(weight)
+            if bias is not None:
+                pad[1][:c].copy_(bias)
+            weight, bias = pad[0], (pad[1] if bias is not None else None)
+            c = pad_to
         if c > 64 or n < 4096:          # wide layer or tiny graph: the BLAS is the right tool
             return torch.nn.functional.linear(x, weight, bias)
         xc, wc = x.contiguous(), weight.contiguous()
@@ -339,7 +395,7 @@ class _Linear(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = g.mm(weight)
+            gx = g[:, :ctx.c].mm(weight)             # (the padded channels carry no gradient)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             lib = _lib.load()
             xc = x.contiguous()
@@ -352,14 +408,16 @@ class _Linear(torch.autograd.Function):
                 rc = lib.sngnn_linear_wgrad(g.data_ptr(), xc.data_ptr(), n, c, f, gw.data_ptr(),
                                             _lib.ptr(gb), ws.data_ptr(), _stream(g.device))
             _lib.check(rc, "sngnn_linear_wgrad")
-        return gx, gw, gb
+            gw = gw[:ctx.c]
+            gb = None if gb is None else gb[:ctx.c]
+        return gx, gw, gb, None
 
 
 def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     """Apply ``lin`` with the hand-written weight gradient (fp32 GPU tensors), or
     plain ``lin(x)`` for anything else."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32:
-        return _Linear.apply(x, lin.weight, lin.bias)
+        return _Linear.apply(x, lin.weight, lin.bias, None)
     return lin(x)
 
 

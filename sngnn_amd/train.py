@@ -125,6 +125,11 @@ class GraphedEpoch:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._epoch()
+        # The captured launches hold raw device pointers into the structure arrays and the
+        # workspaces of the graphs the model ran on.  The cache that owns them evicts (FIFO):
+        # keep them alive for as long as this capture can be replayed.
+        from .graph import GLOBAL_CACHE
+        self._held_graphs = GLOBAL_CACHE.snapshot()
 
     def _materialise_adam_state(self):
         """Adam creates its state lazily inside the first ``step()``; inside a capture

@@ -4,6 +4,9 @@ import torch
 from tests.helpers import random_graph
 
 
+BOUNDS = {2: (0, 520, 900)}          # uneven node ranges
+
+
 def build_case(world: int):
     n_local = 450
     n = n_local * world
@@ -22,6 +25,8 @@ def build_model(kind: str, f: int, n: int):
     torch.manual_seed(77)
     if kind == "SNGNN_Plus":
         return sngnn_amd.SNGNN_Plus(f, 16, 6, n, 2, 4, 0.05, 1, 0.0)
+    if kind == "SNGNN_Plus_bn":          # batch norm between the layers (and conv bias, models.py:177-178)
+        return sngnn_amd.SNGNN_Plus(f, 16, 6, n, 2, 4, 0.05, 1, 0.0, True)
     if kind == "SNGNN_Plus_Plus":
         return sngnn_amd.SNGNN_Plus_Plus(f, 16, 6, n, 2, 4, 0.05, 0.4, 1, 0.0)
     if kind == "SNGNN":

@@ -1,6 +1,7 @@
 """GPU: the multi-GPU code path end to end with a one-rank RCCL group (the GPU box has
-one card): partition graphs, all-gather / reduce-scatter autograd seam, the flipped
-partition of SNGNN++ and the gradient all-reduce must reproduce the single-GPU model."""
+one card): partition graphs, the halo exchange's all_to_all_single / the all-gather +
+reduce-scatter autograd seams, the flipped partition of SNGNN++ and the gradient all-reduce
+must reproduce the single-GPU model."""
 import os
 import socket
 
@@ -28,12 +29,13 @@ def one_rank_group(cuda):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
 @pytest.mark.parametrize("kind,args", [
     ("SNGNN", lambda f, n: (f, 16, 5, 2)),
     ("SNGNN_Plus", lambda f, n: (f, 16, 5, n, 2, 4, 0.0, 1, 0.0)),
     ("SNGNN_Plus_Plus", lambda f, n: (f, 16, 5, n, 2, 4, 0.0, 0.4, 1, 0.0)),
 ])
-def test_partition_path_with_one_rank_equals_single_gpu(cuda, one_rank_group, kind, args):
+def test_partition_path_with_one_rank_equals_single_gpu(cuda, one_rank_group, kind, args, exchange):
     import sngnn_amd
     from sngnn_amd import dist as sd
     n, f = 500, 24
@@ -51,7 +53,7 @@ def test_partition_path_with_one_rank_equals_single_gpu(cuda, one_rank_group, ki
     multi.eval()
     data = Data(x=x, edge_index=ei)
     F.nll_loss(single(data), y).backward()
-    part = sd.Partition(0, 1, n)
+    part = sd.Partition(0, 1, n, exchange=exchange)
     sd.set_partition(part)
     try:
         out = multi(data)

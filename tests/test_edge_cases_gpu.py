@@ -97,3 +97,30 @@ def test_views_and_cache_invalidation(cuda):
     b = conv(x, ei_c)
     c = conv(x, ei_c.clone())
     assert torch.equal(b, c) and not torch.equal(a, b)
+
+
+def test_hub_beyond_the_candidate_finalize_budget(cuda):
+    """A hub whose chunk-local candidates would not fit the candidate finalize's LDS budget
+    (> ~51 k in-edges at top_k = 16): the forward must route it through the streaming
+    finalize (scores in HBM scratch) instead of failing, and agree with the C oracle."""
+    from oracle import c_oracle as CO
+    from sngnn_amd import ops
+    from sngnn_amd.graph import Graph
+    n, C, k, thr = 70_000, 8, 16, 0.1
+    rng = np.random.default_rng(3)
+    src = np.concatenate([np.arange(1, 66_001), rng.integers(0, n, size=40_000)])
+    dst = np.concatenate([np.zeros(66_000, np.int64), rng.integers(1, n, size=40_000)])
+    key = np.unique(src.astype(np.int64) * n + dst)
+    ei = torch.from_numpy(np.stack([key // n, key % n]))
+    h = torch.randn(n, C, generator=torch.Generator().manual_seed(2))
+    ref = CO.aggregate(h.numpy(), ei.numpy(), add_loops=True, remove_loops=True, top_k=k, thr=thr)
+    g = Graph(ei.to(cuda), n, True, True)
+    assert g.max_in_degree >= 66_000
+    out, wsel, _, sel_src, sel_w = ops.aggregate_forward(g, h.to(cuda), k, thr, save_for_backward=True,
+                                                         want_selection=True)
+    from tests.helpers import assert_close, check_selection
+    assert_close(out, torch.from_numpy(ref["out"]))
+    res = dict(sel_src=torch.from_numpy(ref["sel_src"]), ei=torch.from_numpy(ref["ei"]),
+               s=torch.from_numpy(ref["s"]))
+    assert check_selection(res, sel_src, sel_w, k, thr, strict=False, h=h) <= 2
+    np.testing.assert_array_equal(sel_src[0].cpu().numpy(), ref["sel_src"][0])      # the hub itself

@@ -111,6 +111,41 @@ def test_graphed_epoch_matches_eager_trajectory(cuda, kind):
             assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (a["epoch"], k, a[k], b[k])
 
 
+def test_graphed_epoch_survives_graph_cache_eviction(cuda):
+    """A captured epoch holds raw pointers into its graphs' structure arrays and workspaces;
+    building more graphs than the cache holds (16, FIFO) between replays must neither free
+    them nor change the replayed metrics."""
+    import sngnn_amd
+    from sngnn_amd import train as T
+    from sngnn_amd import synth
+    from sngnn_amd.graph import GLOBAL_CACHE
+    from tests.helpers import random_graph
+    data = synth.make_dataset("cora", scale=0.5).to(cuda)
+    n, f = data.x.shape
+
+    def run(evict):
+        torch.manual_seed(5)
+        model = sngnn_amd.SNGNN_Plus(f, 16, 7, n, 2, 3, 0.1, 1, 0.0).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
+        ge = T.GraphedEpoch(model, data, opt, warmup=0)
+        recs = []
+        for ep in range(4):
+            if evict:
+                keep = []
+                for q in range(20):                 # more than the cache holds: everything older is evicted
+                    ei = random_graph(300 + q, 2000, seed=100 * ep + q).to(cuda)
+                    keep.append(GLOBAL_CACHE.get(ei, 300 + q, True, bool(q % 2)))
+                    scratch = torch.full((200_000,), float(q), device=cuda)     # recycle freed memory
+                del keep, scratch
+            recs.append(ge.run())
+        return recs
+
+    a, b = run(False), run(True)
+    for ra, rb in zip(a, b):
+        for k in ra:
+            assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (k, ra[k], rb[k])
+
+
 @pytest.mark.parametrize("kind,args,name", [
     ("SNGNN_Plus", lambda f, n: (f, 16, 7, n, 2, 3, 0.1, 1, 0.0), "plus_2layer"),
     ("SNGNN_Plus_Plus", lambda f, n: (f, 16, 7, n, 1, 4, 0.2, 0.3, 1, 0.0), "plusplus_1layer"),
