@@ -84,7 +84,9 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     const int max_split = g->n_split ? g->rdeg[0] : 0;
     a.use_cand = fwd_use_candidates(a.k, C, max_split) ? 1 : 0;
     // split rows whose (tasks * top_k) candidates exceed one 128-key wave selection
-    a.n_split_gt_wave = top_k > 0 ? g->rows_gt((int64_t)(128 / std::min(top_k, 128)) * CHUNK) : 0;
+    // (no selection: split rows with more than 16 partial rows to add)
+    a.n_split_gt_wave = top_k > 0 ? g->rows_gt((int64_t)(128 / std::min(top_k, 128)) * CHUNK)
+                                  : (top_k < 0 ? g->rows_gt((int64_t)16 * CHUNK) : 0);
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
     switch (cfg.vec) {

@@ -773,10 +773,21 @@ __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, in
     int &s_n = sB[max_slots];
 
     if (!rank) {
-        // streaming row (deg <= top_k or no selection): add the tasks' partial rows
+        // streaming row (deg <= top_k or no selection): add the tasks' partial rows.  The
+        // FINC_WAVES waves each sum every FINC_WAVES-th task (their loads in flight together),
+        // then the slices are added in slice order: a fixed order, and a hub's ~100 partial
+        // rows cost a handful of memory round trips instead of one each.
+        for (int c0 = 0; c0 < a.C; c0 += 64) {
+            const int c = c0 + lane;
+            float s = 0.f;
+            if (c < a.C)
+                for (int t = t0 + wave; t < t1; t += FINC_WAVES) s += a.partial[(size_t)t * a.C + c];
+            if (c < a.C) s_part[(size_t)wave * a.C + c] = s;
+        }
+        __syncthreads();
         for (int c = tid; c < a.C; c += FINC_BLOCK) {
             float s = 0.f;
-            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+            for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + c];
             a.out[(size_t)i * a.C + c] = s / (float)deg;
         }
         if (emit) {
@@ -888,9 +899,15 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     const int i = d.x, rs = d.y, deg = d.z;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
     if (a.k < 0) {
+        // (rows of at most 16 tasks come here: their partial rows are loaded together)
         for (int c = lane; c < a.C; c += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = t0 + u < t1 ? a.partial[(size_t)(t0 + u) * a.C + c] : 0.f;
             float s = 0.f;
-            for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+            for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
             a.out[(size_t)i * a.C + c] = s / (float)deg;
         }
         return;
@@ -971,7 +988,9 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
         // (a second launch only pays when there are many such rows: arxiv-like graphs have a
         // few hundred split rows in all, products-like ones 10^5)
         const int n_wave = a.n_split - std::min(a.n_split, a.n_split_gt_wave);
-        const int n_big = (a.k > 0 && n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - n_wave : (a.k > 0 ? a.n_split : 0);
+        // (no selection, k < 0: the split is by the number of partial rows to add, > 16 tasks -> workgroup)
+        const int n_big = a.k < 0 ? a.n_split - n_wave
+                                  : ((a.k > 0 && n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - n_wave : (a.k > 0 ? a.n_split : 0));
         if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
         if (a.n_split > n_big)
             k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);

@@ -65,16 +65,23 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float *__restrict__ 
 // ---------------------------------------------------------------------------
 constexpr int TB_M = 128, TB_K = 32, TB_LD = TB_K + 1, TB_LOADS = TB_M * TB_K / 256;
 
+// Few tiles (N of a few thousand: 171 upper-triangle tiles at Chameleon's size for 256 CUs):
+// the contraction is split over ks workgroups per tile, each writes its raw partial tile
+// (both orientations) to part[s] and k_cosine_reduce adds the ks partials in a fixed order
+// and applies the inverse norms.
 __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x, int64_t N,
                                                      int64_t F, const float *__restrict__ inv,
-                                                     float *__restrict__ S, int nb)
+                                                     float *__restrict__ S, int nb, int ks, int64_t k_per,
+                                                     float *__restrict__ part)
 {
     __shared__ float sA[TB_M * TB_LD];
     __shared__ float sB[TB_M * TB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;          // wave's 64x64 quadrant
     // linear workgroup id -> (by <= bx) of the upper triangle, row by row
-    int by = 0, rem = blockIdx.x;
+    const int split = blockIdx.x % ks;
+    const int64_t k_begin = (int64_t)split * k_per, k_end = min(F, k_begin + k_per);
+    int by = 0, rem = blockIdx.x / ks;
     while (rem >= nb - by) { rem -= nb - by; ++by; }
     const int bx = by + rem;
     const int64_t row0 = (int64_t)by * TB_M, col0 = (int64_t)bx * TB_M;
@@ -95,12 +102,12 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
 #pragma unroll
         for (int u = 0; u < TB_LOADS; ++u) {
             const int64_t r_a = row0 + sr + 8 * u, r_b = col0 + sr + 8 * u;
-            ra[u] = (r_a < N && k < F) ? x[r_a * F + k] : 0.f;
-            rb[u] = diag ? ra[u] : ((r_b < N && k < F) ? x[r_b * F + k] : 0.f);
+            ra[u] = (r_a < N && k < k_end) ? x[r_a * F + k] : 0.f;
+            rb[u] = diag ? ra[u] : ((r_b < N && k < k_end) ? x[r_b * F + k] : 0.f);
         }
     };
-    fetch(0);
-    for (int64_t k0 = 0; k0 < F; k0 += TB_K) {
+    fetch(k_begin);
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += TB_K) {
         __syncthreads();                                  // previous step's LDS reads are done
 #pragma unroll
         for (int u = 0; u < TB_LOADS; ++u) {
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
             sB[(sr + 8 * u) * TB_LD + sc] = rb[u];
         }
         __syncthreads();
-        if (k0 + TB_K < F) fetch(k0 + TB_K);              // in flight during the MFMAs below
+        if (k0 + TB_K < k_end) fetch(k0 + TB_K);          // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < TB_K; kk += 2) {
             float a[2], b[2];
@@ -136,12 +143,32 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
             for (int r = 0; r < 16; ++r) {
                 const int64_t rr = row0 + wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (rr < N && c < N) {
-                    const float v = acc[ta][tb][r] * (inv[rr] * ic);
-                    S[rr * N + c] = v;
-                    if (!diag) S[c * N + rr] = v;         // mirror image of an off-diagonal tile
+                    if (ks == 1) {
+                        const float v = acc[ta][tb][r] * (inv[rr] * ic);
+                        S[rr * N + c] = v;
+                        if (!diag) S[c * N + rr] = v;     // mirror image of an off-diagonal tile
+                    } else {
+                        float *P = part + (size_t)split * N * N;
+                        P[rr * N + c] = acc[ta][tb][r];
+                        if (!diag) P[c * N + rr] = acc[ta][tb][r];
+                    }
                 }
             }
         }
+}
+
+// S = (sum of the ks partial products, in split order) * inv_r * inv_c; workgroup = one row segment
+__global__ __launch_bounds__(256) void k_cosine_reduce(const float *__restrict__ part, int ks, int64_t N,
+                                                       const float *__restrict__ inv, float *__restrict__ S)
+{
+    const int64_t r = blockIdx.y, total = N * N;
+    const float ir = inv[r];
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < N; c += (int64_t)gridDim.x * 256) {
+        const int64_t e = r * N + c;
+        float v = part[e];
+        for (int sp = 1; sp < ks; ++sp) v += part[(size_t)sp * total + e];
+        S[e] = v * (ir * inv[c]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -260,7 +287,20 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     SN_REQUIRE(inv.alloc((size_t)N * 4) == 0, SNGNN_ENOMEM, "out of device memory");
     k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(), nullptr);
     const int nb = (int)((N + TB_M - 1) / TB_M);
-    k_cosine_mfma<<<nb * (nb + 1) / 2, 256, 0, st>>>(x, N, F, inv.as<float>(), S, nb);
+    const int tiles = nb * (nb + 1) / 2;
+    // fewer tiles than two per CU: split the contraction (at least two K-steps per split)
+    int ks = 1;
+    if (tiles < 512) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, F / (2 * TB_K)));
+    const int64_t k_per = ((F + ks - 1) / ks + TB_K - 1) / TB_K * TB_K;
+    ks = (int)((F + k_per - 1) / k_per);
+    AsyncBuf part(st);
+    if (ks > 1) SN_REQUIRE(part.alloc((size_t)ks * N * N * 4) == 0, SNGNN_ENOMEM, "out of device memory");
+    k_cosine_mfma<<<tiles * ks, 256, 0, st>>>(x, N, F, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
+    if (ks > 1) {
+        SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "internal: split contraction is for small N only");
+        k_cosine_reduce<<<dim3((unsigned)std::min<int64_t>((N + 255) / 256, 8), (unsigned)N), 256, 0, st>>>(
+            part.as<float>(), ks, N, inv.as<float>(), S);
+    }
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }

@@ -476,6 +476,56 @@ def make_trajectories(R, write):
                                 **{"init." + k: v for k, v in init.items()}, **final)
 
 
+def make_actor_real(R, write):
+    """Config 3 on the REAL Actor graph the reference bundles (datasets/data/Actor/raw: features,
+    labels, the geom-gcn split 0), the published sweep's hyper-parameters
+    (train_script_SNGNN_plus_plus.sh:5-44: lr 0.1, weight decay 5e-4, dropout 0, 1 layer, top_k 1,
+    thr 0.99, self-loops kept, init_beta 0.3, seed 1234) and the trainer's loop (train.py:73-160)
+    on the reference's own SNGNN_Plus_Plus class: 8 epochs of loss / accuracy + the final
+    parameters.  The features travel as a fixture (data): indices of the non-zero entries."""
+    raw = os.path.join(REFERENCE, "datasets", "data", "Actor", "raw")
+    from sngnn_amd import datasets as DS
+    d = DS.select_split(DS.load_geom_gcn(raw, "film"), 0)
+    n, f = d.x.shape
+    classes = int(d.y.max()) + 1
+    args = (f, 64, classes, n, 1, 1, 0.99, 0.3, 0, 0.0)
+    out = []
+    for lib in (R, O):
+        torch.manual_seed(1234)
+        model = lib.SNGNN_Plus_Plus(*args)
+        init = {k: v.clone().numpy() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.parameters(), lr=0.1, weight_decay=5e-4)
+        traj = []
+        for _ in range(8):
+            model.train()
+            opt.zero_grad()
+            o = model(d)
+            loss = F.nll_loss(o[d.train_mask], d.y[d.train_mask])
+            loss.backward()
+            opt.step()
+            model.eval()
+            with torch.no_grad():
+                o = model(d)
+                rec = [float(loss)]
+                for m in (d.val_mask, d.test_mask):
+                    rec += [float(F.nll_loss(o[m], d.y[m])), float((o[m].max(1)[1] == d.y[m]).float().mean())]
+            traj.append(rec)
+        out.append((np.array(traj, np.float64), init,
+                    {"final." + k: v.clone().numpy() for k, v in model.state_dict().items()}))
+    (tr, init, final), (to, _, _) = out
+    assert np.array_equal(tr, to), "real Actor: trajectory of the reference class != oracle"
+    print("  traj_actor_real: reference class == oracle, 8 epochs", [round(t[0], 4) for t in tr],
+          "test acc", [round(t[4], 4) for t in tr])
+    if write:
+        nz = torch.nonzero(d.x)
+        np.savez_compressed(os.path.join(OUT, "actor_features.npz"), shape=np.array([n, f], np.int64),
+                            row=nz[:, 0].numpy().astype(np.int32), col=nz[:, 1].numpy().astype(np.int16),
+                            val=d.x[nz[:, 0], nz[:, 1]].numpy().astype(np.float32))
+        np.savez_compressed(os.path.join(OUT, "traj_actor_real_plusplus.npz"), traj=tr,
+                            args=np.array([64, 1, 1, 0, 0], np.int64), thr_beta=np.array([0.99, 0.3]),
+                            **{"init." + k: v for k, v in init.items() if not k.endswith("w.weight")}, **final)
+
+
 def main():
     global USE_LOOP_SCATTER_MAX
     ap = argparse.ArgumentParser()
@@ -498,6 +548,8 @@ def main():
     check_models(R)
     print("trainer-loop trajectories:")
     make_trajectories(R, write=not args.check)
+    print("real Actor, published hyper-parameters:")
+    make_actor_real(R, write=not args.check)
     print("OK: the reference's in-tree lines agree with the oracle bit for bit; "
           "Appendix A (third-party kernels) remains unpinned")
 

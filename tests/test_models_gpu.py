@@ -232,3 +232,49 @@ def test_actor_topology_sngnn_plus_plus(cuda):
             gq = q.grad.to_dense() if q.grad.is_sparse else q.grad
             scale = gq.abs().max().clamp_min(1e-12)
             assert (p.grad.cpu() - gq).abs().max() <= 2e-4 * scale + 1e-7, name
+
+
+def test_real_actor_published_hyperparameters(cuda):
+    """BASELINE config 3 end to end on the REAL Actor data the reference bundles (features,
+    labels, geom-gcn split 0; fixtures tests/golden/actor_{topology,features}.npz) with the
+    published sweep's hyper-parameters (train_script_SNGNN_plus_plus.sh:5-44: lr 0.1, weight
+    decay 5e-4, dropout 0, 1 layer, top_k 1, thr 0.99, self-loops kept, init_beta 0.3, seed
+    1234): 8 epochs of the trainer's loop against the trajectory the reference's own
+    SNGNN_Plus_Plus class produced on the CPU (tests/golden/pin_reference.py)."""
+    import os
+    import numpy as np
+    import sngnn_amd
+    from sngnn_amd import train as T
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    topo, feat = np.load(os.path.join(gdir, "actor_topology.npz")), np.load(os.path.join(gdir, "actor_features.npz"))
+    z = np.load(os.path.join(gdir, "traj_actor_real_plusplus.npz"))
+    n, f = (int(v) for v in feat["shape"])
+    x = torch.zeros(n, f)
+    x[torch.from_numpy(feat["row"].astype(np.int64)), torch.from_numpy(feat["col"].astype(np.int64))] = \
+        torch.from_numpy(feat["val"])
+    assert (n, f) == (7600, 932)
+    data = Data(x=x, edge_index=torch.from_numpy(topo["edge_index"].astype(np.int64)),
+                y=torch.from_numpy(topo["y"].astype(np.int64)),
+                train_mask=torch.from_numpy(topo["train_mask0"]).bool(),
+                val_mask=torch.from_numpy(topo["val_mask0"]).bool(),
+                test_mask=torch.from_numpy(topo["test_mask0"]).bool())
+    thr, beta0 = (float(v) for v in z["thr_beta"])
+    torch.manual_seed(1234)
+    model = sngnn_amd.SNGNN_Plus_Plus(f, 64, 5, n, 1, 1, thr, beta0, 0, 0.0)
+    for k, v in model.state_dict().items():
+        if "init." + k in z.files:
+            assert np.array_equal(v.numpy(), z["init." + k]), k
+    model = model.to(cuda)
+    d = data.to(cuda)
+    opt = torch.optim.Adam(model.parameters(), lr=0.1, weight_decay=5e-4)
+    res = T.train(model, d, opt, epochs=8, patience=300)
+    got = np.array([[h["train_loss"], h["val_loss"], h["val_acc"], h["test_loss"], h["test_acc"]]
+                    for h in res["history"]])
+    want = z["traj"]
+    assert np.allclose(got[:, [0, 1, 3]], want[:, [0, 1, 3]], rtol=1e-4, atol=1e-5), (got, want)
+    # accuracies: a handful of the 1 520 / 2 432 masked rows may sit on a decision boundary
+    assert np.abs(got[:, [2, 4]] - want[:, [2, 4]]).max() <= 3.0 / 1520, (got[:, [2, 4]], want[:, [2, 4]])
+    # final parameters (lr 0.1: Adam moves a parameter by up to 0.8 in 8 steps; 1e-3 of that)
+    for k, v in model.state_dict().items():
+        w = z["final." + k]
+        assert np.abs(v.cpu().numpy() - w).max() <= 1e-3, k
