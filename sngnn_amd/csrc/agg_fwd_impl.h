@@ -63,7 +63,10 @@ struct FwdArgs {
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
 };
 
-constexpr int FWD_WAVES_PER_SIMD = 6;   // register budget of the main kernel (<= 80 VGPRs)
+#ifndef SNGNN_FWD_WAVES
+#define SNGNN_FWD_WAVES 6
+#endif
+constexpr int FWD_WAVES_PER_SIMD = SNGNN_FWD_WAVES;   // register budget of the main kernel (6: <= 80 VGPRs)
 
 // source rows in flight per lane group (x 64/G groups per wave): ~16 registers of row data
 template <int R> struct Unroll { static constexpr int U = (R == 1) ? 4 : (R == 2 ? 2 : 1); };

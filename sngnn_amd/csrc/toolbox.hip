@@ -288,9 +288,11 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(), nullptr);
     const int nb = (int)((N + TB_M - 1) / TB_M);
     const int tiles = nb * (nb + 1) / 2;
-    // fewer tiles than two per CU: split the contraction (at least two K-steps per split)
+    // tiles for at most three quarters of the CUs: split the contraction (at least two K-steps per
+    // split).  Measured: Chameleon's 171 tiles 570 -> 480 us with 3 splits; at Cora's 253 tiles (one
+    // per CU already) splitting only added the reduction pass (355 -> 391 us), hence the bound.
     int ks = 1;
-    if (tiles < 512) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, F / (2 * TB_K)));
+    if (tiles <= 192) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, F / (2 * TB_K)));
     const int64_t k_per = ((F + ks - 1) / ks + TB_K - 1) / TB_K * TB_K;
     ks = (int)((F + k_per - 1) / k_per);
     AsyncBuf part(st);
