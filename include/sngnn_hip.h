@@ -322,6 +322,16 @@ int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, const int32_t 
 int sngnn_edge_cosine(const float *x, int64_t N, int64_t F,
                       const int64_t *edge_index_dev, int64_t E, float *sim,
                       void *stream);
+/*
+ * sparse.py:8-14 without forming the product: entries (pair_a[p], pair_b[p]) of
+ * M_n^T M_n, M_n = the column-normalised sparse input in CSC form (colptr int64
+ * [n_cols + 1], rowidx int32 ascending inside a column, vals = the NORMALISED values).
+ * What sparse.py's linked / neighbourhood statistics read out of the scipy product
+ * row by row (sparse.py:45-120).  Synchronises the stream (range check of the pairs).
+ */
+int sngnn_sparse_pair_dot(const int64_t *colptr, const int32_t *rowidx, const float *vals,
+                          int64_t n_cols, const int64_t *pair_a, const int64_t *pair_b,
+                          int64_t n_pairs, float *out, void *stream);
 
 /*
  * kNN similarity graph (the north star's "Node-Similarity build"):

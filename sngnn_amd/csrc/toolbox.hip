@@ -344,6 +344,63 @@ extern "C" int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, con
     return SNGNN_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Sparse columns (sparse.py:8-14): entry (a, b) of M_n^T M_n for a list of column pairs,
+// M_n in CSC with ascending row ids inside a column.  One wave per pair: the lanes stride
+// over the shorter column, each entry binary-searches its row id in the longer one; the
+// products are summed in lane order (fixed: deterministic).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sparse_pair_dot(const int64_t *__restrict__ colptr,
+                                                         const int32_t *__restrict__ rowidx,
+                                                         const float *__restrict__ vals,
+                                                         const int64_t *__restrict__ pa,
+                                                         const int64_t *__restrict__ pb, int64_t n_pairs,
+                                                         int64_t n_cols, float *__restrict__ out, int *bad)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n_pairs) return;
+    int64_t a = pa[p], b = pb[p];
+    if (a < 0 || a >= n_cols || b < 0 || b >= n_cols) {
+        if (lane == 0) { atomicOr(bad, 1); out[p] = 0.f; }
+        return;
+    }
+    int64_t a0 = colptr[a], a1 = colptr[a + 1], b0 = colptr[b], b1 = colptr[b + 1];
+    if (a1 - a0 > b1 - b0) { int64_t t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; }   // a = shorter
+    float acc = 0.f;
+    for (int64_t q = a0 + lane; q < a1; q += 64) {
+        const int32_t r = rowidx[q];
+        int64_t lo = b0, hi = b1;
+        while (lo < hi) {
+            const int64_t m = (lo + hi) >> 1;
+            if (rowidx[m] < r) lo = m + 1; else hi = m;
+        }
+        if (lo < b1 && rowidx[lo] == r) acc = fmaf(vals[q], vals[lo], acc);
+    }
+    acc = wave_sum_f(acc);
+    if (lane == 0) out[p] = acc;
+}
+
+extern "C" int sngnn_sparse_pair_dot(const int64_t *colptr, const int32_t *rowidx, const float *vals,
+                                     int64_t n_cols, const int64_t *pair_a, const int64_t *pair_b,
+                                     int64_t n_pairs, float *out, void *stream)
+{
+    SN_REQUIRE(n_cols >= 0 && n_pairs >= 0, SNGNN_EINVAL, "bad shape");
+    if (n_pairs == 0) return SNGNN_OK;
+    SN_REQUIRE(colptr && pair_a && pair_b && out, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    AsyncBuf bad(st);
+    SN_REQUIRE(bad.alloc(4) == 0, SNGNN_ENOMEM, "out of device memory");
+    SN_HIP(hipMemsetAsync(bad.p, 0, 4, st));
+    k_sparse_pair_dot<<<(unsigned)((n_pairs + 3) / 4), 256, 0, st>>>(colptr, rowidx, vals, pair_a, pair_b, n_pairs,
+                                                                      n_cols, out, bad.as<int>());
+    int h_bad = 0;
+    SN_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
+    SN_HIP(hipStreamSynchronize(st));
+    SN_REQUIRE(!h_bad, SNGNN_ERANGE, "a pair names a column outside [0, n_cols)");
+    return SNGNN_OK;
+}
+
 extern "C" int sngnn_edge_cosine(const float *x, int64_t N, int64_t F, const int64_t *edge_index_dev,
                                  int64_t E, float *sim, void *stream)
 {

@@ -162,40 +162,81 @@ def class_similarity_dense_large(x, y):
 
 
 # ---------------------------------------------------------------------------
-# SimGFAToolbox/sparse.py: the same statistics on the column-normalised input
+# SimGFAToolbox/sparse.py: the same statistics on the COLUMN-normalised sparse input
 # (``cosine_similarity_sparse`` returns M_n^T M_n - node-to-node cosine when M is the
-# [N, N] adjacency, as in toolbox-example.py:28-29).  Here the input is densified on
-# the GPU and sent through the MFMA cosine of its transpose; that is the right tool
-# for the small/medium graphs the reference's Python ``getrow`` loops can handle at
-# all.  For inputs too large to densify the scipy path of the reference remains the
-# baseline.
+# [N, N] adjacency, as in toolbox-example.py:28-29).  The reference forms the scipy product
+# and then reads it row by row in Python (``sim.getrow(k).toarray()``, sparse.py:30,68,106).
+# Here the input stays sparse on the GPU (CSC: the normalised values by column): the linked /
+# neighbourhood statistics are column-pair dot products (``sngnn_sparse_pair_dot``), the
+# class matrix is <m_A, m_B> with m_A the sum of class A's normalised columns - O(nnz), the
+# product is never formed.  Only the functions whose RESULT is the whole [cols, cols] matrix
+# (``cosine_similarity_sparse``, ``node_similarity_sparse``) densify, through the MFMA cosine.
 # ---------------------------------------------------------------------------
 _DENSE_LIMIT = 1 << 31      # elements of the densified input / of the [M, M] result
 
 
-def _as_dense_gpu(mat, device=None) -> torch.Tensor:
-    if isinstance(mat, torch.Tensor):
-        t = mat.to_dense() if mat.layout != torch.strided else mat
-    else:                                   # scipy.sparse matrix
-        coo = mat.tocoo()
-        idx = torch.from_numpy(__import__("numpy").vstack([coo.row, coo.col])).long()
-        t = torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data).float(), coo.shape)
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        t = t.to(device).to_dense()
-    if device is not None:
-        t = t.to(device)
-    if not t.is_cuda:
-        raise ValueError("the matrix must live on the GPU (or be a scipy.sparse matrix)")
-    if t.numel() > _DENSE_LIMIT or t.size(1) ** 2 > _DENSE_LIMIT:
-        raise ValueError("input too large to densify on the GPU; use the reference's scipy path")
-    return t.to(torch.float32)
+class _SparseCols:
+    """The column-normalised input in CSC form on the GPU (sklearn ``normalize(axis=0)``:
+    a column of zeros stays zero)."""
+
+    def __init__(self, mat, device=None):
+        import numpy as np
+        if isinstance(mat, torch.Tensor):
+            t = mat.to_sparse() if mat.layout == torch.strided else mat
+            t = t.coalesce()
+            if device is not None:
+                t = t.to(device)
+            idx, val = t.indices(), t.values()
+            self.shape = tuple(t.shape)
+        else:                                   # scipy.sparse matrix
+            coo = mat.tocoo()
+            coo.sum_duplicates()
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            idx = torch.from_numpy(np.vstack([coo.row, coo.col]).astype(np.int64)).to(device)
+            val = torch.from_numpy(coo.data.astype(np.float32)).to(device)
+            self.shape = tuple(coo.shape)
+        if not val.is_cuda:
+            raise ValueError("the matrix must live on the GPU (or be a scipy.sparse matrix)")
+        rows, cols = idx[0], idx[1]
+        n_cols = self.shape[1]
+        order = torch.argsort(cols * self.shape[0] + rows)          # by column, rows ascending
+        self.rowidx = rows[order].to(torch.int32).contiguous()
+        col_s, val_s = cols[order], val[order].to(torch.float32)
+        sq = torch.zeros(n_cols, dtype=torch.float64, device=val.device).index_add_(0, col_s, val_s.double() ** 2)
+        nrm = sq.sqrt()
+        inv = torch.where(nrm > 0, 1.0 / nrm, torch.zeros_like(nrm))
+        self.vals = (val_s.double() * inv[col_s]).to(torch.float32).contiguous()
+        self.cols = col_s
+        self.colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=val.device)
+        self.colptr[1:] = torch.cumsum(torch.bincount(col_s, minlength=n_cols), 0)
+        self.device = val.device
+
+    def pair_dot(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        a = a.to(self.device, torch.int64).contiguous()
+        b = b.to(self.device, torch.int64).contiguous()
+        out = torch.empty(a.numel(), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _lib.load().sngnn_sparse_pair_dot(self.colptr.data_ptr(), self.rowidx.data_ptr(),
+                                                   self.vals.data_ptr(), self.shape[1], a.data_ptr(),
+                                                   b.data_ptr(), a.numel(), out.data_ptr(),
+                                                   torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "sngnn_sparse_pair_dot")
+        return out
+
+    def dense(self) -> torch.Tensor:
+        if self.shape[0] * self.shape[1] > _DENSE_LIMIT or self.shape[1] ** 2 > _DENSE_LIMIT:
+            raise ValueError("the full [cols, cols] similarity does not fit: use the linked / "
+                             "neighbourhood / class statistics, which never form it")
+        m = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+        m[self.rowidx.long(), self.cols] = self.vals
+        return m
 
 
 def cosine_similarity_sparse(mat, device=None) -> torch.Tensor:
     """sparse.py:8-14: normalise the COLUMNS of ``mat`` and return ``M_n.T @ M_n``
-    ([cols, cols], dense on the GPU)."""
-    m = _as_dense_gpu(mat, device)
+    ([cols, cols], dense on the GPU; the whole matrix is the result, so it is formed)."""
+    m = _SparseCols(mat, device).dense()
     return cosine_similarity_dense_small(m.t().contiguous())
 
 
@@ -208,32 +249,34 @@ def node_similarity_sparse(x, device=None):
 
 def linked_node_similarity_sparse(x, edge_index, device=None):
     """sparse.py:45-77: the similarity at the linked pairs (edge order preserved)."""
-    sim = cosine_similarity_sparse(x, device)
-    ei = edge_index.to(sim.device)
-    vals = sim[ei[0], ei[1]]
+    sp = _SparseCols(x, device)
+    vals = sp.pair_dot(edge_index[0], edge_index[1])
     return vals.reshape(-1, 1), torch.mean(vals)
 
 
 def neighborhood_similarity_sparse(x, edge_index, device=None):
     """sparse.py:80-120: per node the mean similarity to its out-neighbours (0 for a
     node without out-edges) and the mean over all nodes."""
-    sim = cosine_similarity_sparse(x, device)
-    ei = edge_index.to(sim.device)
-    n = sim.size(0)
-    tot, cnt = _mean_by_source(sim[ei[0], ei[1]], ei[0], n)
+    sp = _SparseCols(x, device)
+    ei = edge_index.to(sp.device)
+    n = sp.shape[1]
+    tot, cnt = _mean_by_source(sp.pair_dot(ei[0], ei[1]), ei[0], n)
     per_node = torch.where(cnt > 0, tot / cnt.clamp(min=1), torch.zeros_like(tot)).to(torch.float32)
     return per_node.reshape(-1, 1), per_node.sum() / n
 
 
 def class_similarity_sparse(x, y, device=None):
-    """sparse.py:123-152: block sums / block sizes of the similarity per class pair."""
-    sim = cosine_similarity_sparse(x, device)
-    yl = y.to(sim.device).long()
+    """sparse.py:123-152: block sums / block sizes of the similarity per class pair -
+    sum_{i in A, j in B} <c_i, c_j> = <m_A, m_B>, m_A = the sum of class A's normalised columns."""
+    sp = _SparseCols(x, device)
+    yl = y.to(sp.device).long()
     n_classes = len(torch.unique(yl))
-    onehot = torch.zeros((sim.size(0), n_classes), dtype=torch.float64, device=sim.device)
-    onehot[torch.arange(sim.size(0), device=sim.device), yl] = 1.0
-    sums = onehot.t() @ sim.double() @ onehot
-    cnt = onehot.sum(0)
+    rows = sp.shape[0]
+    m = torch.zeros(n_classes * rows, dtype=torch.float64, device=sp.device)
+    m.index_add_(0, yl[sp.cols] * rows + sp.rowidx.long(), sp.vals.double())
+    m = m.view(n_classes, rows)
+    sums = m @ m.t()
+    cnt = torch.bincount(yl, minlength=n_classes).double()
     return (sums / (cnt[:, None] * cnt[None, :])).to(torch.float32)
 
 

@@ -198,3 +198,59 @@ def test_knn_edge_index_feeds_the_conv_layer(cuda):
     assert out.shape == (400, 16) and torch.isfinite(out).all()
     with pytest.raises(ValueError):
         T.knn_graph(x, 33)
+
+
+def test_linked_node_similarity_dense_large(cuda):
+    """SimGFAToolbox/dense.py:33-62: the linked-pair similarities listed by source node
+    (edges sorted by (src, dst), PyG sort_edge_index) equal dense.py:152-155's values in that
+    order; the mean is the mean over the linked pairs."""
+    from sngnn_amd import toolbox as T
+    n, f = 400, 37
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, f, generator=gen)
+    x[3] = 0.0
+    ei = random_graph(n, 3000, 12)
+    ei = ei[:, torch.randperm(ei.size(1), generator=gen)]           # unsorted input
+    vals, mean = T.linked_node_similarity_dense_large(x.to(cuda), ei.to(cuda))
+    key = ei[0] * n + ei[1]
+    order = torch.argsort(key, stable=True)
+    ref_all, ref_mean = O.linked_node_similarity_dense_small(x, ei[:, order])
+    assert vals.shape == (ei.size(1), 1)
+    assert (vals.cpu() - ref_all).abs().max() < 2e-6
+    assert abs(float(mean) - float(ref_mean)) < 1e-6
+
+
+def test_sparse_statistics_never_form_the_product(cuda):
+    """A [300 000 x 300 000] adjacency (9e10 entries: nothing dense fits): the linked /
+    neighbourhood / class statistics of SimGFAToolbox/sparse.py:45-152 stay sparse on the GPU.
+    Checked against scipy on sampled pairs and against the same code's own small-N results
+    being exact (previous test)."""
+    import scipy.sparse as sp
+    import sklearn.preprocessing as pp
+    from sngnn_amd import toolbox as T
+    n = 300_000
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, n, size=2_000_000)
+    dst = (src + rng.integers(-50, 50, size=src.size)) % n          # neighbours share neighbours
+    adj = sp.csc_matrix((np.ones(src.size), (src, dst)), shape=(n, n))
+    ei = torch.from_numpy(np.stack([src[:50_000], dst[:50_000]]))
+    lv, lm = T.linked_node_similarity_sparse(adj, ei, device=cuda)
+    coln = pp.normalize(adj, axis=0)
+    pick = rng.integers(0, 50_000, size=300)
+    for p in pick:
+        a, b = int(ei[0, p]), int(ei[1, p])
+        want = float(coln[:, a].multiply(coln[:, b]).sum())
+        assert abs(float(lv[p]) - want) < 2e-6, (a, b)
+    assert 0.0 <= float(lm) <= 1.0
+    pn, pm = T.neighborhood_similarity_sparse(adj, ei, device=cuda)
+    assert pn.shape == (n, 1) and abs(float(pm) - float(pn.sum()) / n) < 1e-6
+    y = torch.from_numpy(rng.integers(0, 3, size=n))
+    cm = T.class_similarity_sparse(adj, y, device=cuda).cpu()
+    # <m_A, m_B> against scipy: m_A = coln @ onehot_A
+    oh = sp.csc_matrix((np.ones(n), (np.arange(n), y.numpy())), shape=(n, 3))
+    m = (coln @ oh).toarray()                                        # [rows, 3]
+    want = torch.from_numpy(m.T @ m) / (torch.bincount(y, minlength=3).double()[:, None] *
+                                        torch.bincount(y, minlength=3).double()[None, :])
+    assert (cm.double() - want).abs().max() <= 1e-5 * want.abs().max()
+    with pytest.raises(ValueError, match="does not fit"):
+        T.cosine_similarity_sparse(adj, device=cuda)
