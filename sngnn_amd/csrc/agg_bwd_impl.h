@@ -17,9 +17,11 @@
 //             without the projection where the eps clamp is active)
 // Both passes are gathers with a fixed summation order: no floating-point
 // atomics, bitwise reproducible.  Row classes by degree as in the forward.
-// Pass T leaves one record per edge, wd[e] = {w_e / deg_i (or the UNSELECTED marker),
-// ds_e}, in CSR order (coalesced writes), so pass S needs a single random 8-byte read
-// per out-edge - not the cosine, ds_e and the target's degree from three arrays.
+// Pass T leaves one record per edge, {w_e / deg_i (or the UNSELECTED marker), ds_e}, at the
+// edge's position in the CSC order (graph.csc_pos; a random 8-byte WRITE per edge, fire and
+// forget), so pass S reads the records of a source's out-edges as one coalesced stream -
+// not a dependent random read per out-edge, which at low keep rates (a third of the edges at
+// arxiv size, k = 16, thr = 0) was most of what pass S touched.
 #pragma once
 #include "device_utils.h"
 
@@ -29,8 +31,8 @@ struct BwdArgs {
     const float *h, *gout, *wsel;
     int C, N, Ntot, row_off;      // N owned target rows; Ntot sources / rows of h, grad_h
     const int32_t *rowptr, *col, *rperm;
-    const int32_t *cscptr, *csc_eid, *csc_dst, *sperm;
-    float2 *wd;                   // [E'] per-edge record written by pass T, read by pass S
+    const int32_t *cscptr, *csc_eid, *csc_dst, *csc_pos, *sperm;
+    float2 *wd;                   // [E'] per-edge record in CSC order: written by pass T, read by pass S
     float *dnT, *grad_h;
     int n_split, n_med_end, n_tasks;
     const int32_t *task_slot, *task_chunk, *split_task0;
@@ -63,7 +65,7 @@ __device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<
 // one kept in-edge of target i (source row x, record weight wq = w_e / deg_i):
 // ds_e, its record, and its contribution to dnT_i
 template <int VEC, int G, int R>
-__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, float wq, const Row<VEC, G, R> &x,
+__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int cp, float wq, const Row<VEC, G, R> &x,
                                            const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc,
                                            float live = 1.0f)
 {
@@ -72,12 +74,13 @@ __device__ __forceinline__ void t_edge_row(const BwdArgs &a, int e, float wq, co
     // its partner's instead of behind a branch
     const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
     const float d = group_sum<G>(gp.dot_partial(x));
-    if (lg == 0) a.wd[e] = make_float2(wq, d);
+    if (lg == 0) a.wd[cp] = make_float2(wq, d);
     fma_row<VEC, G, R>(acc, d * invj * live, x);
 }
 
-// kept edges among [e0, e1) of a CSR row, compacted (ascending) into list[] with their
-// record weights w * wscale in wlist[]; unkept edges get their (final) record here.
+// kept edges among [e0, e1) of a CSR row, compacted (ascending): their record positions
+// (CSC order) into list[], record weights w * wscale into wlist[]; unkept edges get their
+// (final) record here.
 // Lanes cover the range 64 at a time.
 __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, float wscale,
                                          int *list, float *wlist, int *jlist = nullptr)
@@ -87,15 +90,16 @@ __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
         const float w = t < e1 ? a.wsel[rs + t] : SNGNN_UNSELECTED;
+        const int cp = t < e1 ? a.csc_pos[rs + t] : 0;
         const bool kept = is_kept(w);
         const unsigned long long m = __ballot(kept);
         if (kept) {
             const int o = n + prefix_popc(m);
-            list[o] = t;
+            list[o] = cp;
             wlist[o] = w * wscale;
             if (jlist) jlist[o] = a.col[rs + t];       // source ids now (coalesced), not per gather
         } else if (t < e1) {
-            a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+            a.wd[cp] = make_float2(SNGNN_UNSELECTED, 0.f);
         }
         n += __popcll(m);
     }
@@ -122,20 +126,21 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     // right there (s_waitcnt vmcnt(0) before the branch closes), which would serialise the
     // rows meant to be in flight together.
     int *s_j = lds_wave + gid * 3 * SMALL_T;                 // [SMALL_T] kept: source id
-    int *s_e = s_j + SMALL_T;                                //                 edge position
+    int *s_e = s_j + SMALL_T;                                //                 record position (CSC)
     float *s_w = reinterpret_cast<float *>(s_j + 2 * SMALL_T);   //             w_e / deg_i
     const float invdeg = 1.0f / (float)max(deg, 1);
     int nk = 0;
     for (int t0 = 0; t0 < deg; t0 += G) {
         const int t = t0 + lg;
         const float w = t < deg ? a.wsel[rs + t] : SNGNN_UNSELECTED;
+        const int cp = t < deg ? a.csc_pos[rs + t] : 0;
         const bool kept = is_kept(w);
-        if (t < deg && !kept) a.wd[rs + t] = make_float2(SNGNN_UNSELECTED, 0.f);
+        if (t < deg && !kept) a.wd[cp] = make_float2(SNGNN_UNSELECTED, 0.f);
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
             const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
             s_j[pos] = a.col[rs + t];
-            s_e[pos] = t;
+            s_e[pos] = cp;
             s_w[pos] = w * invdeg;
         }
         nk += __popcll(gm);
@@ -151,8 +156,8 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
         RowT x0, x1;
         x0.load(a.h + (size_t)s_j[q0] * a.C, a.C, lg);
         x1.load(a.h + (size_t)s_j[q1] * a.C, a.C, lg);
-        t_edge_row<VEC, G, R>(a, rs + s_e[q0], s_w[q0], x0, gp, lg, acc);
-        t_edge_row<VEC, G, R>(a, rs + s_e[q1], s_w[q1], x1, gp, lg, acc, two ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(a, s_e[q0], s_w[q0], x0, gp, lg, acc);
+        t_edge_row<VEC, G, R>(a, s_e[q1], s_w[q1], x1, gp, lg, acc, two ? 1.0f : 0.0f);
     }
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
@@ -196,8 +201,8 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
         RowT xa, xb;
         xa.load(a.h + (size_t)jlist[qa] * a.C, a.C, lg);
         xb.load(a.h + (size_t)jlist[qb] * a.C, a.C, lg);
-        t_edge_row<VEC, G, R>(a, rs + lds_wave[qa], wlist[qa], xa, gp, lg, acc, q0 + gid < nsel ? 1.0f : 0.0f);
-        t_edge_row<VEC, G, R>(a, rs + lds_wave[qb], wlist[qb], xb, gp, lg, acc, q0 + NG + gid < nsel ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(a, lds_wave[qa], wlist[qa], xa, gp, lg, acc, q0 + gid < nsel ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(a, lds_wave[qb], wlist[qb], xb, gp, lg, acc, q0 + NG + gid < nsel ? 1.0f : 0.0f);
     }
     acc.reduce_across_groups();
     if (gid == 0) {
@@ -319,7 +324,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     for (int t0 = 0; t0 < od; t0 += G) {
         const int t = t0 + lg;
         float2 rec = make_float2(SNGNN_UNSELECTED, 0.f);
-        if (t < od) rec = a.wd[a.csc_eid[qs + t]];
+        if (t < od) rec = a.wd[qs + t];
         const bool kept = is_kept(rec.x);
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
@@ -378,7 +383,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     int nsel = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
-        const float2 rec = t < e1 ? a.wd[a.csc_eid[qs + t]] : make_float2(SNGNN_UNSELECTED, 0.f);
+        const float2 rec = t < e1 ? a.wd[qs + t] : make_float2(SNGNN_UNSELECTED, 0.f);
         const bool kept = is_kept(rec.x);
         const unsigned long long m = __ballot(kept);
         if (kept) { const int o = nsel + prefix_popc(m); s_i[o] = a.csc_dst[qs + t]; s_rec[o] = rec; }

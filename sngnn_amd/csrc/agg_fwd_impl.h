@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void k_normalize_rows(const float *__restric
 {
     using RowT = Row<VEC, G, R>;
     constexpr int RPW = 64 / G;
-    constexpr int U = Unroll<R>::U;
+    constexpr int U = Unroll<R>::U >= 2 ? 2 : 1;      // rows per lane group per step
     const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
     const int64_t nw = (int64_t)gridDim.x * WAVES;
@@ -120,10 +120,12 @@ template <int VEC, int G, int R>
 int launch_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st)
 {
     constexpr int RPW = 64 / G;
-    constexpr int U = Unroll<R>::U;
+    constexpr int U = Unroll<R>::U >= 2 ? 2 : 1;
     if (rows <= 0) return SNGNN_OK;
-    const int64_t sets = (rows + RPW * U - 1) / (RPW * U);
-    const int grid = (int)std::min<int64_t>(ceil_div(sets, WAVES), 256 * 8);
+    // a streaming pass: short work items (one step per wave up to 8 resident workgroups per CU,
+    // grid-stride beyond), so the launch drains evenly
+    const int64_t steps = (rows + RPW * U - 1) / (RPW * U);
+    const int grid = (int)std::min<int64_t>(ceil_div(steps, WAVES), 256 * 8 * 4);
     k_normalize_rows<VEC, G, R><<<grid, BLOCK, 0, st>>>(h, rows, C, n, nrm);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

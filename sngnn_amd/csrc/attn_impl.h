@@ -201,7 +201,7 @@ template <int VEC, int G, int R> int launch_attn_fwd(const AttnArgs &a0, hipStre
 }
 
 // ------------------------------ backward, pass T ----------------------------
-// BwdArgs (agg_bwd_impl.h) with wsel = alpha, records wd[e] = {alpha_e, ds_e}, partT rows
+// BwdArgs (agg_bwd_impl.h) with wsel = alpha, records {alpha_e, ds_e} at the edge's CSC position, partT rows
 // of 2C + 4 floats.
 
 // one in-edge: accumulates A, B, dot; returns t_e
@@ -259,7 +259,7 @@ __device__ __forceinline__ void attn_t_small(const BwdArgs &a, int blk, int *lds
     fma_row<VEC, G, R>(A, -dot, B);                       // dnT_i = A - dot * B
     A.store(a.dnT + (size_t)i * a.C, a.C, lg);
     wave_lds_sync();
-    for (int t = lg; t < deg; t += G) a.wd[rs + t] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
+    for (int t = lg; t < deg; t += G) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
 }
 
 template <int VEC, int G, int R>
@@ -317,11 +317,11 @@ __device__ __forceinline__ void attn_t_wave(const BwdArgs &a, int blk, int *lds_
             B.store(p + a.C, a.C, lg);
             if (lg == 0) p[2 * a.C] = dot;
         }
-        for (int t = lane; t < n; t += 64) a.wd[rs + e0 + t] = make_float2(s_a[t], s_t[t]);
+        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + e0 + t]] = make_float2(s_a[t], s_t[t]);
     } else {
         fma_row<VEC, G, R>(A, -dot, B);
         if (gid == 0) A.store(a.dnT + (size_t)i * a.C, a.C, lg);
-        for (int t = lane; t < n; t += 64) a.wd[rs + t] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
+        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
     }
 }
 
@@ -373,9 +373,10 @@ static __global__ __launch_bounds__(256) void k_attn_bwd_t_fin(const BwdArgs a)
         __syncthreads();
     }
     for (int t = threadIdx.x; t < deg; t += 256) {
-        float2 rec = a.wd[rs + t];
+        const int cp = a.csc_pos[rs + t];
+        float2 rec = a.wd[cp];
         rec.y = rec.x * (rec.y - dot);
-        a.wd[rs + t] = rec;
+        a.wd[cp] = rec;
     }
 }
 

@@ -89,6 +89,7 @@ struct sngnn_graph {
     // device arrays
     int32_t *rowptr = nullptr, *col = nullptr, *eid = nullptr;
     int32_t *cscptr = nullptr, *csc_eid = nullptr, *csc_dst = nullptr;
+    int32_t *csc_pos = nullptr;       // [E'] CSR edge index -> its position in the CSC order (inverse of csc_eid)
     int32_t *rperm = nullptr, *sperm = nullptr;
     int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, 0}
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm

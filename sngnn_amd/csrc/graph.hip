@@ -64,6 +64,13 @@ __global__ void k_iota(int32_t *a, int64_t n)
     if (t < n) a[t] = (int32_t)t;
 }
 
+// inv[perm[q]] = q
+__global__ void k_invert(const int32_t *__restrict__ perm, int32_t *__restrict__ inv, int64_t n)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) inv[perm[t]] = (int32_t)t;
+}
+
 __global__ void k_gather(const int32_t *__restrict__ idx, const int32_t *__restrict__ table,
                          int32_t *__restrict__ out, int64_t n)
 {
@@ -232,7 +239,7 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
 
     if ((rc = dev_alloc(&g->rowptr, N + 1)) || (rc = dev_alloc(&g->col, Ep)) ||
         (rc = dev_alloc(&g->eid, Ep)) || (rc = dev_alloc(&g->cscptr, Ntot + 1)) ||
-        (rc = dev_alloc(&g->csc_eid, Ep)) || (rc = dev_alloc(&g->csc_dst, Ep)) ||
+        (rc = dev_alloc(&g->csc_eid, Ep)) || (rc = dev_alloc(&g->csc_dst, Ep)) || (rc = dev_alloc(&g->csc_pos, Ep)) ||
         (rc = dev_alloc(&g->rperm, N)) || (rc = dev_alloc(&g->sperm, Ntot)))
         return rc;
 
@@ -272,6 +279,7 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if (Ep > 0) {
         if ((rc = sort_pairs(g->col, d_keys, d_iota, g->csc_eid, Ep, nbits, false, st))) return rc;
         k_gather<<<grid1(Ep), 256, 0, st>>>(g->csc_eid, dst_csr.as<int32_t>(), g->csc_dst, Ep);
+        k_invert<<<grid1(Ep), 256, 0, st>>>(g->csc_eid, g->csc_pos, Ep);
         int32_t mn = 0;
         SN_HIP(hipMemcpy(&mn, d_keys, 4, hipMemcpyDeviceToHost));
         g->src_min = mn;
@@ -345,7 +353,7 @@ int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int 
 void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
-    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->rperm,
+    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->rperm,
                     g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -467,8 +467,7 @@ static int launch_linear_rows(const float *x, const float *w, const float *b, in
     const int ntiles = (int)((N + 15) / 16);
     // one workgroup per CU (one wave per SIMD): measured faster than two (29 vs 36 us at
     // arxiv size) - the kernel is bound by its MFMA stream, more waves only add W traffic
-    static const int wg_cap = getenv("SNGNN_DEBUG_LIN_GRID") ? atoi(getenv("SNGNN_DEBUG_LIN_GRID")) : 256;
-    const int grid = std::min(wg_cap, (ntiles + 3) / 4);
+    const int grid = std::min(256, (ntiles + 3) / 4);
     switch ((C + 15) / 16) {
     case 1: k_linear_rows<1, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
     case 2: k_linear_rows<2, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
