@@ -20,7 +20,7 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     BwdArgs a;
     a.h = h; a.gout = grad_out; a.wsel = wsel;
     a.C = C; a.N = (int)g->N; a.Ntot = (int)g->Ntot; a.row_off = (int)g->row_off;
-    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm;
+    a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm; a.rdesc = g->rdesc; a.sdesc = g->sdesc;
     a.cscptr = g->cscptr; a.csc_eid = g->csc_eid; a.csc_dst = g->csc_dst; a.csc_pos = g->csc_pos;
     a.sperm = g->sperm;
     // workspace layout (sngnn_graph_workspace_bytes): wd (2 floats per edge) | dnT | partT | partS

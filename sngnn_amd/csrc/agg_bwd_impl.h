@@ -31,6 +31,7 @@ struct BwdArgs {
     const float *h, *gout, *wsel;
     int C, N, Ntot, row_off;      // N owned target rows; Ntot sources / rows of h, grad_h
     const int32_t *rowptr, *col, *rperm;
+    const int4 *rdesc, *sdesc;    // per degree-sorted slot: {node, first entry, degree, 0}: one load, not a chain of three
     const int32_t *cscptr, *csc_eid, *csc_dst, *csc_pos, *sperm;
     float2 *wd;                   // [E'] per-edge record in CSC order: written by pass T, read by pass S
     float *dnT, *grad_h;
@@ -118,9 +119,8 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     const int gid = lane / G, lg = lane % G;
     const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
     if (slot >= a.N) return;                     // group-uniform
-    const int i = a.rperm[slot];
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
+    const int4 d = a.rdesc[slot];
+    const int i = d.x, rs = d.y, deg = d.z;
     // The kept edges are compacted first (ballot within the group), so the gather loop below
     // has no `if (kept)` around its loads: a load inside a divergent branch is waited for
     // right there (s_waitcnt vmcnt(0) before the branch closes), which would serialise the
@@ -170,19 +170,20 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int gid = lane / G, lg = lane % G;
     int i, e0, e1, tq = 0;
+    int4 d;
     if (task) {
         tq = blk * WAVES + wave;
         if (tq >= a.n_tasks) return;
-        i = a.rperm[a.task_slot[tq]];
+        d = a.rdesc[a.task_slot[tq]];
         e0 = a.task_chunk[tq] * CHUNK;
     } else {
         const int slot = a.n_split + blk * WAVES + wave;
         if (slot >= a.n_med_end) return;
-        i = a.rperm[slot];
+        d = a.rdesc[slot];
         e0 = 0;
     }
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
+    i = d.x;
+    const int rs = d.y, deg = d.z;
     e1 = task ? min(deg, e0 + CHUNK) : deg;
     RowT gp, acc;
     const float invdeg = 1.0f / (float)deg;
@@ -266,18 +267,27 @@ __device__ __forceinline__ void s_edge(const BwdArgs &a, int i, float2 rec, int 
     fma_row<VEC, G, R>(dns, rec.y * invi, x);
 }
 
+// the rows s_finish needs, requested at the START of an item so that they travel with the
+// item's first loads instead of adding a round trip at its end
+template <int VEC, int G, int R> struct FinishRows {
+    Row<VEC, G, R> t, hv;
+    bool own;
+    __device__ __forceinline__ void load(const BwdArgs &a, int v, int lg)
+    {
+        const int vl = v - a.row_off;                 // owned nodes also carry a target part
+        own = vl >= 0 && vl < a.N;
+        t.load(a.dnT + (size_t)(own ? vl : 0) * a.C, a.C, lg);
+        hv.load(a.h + (size_t)v * a.C, a.C, lg);
+    }
+};
+
 // dh_v from msg_v and dn_v = dnT_v + dnS_v
 template <int VEC, int G, int R>
 __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VEC, G, R> &msg,
-                                         Row<VEC, G, R> &dn)
+                                         Row<VEC, G, R> &dn, FinishRows<VEC, G, R> &f)
 {
-    Row<VEC, G, R> t, hv;
-    const int vl = v - a.row_off;                 // owned nodes also carry a target part
-    if (vl >= 0 && vl < a.N) {
-        t.load(a.dnT + (size_t)vl * a.C, a.C, lg);
-        dn.add(t);
-    }
-    hv.load(a.h + (size_t)v * a.C, a.C, lg);
+    if (f.own) dn.add(f.t);
+    Row<VEC, G, R> &hv = f.hv;
     const float qv = group_sum<G>(hv.dot_partial(hv));
     const float invv = inv_norm_of(qv);
     hv.scale(invv);                               // n_v
@@ -314,9 +324,10 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     const int gid = lane / G, lg = lane % G;
     const int slot = a.n_smed_end + (blk * WAVES + wave) * RPW + gid;
     if (slot >= a.Ntot) return;
-    const int v = a.sperm[slot];
-    const int qs = a.cscptr[v];
-    const int od = a.cscptr[v + 1] - qs;
+    const int4 d = a.sdesc[slot];
+    const int v = d.x, qs = d.y, od = d.z;
+    FinishRows<VEC, G, R> fin;
+    fin.load(a, v, lg);
     int *s_i = lds_wave + gid * 3 * SMALL_T;                          // kept out-edges: target row
     float *s_w = reinterpret_cast<float *>(s_i + SMALL_T);
     float *s_ds = reinterpret_cast<float *>(s_i + 2 * SMALL_T);
@@ -353,7 +364,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
         // loads are in flight together)
         s_edge_rows<VEC, G, R>(x1, g1, two ? s_w[q1] : 0.f, two ? s_ds[q1] : 0.f, msg, dns);
     }
-    s_finish<VEC, G, R>(a, v, lg, msg, dns);
+    s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
 template <int VEC, int G, int R>
@@ -364,19 +375,20 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int gid = lane / G, lg = lane % G;
     int v, e0, tq = 0;
+    int4 d;
     if (task) {
         tq = blk * WAVES + wave;
         if (tq >= a.n_stasks) return;
-        v = a.sperm[a.stask_slot[tq]];
+        d = a.sdesc[a.stask_slot[tq]];
         e0 = a.stask_chunk[tq] * CHUNK;
     } else {
         const int slot = a.n_ssplit + blk * WAVES + wave;
         if (slot >= a.n_smed_end) return;
-        v = a.sperm[slot];
+        d = a.sdesc[slot];
         e0 = 0;
     }
-    const int qs = a.cscptr[v];
-    const int od = a.cscptr[v + 1] - qs;
+    v = d.x;
+    const int qs = d.y, od = d.z;
     const int e1 = task ? min(od, e0 + CHUNK) : od;
     int *s_i = lds_wave;                                         // [WAVE_T] kept target rows
     float2 *s_rec = reinterpret_cast<float2 *>(lds_wave + WAVE_T);   // their records
@@ -417,7 +429,9 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
             dns.store(a.partS + (size_t)tq * 2 * a.C + a.C, a.C, lg);
         }
     } else if (gid == 0) {
-        s_finish<VEC, G, R>(a, v, lg, msg, dns);
+        FinishRows<VEC, G, R> fin;
+        fin.load(a, v, lg);
+        s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
     }
 }
 
@@ -452,7 +466,9 @@ __global__ __launch_bounds__(64) void k_bwd_s_fin(const BwdArgs a)
         t.load(a.partS + (size_t)tq * 2 * a.C + a.C, a.C, lg);
         dns.add(t);
     }
-    s_finish<VEC, G, R>(a, v, lg, msg, dns);
+    FinishRows<VEC, G, R> fin;
+    fin.load(a, v, lg);
+    s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
 template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream_t st)

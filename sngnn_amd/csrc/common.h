@@ -92,6 +92,7 @@ struct sngnn_graph {
     int32_t *csc_pos = nullptr;       // [E'] CSR edge index -> its position in the CSC order (inverse of csc_eid)
     int32_t *rperm = nullptr, *sperm = nullptr;
     int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, 0}
+    int4 *sdesc = nullptr;     // [Ntot] per slot of sperm: {source, first CSC entry, out-degree, 0}
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch

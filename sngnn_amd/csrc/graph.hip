@@ -293,6 +293,8 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
         SN_HIP(hipMemcpy(g->sdeg.data(), deg_sorted.p, (size_t)Ntot * 4, hipMemcpyDeviceToHost));
     }
     g->max_out_deg = Ntot ? g->sdeg[0] : 0;
+    if ((rc = dev_alloc(&g->sdesc, Ntot))) return rc;
+    if (Ntot > 0) k_row_desc<<<grid1(Ntot), 256, 0, st>>>(g->sperm, g->cscptr, Ntot, g->sdesc);
 
     // 7. split-row / split-source task lists
     g->n_split = g->rows_gt(WAVE_T);
@@ -354,7 +356,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->rperm,
-                    g->sperm, g->rdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
+                    g->sperm, g->rdesc, g->sdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
