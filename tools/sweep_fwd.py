@@ -23,12 +23,17 @@ n, c, ei, x, h, lin = bench.make_rank_inputs(workload, 0, 1, 1234, dev, channels
 g = Graph(ei, n, True, True)
 print(f"workload {workload} C={c} E'={g.num_edges}")
 m, f, z, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+if os.environ.get("MODE") == "normalized":      # the caller holds the unit rows: no normalisation pass
+    un, unrm = ops.normalize_rows(h)
+    call = lambda k, thr: ops.aggregate_forward_normalized(g, un, unrm, k, thr)
+else:
+    call = lambda k, thr: ops.aggregate_forward(g, h, k, thr)
 for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
     res, wall = [], []
     for rnd in range(int(os.environ.get("ROUNDS", 4))):
         lib.sngnn_profile_enable(1)
         for rep in range(12):
-            ops.aggregate_forward(g, h, k, thr)
+            call(k, thr)
             lib.sngnn_profile_last_forward(C.byref(z), C.byref(m), C.byref(f), C.byref(e0))
             if rep >= 2:
                 res.append(((z.value - e0.value) * 1e3, (m.value - e0.value) * 1e3, (f.value - e0.value) * 1e3))
@@ -36,7 +41,7 @@ for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for rep in range(50):
-            ops.aggregate_forward(g, h, k, thr)
+            call(k, thr)
         torch.cuda.synchronize()
         wall.append((time.perf_counter() - t0) / 50 * 1e6)
     med = np.median(np.array(res), axis=0)
