@@ -23,9 +23,13 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     a.rowptr = g->rowptr; a.col = g->col; a.rperm = g->rperm; a.rdesc = g->rdesc; a.sdesc = g->sdesc;
     a.cscptr = g->cscptr; a.csc_eid = g->csc_eid; a.csc_dst = g->csc_dst; a.csc_pos = g->csc_pos;
     a.sperm = g->sperm;
-    // workspace layout (sngnn_graph_workspace_bytes): wd (2 floats per edge) | dnT | partT | partS
+    // workspace layout (sngnn_graph_workspace_bytes): [2 floats per edge: the kept-bit mask
+    // lives in its first words; the attention mode keeps records there] | dnT | partT | partS
     float *ws = (float *)workspace;
-    a.wd = (float2 *)ws;
+    a.wd = nullptr;
+    a.kmask = (unsigned *)ws;
+    a.kmask_words = (g->Ep + 31) / 32;
+    a.inv_deg = g->inv_deg;
     const size_t ds_len = (2 * (size_t)g->Ep + 3) / 4 * 4;  // keep rows 16-byte aligned
     a.dnT = ws + ds_len;
     a.partT = a.dnT + (size_t)g->N * C;

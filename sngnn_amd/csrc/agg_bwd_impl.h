@@ -17,11 +17,15 @@
 //             without the projection where the eps clamp is active)
 // Both passes are gathers with a fixed summation order: no floating-point
 // atomics, bitwise reproducible.  Row classes by degree as in the forward.
-// Pass T leaves one record per edge, {w_e / deg_i (or the UNSELECTED marker), ds_e}, at the
-// edge's position in the CSC order (graph.csc_pos; a random 8-byte WRITE per edge, fire and
-// forget), so pass S reads the records of a source's out-edges as one coalesced stream -
-// not a dependent random read per out-edge, which at low keep rates (a third of the edges at
-// arxiv size, k = 16, thr = 0) was most of what pass S touched.
+// What pass S needs to know about an out-edge is one bit - kept or not: w_e and ds_e are dot
+// products of rows it gathers anyway (n_i, G_i) with its own row, so it recomputes them
+// (ds_e = <G_i, h_j> / deg_i, w_e = <h_i, h_j> inv_i inv_j).  Pass T sets the bit of every KEPT
+// edge in a bitmask in CSC order (graph.csc_pos; one fire-and-forget atomic OR per kept edge
+// into a 145 KB, cache-resident mask at arxiv size) and pass S reads the bits of a source's
+// out-edges as one coalesced word stream.  (Round 2 first had pass T write an 8-byte record
+// {w_e / deg_i, ds_e} per EDGE at its CSC position: 1.16 M scattered sector writes, 14 us of
+// pass T's 44.6; the attention mode, whose per-edge weight is not recomputable from two rows,
+// still does - REC = true below.)
 #pragma once
 #include "device_utils.h"
 
@@ -33,7 +37,10 @@ struct BwdArgs {
     const int32_t *rowptr, *col, *rperm;
     const int4 *rdesc, *sdesc;    // per degree-sorted slot: {node, first entry, degree, 0}: one load, not a chain of three
     const int32_t *cscptr, *csc_eid, *csc_dst, *csc_pos, *sperm;
-    float2 *wd;                   // [E'] per-edge record in CSC order: written by pass T, read by pass S
+    float2 *wd;                   // [E'] per-edge record in CSC order (attention mode: attn_impl.h)
+    unsigned *kmask;              // [kmask_words = ceil(E'/32)] kept bits in CSC order: set by pass T, read by pass S
+    int64_t kmask_words;
+    const float *inv_deg;         // [N] 1 / max(in-degree, 1)
     float *dnT, *grad_h;
     int n_split, n_med_end, n_tasks;
     const int32_t *task_slot, *task_chunk, *split_task0;
@@ -63,28 +70,26 @@ __device__ __forceinline__ void fma_row(Row<VEC, G, R> &acc, float w, const Row<
 }
 
 // ------------------------------- pass T ------------------------------------
-// one kept in-edge of target i (source row x, record weight wq = w_e / deg_i):
-// ds_e, its record, and its contribution to dnT_i
+// one kept in-edge of target i (source row x): ds_e and its contribution to dnT_i
 template <int VEC, int G, int R>
-__device__ __forceinline__ void t_edge_row(const BwdArgs &a, int cp, float wq, const Row<VEC, G, R> &x,
-                                           const Row<VEC, G, R> &gp, int lg, Row<VEC, G, R> &acc,
-                                           float live = 1.0f)
+__device__ __forceinline__ void t_edge_row(const Row<VEC, G, R> &x, const Row<VEC, G, R> &gp,
+                                           Row<VEC, G, R> &acc, float live = 1.0f)
 {
-    // live = 0: a padding repeat of the previous edge (odd count) - it rewrites the same
-    // record and adds nothing; keeping it unconditional keeps its row load in flight with
-    // its partner's instead of behind a branch
+    // live = 0: a padding repeat of the previous edge (odd count) adds nothing; keeping it
+    // unconditional keeps its row load in flight with its partner's instead of behind a branch
     const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
     const float d = group_sum<G>(gp.dot_partial(x));
-    if (lg == 0) a.wd[cp] = make_float2(wq, d);
     fma_row<VEC, G, R>(acc, d * invj * live, x);
 }
 
-// kept edges among [e0, e1) of a CSR row, compacted (ascending): their record positions
-// (CSC order) into list[], record weights w * wscale into wlist[]; unkept edges get their
-// (final) record here.
-// Lanes cover the range 64 at a time.
-__device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, float wscale,
-                                         int *list, float *wlist, int *jlist = nullptr)
+__device__ __forceinline__ void set_kept_bit(const BwdArgs &a, int cp)
+{
+    atomicOr(a.kmask + (cp >> 5), 1u << (cp & 31));        // result unused: no return trip
+}
+
+// kept edges among [e0, e1) of a CSR row, compacted (ascending): their source ids into
+// jlist[]; their bits in the CSC-order mask are set here.  Lanes cover the range 64 at a time.
+__device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, int *jlist)
 {
     const int lane = lane_id();
     int n = 0;
@@ -92,15 +97,13 @@ __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e
         const int t = base + lane;
         const float w = t < e1 ? a.wsel[rs + t] : SNGNN_UNSELECTED;
         const int cp = t < e1 ? a.csc_pos[rs + t] : 0;
+        // (with the weight, not behind `if (kept)`: a load inside the branch is a round trip of its own)
+        const int j = t < e1 ? a.col[rs + t] : 0;
         const bool kept = is_kept(w);
         const unsigned long long m = __ballot(kept);
         if (kept) {
-            const int o = n + prefix_popc(m);
-            list[o] = cp;
-            wlist[o] = w * wscale;
-            if (jlist) jlist[o] = a.col[rs + t];       // source ids now (coalesced), not per gather
-        } else if (t < e1) {
-            a.wd[cp] = make_float2(SNGNN_UNSELECTED, 0.f);
+            jlist[n + prefix_popc(m)] = j;
+            set_kept_bit(a, cp);
         }
         n += __popcll(m);
     }
@@ -125,23 +128,19 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     // has no `if (kept)` around its loads: a load inside a divergent branch is waited for
     // right there (s_waitcnt vmcnt(0) before the branch closes), which would serialise the
     // rows meant to be in flight together.
-    int *s_j = lds_wave + gid * 3 * SMALL_T;                 // [SMALL_T] kept: source id
-    int *s_e = s_j + SMALL_T;                                //                 record position (CSC)
-    float *s_w = reinterpret_cast<float *>(s_j + 2 * SMALL_T);   //             w_e / deg_i
+    int *s_j = lds_wave + gid * SMALL_T;                     // [SMALL_T] kept: source id
     const float invdeg = 1.0f / (float)max(deg, 1);
     int nk = 0;
     for (int t0 = 0; t0 < deg; t0 += G) {
         const int t = t0 + lg;
         const float w = t < deg ? a.wsel[rs + t] : SNGNN_UNSELECTED;
         const int cp = t < deg ? a.csc_pos[rs + t] : 0;
+        const int j = t < deg ? a.col[rs + t] : 0;       // with the weight: not a round trip of its own
         const bool kept = is_kept(w);
-        if (t < deg && !kept) a.wd[cp] = make_float2(SNGNN_UNSELECTED, 0.f);
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
-            const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
-            s_j[pos] = a.col[rs + t];
-            s_e[pos] = cp;
-            s_w[pos] = w * invdeg;
+            s_j[nk + __popcll(gm & ((1ull << lg) - 1ull))] = j;
+            set_kept_bit(a, cp);
         }
         nk += __popcll(gm);
     }
@@ -156,8 +155,8 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
         RowT x0, x1;
         x0.load(a.h + (size_t)s_j[q0] * a.C, a.C, lg);
         x1.load(a.h + (size_t)s_j[q1] * a.C, a.C, lg);
-        t_edge_row<VEC, G, R>(a, s_e[q0], s_w[q0], x0, gp, lg, acc);
-        t_edge_row<VEC, G, R>(a, s_e[q1], s_w[q1], x1, gp, lg, acc, two ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(x0, gp, acc);
+        t_edge_row<VEC, G, R>(x1, gp, acc, two ? 1.0f : 0.0f);
     }
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
@@ -190,9 +189,8 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
     gp.load(a.gout + (size_t)i * a.C, a.C, lg);
     gp.scale(invdeg);
     acc.zero();
-    float *wlist = reinterpret_cast<float *>(lds_wave + WAVE_T);
-    int *jlist = lds_wave + 2 * WAVE_T;
-    const int nsel = kept_list(a, rs, e0, e1, invdeg, lds_wave, wlist, jlist);
+    int *jlist = lds_wave;
+    const int nsel = kept_list(a, rs, e0, e1, jlist);
     wave_lds_sync();
     // two kept rows per lane group in flight, unconditionally (a slot past the end repeats the
     // last kept edge with live = 0): no col -> row chain, no load behind a branch.  Matters on
@@ -202,8 +200,8 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
         RowT xa, xb;
         xa.load(a.h + (size_t)jlist[qa] * a.C, a.C, lg);
         xb.load(a.h + (size_t)jlist[qb] * a.C, a.C, lg);
-        t_edge_row<VEC, G, R>(a, lds_wave[qa], wlist[qa], xa, gp, lg, acc, q0 + gid < nsel ? 1.0f : 0.0f);
-        t_edge_row<VEC, G, R>(a, lds_wave[qb], wlist[qb], xb, gp, lg, acc, q0 + NG + gid < nsel ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(xa, gp, acc, q0 + gid < nsel ? 1.0f : 0.0f);
+        t_edge_row<VEC, G, R>(xb, gp, acc, q0 + NG + gid < nsel ? 1.0f : 0.0f);
     }
     acc.reduce_across_groups();
     if (gid == 0) {
@@ -215,7 +213,7 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
 {
-    __shared__ __align__(16) int lds[WAVES][384];
+    __shared__ __align__(16) int lds[WAVES][WAVE_T];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
     if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
@@ -301,7 +299,21 @@ __device__ __forceinline__ void s_finish(const BwdArgs &a, int v, int lg, Row<VE
     msg.store(a.grad_h + (size_t)v * a.C, a.C, lg);
 }
 
-// the same with both rows already loaded
+// one kept out-edge (v -> i) from the rows alone: x = h_i, gi = G_i, hv = h_v (own, raw),
+// invv = inv_v, invdeg = 1 / deg_i;  w_e = <h_i, h_v> inv_i inv_v,  ds_e = <G_i, h_v> / deg_i
+template <int VEC, int G, int R>
+__device__ __forceinline__ void s_edge_recompute(const Row<VEC, G, R> &x, const Row<VEC, G, R> &gi,
+                                                 const Row<VEC, G, R> &hv, float invv, float invdeg,
+                                                 float live, Row<VEC, G, R> &msg, Row<VEC, G, R> &dns)
+{
+    const float invi = inv_norm_of(group_sum<G>(x.dot_partial(x)));
+    const float w = group_sum<G>(x.dot_partial(hv)) * (invi * invv);
+    const float dse = group_sum<G>(gi.dot_partial(hv)) * invdeg;
+    fma_row<VEC, G, R>(msg, w * invdeg * live, gi);
+    fma_row<VEC, G, R>(dns, dse * invi * live, x);
+}
+
+// the same with both rows already loaded and the per-edge scalars from a record
 template <int VEC, int G, int R>
 __device__ __forceinline__ void s_edge_rows(const Row<VEC, G, R> &x, const Row<VEC, G, R> &gi,
                                             float w, float dse, Row<VEC, G, R> &msg,
@@ -315,7 +327,9 @@ __device__ __forceinline__ void s_edge_rows(const Row<VEC, G, R> &x, const Row<V
 // small sources (out-degree <= SMALL_T), one group per source: per-edge scalars of all
 // out-edges are fetched by the group's lanes in parallel, then the (h_i, G_i) row pairs
 // of the kept edges are gathered two edges at a time.
-template <int VEC, int G, int R>
+//   REC = true:  per-edge scalars from the records a.wd (attention mode)
+//   REC = false: kept bits from a.kmask, scalars recomputed from the rows
+template <int VEC, int G, int R, bool REC>
 __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -335,20 +349,28 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     for (int t0 = 0; t0 < od; t0 += G) {
         const int t = t0 + lg;
         float2 rec = make_float2(SNGNN_UNSELECTED, 0.f);
-        if (t < od) rec = a.wd[qs + t];
-        const bool kept = is_kept(rec.x);
+        int it = 0;
+        bool kept = false;
+        if (t < od) {                                                 // together: one round trip
+            const int q = qs + t;
+            it = a.csc_dst[q];
+            if constexpr (REC) rec = a.wd[q];
+            else kept = (a.kmask[q >> 5] >> (q & 31)) & 1u;
+        }
+        if constexpr (REC) kept = is_kept(rec.x);
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
             const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
-            s_i[pos] = a.csc_dst[qs + t];
-            s_w[pos] = rec.x;
-            s_ds[pos] = rec.y;
+            s_i[pos] = it;
+            if constexpr (REC) { s_w[pos] = rec.x; s_ds[pos] = rec.y; }
         }
         nk += __popcll(gm);
     }
     RowT msg, dns;
     msg.zero();
     dns.zero();
+    float invv = 0.f;
+    if constexpr (!REC) invv = inv_norm_of(group_sum<G>(fin.hv.dot_partial(fin.hv)));
     wave_lds_sync();
     for (int q0 = 0; q0 < nk; q0 += 2) {
         const bool two = q0 + 1 < nk;
@@ -359,15 +381,21 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
         g0.load(a.gout + (size_t)i0 * a.C, a.C, lg);
         x1.load(a.h + (size_t)(i1 + a.row_off) * a.C, a.C, lg);
         g1.load(a.gout + (size_t)i1 * a.C, a.C, lg);
-        s_edge_rows<VEC, G, R>(x0, g0, s_w[q0], s_ds[q0], msg, dns);
         // (odd count: the repeat enters with zero weights - unconditional, so that all four row
         // loads are in flight together)
-        s_edge_rows<VEC, G, R>(x1, g1, two ? s_w[q1] : 0.f, two ? s_ds[q1] : 0.f, msg, dns);
+        if constexpr (REC) {
+            s_edge_rows<VEC, G, R>(x0, g0, s_w[q0], s_ds[q0], msg, dns);
+            s_edge_rows<VEC, G, R>(x1, g1, two ? s_w[q1] : 0.f, two ? s_ds[q1] : 0.f, msg, dns);
+        } else {
+            const float d0 = a.inv_deg[i0], d1 = a.inv_deg[i1];       // travel with the rows
+            s_edge_recompute<VEC, G, R>(x0, g0, fin.hv, invv, d0, 1.0f, msg, dns);
+            s_edge_recompute<VEC, G, R>(x1, g1, fin.hv, invv, d1, two ? 1.0f : 0.0f, msg, dns);
+        }
     }
     s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool REC>
 __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
 {
     using RowT = Row<VEC, G, R>;
@@ -390,36 +418,59 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     v = d.x;
     const int qs = d.y, od = d.z;
     const int e1 = task ? min(od, e0 + CHUNK) : od;
+    RowT hv;                                                      // own row (raw): every group its copy
+    float invv = 0.f;
+    if constexpr (!REC) hv.load(a.h + (size_t)v * a.C, a.C, lg);
     int *s_i = lds_wave;                                         // [WAVE_T] kept target rows
     float2 *s_rec = reinterpret_cast<float2 *>(lds_wave + WAVE_T);   // their records
     int nsel = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
-        const float2 rec = t < e1 ? a.wd[qs + t] : make_float2(SNGNN_UNSELECTED, 0.f);
-        const bool kept = is_kept(rec.x);
+        const int q = qs + t;
+        float2 rec = make_float2(SNGNN_UNSELECTED, 0.f);
+        const int it = t < e1 ? a.csc_dst[q] : 0;                     // with the flags: one round trip
+        bool kept;
+        if constexpr (REC) {
+            if (t < e1) rec = a.wd[q];
+            kept = is_kept(rec.x);
+        } else {
+            kept = t < e1 && ((a.kmask[q >> 5] >> (q & 31)) & 1u);
+        }
         const unsigned long long m = __ballot(kept);
-        if (kept) { const int o = nsel + prefix_popc(m); s_i[o] = a.csc_dst[qs + t]; s_rec[o] = rec; }
+        if (kept) {
+            const int o = nsel + prefix_popc(m);
+            s_i[o] = it;
+            if constexpr (REC) s_rec[o] = rec;
+        }
         nsel += __popcll(m);
     }
+    if constexpr (!REC) invv = inv_norm_of(group_sum<G>(hv.dot_partial(hv)));
     wave_lds_sync();
     RowT msg, dns;
     msg.zero();
     dns.zero();
     // two kept out-edges per lane group per step, unconditionally (a slot past the end repeats
-    // the last one with a zero record): four row loads in flight per group
+    // the last one with zero weight): four row loads in flight per group
     for (int q0 = 0; q0 < nsel; q0 += 2 * NG) {
         const int qa = min(q0 + gid, nsel - 1), qb = min(q0 + NG + gid, nsel - 1);
+        const bool la = q0 + gid < nsel, lb = q0 + NG + gid < nsel;
         const int ia = s_i[qa], ib = s_i[qb];
-        float2 ra = s_rec[qa], rb = s_rec[qb];
-        if (q0 + gid >= nsel) ra = make_float2(0.f, 0.f);
-        if (q0 + NG + gid >= nsel) rb = make_float2(0.f, 0.f);
         RowT xa, ga, xb, gb;
         xa.load(a.h + (size_t)(ia + a.row_off) * a.C, a.C, lg);
         ga.load(a.gout + (size_t)ia * a.C, a.C, lg);
         xb.load(a.h + (size_t)(ib + a.row_off) * a.C, a.C, lg);
         gb.load(a.gout + (size_t)ib * a.C, a.C, lg);
-        s_edge_rows<VEC, G, R>(xa, ga, ra.x, ra.y, msg, dns);
-        s_edge_rows<VEC, G, R>(xb, gb, rb.x, rb.y, msg, dns);
+        if constexpr (REC) {
+            float2 ra = s_rec[qa], rb = s_rec[qb];
+            if (!la) ra = make_float2(0.f, 0.f);
+            if (!lb) rb = make_float2(0.f, 0.f);
+            s_edge_rows<VEC, G, R>(xa, ga, ra.x, ra.y, msg, dns);
+            s_edge_rows<VEC, G, R>(xb, gb, rb.x, rb.y, msg, dns);
+        } else {
+            const float da = a.inv_deg[ia], db = a.inv_deg[ib];       // travel with the rows
+            s_edge_recompute<VEC, G, R>(xa, ga, hv, invv, da, la ? 1.0f : 0.0f, msg, dns);
+            s_edge_recompute<VEC, G, R>(xb, gb, hv, invv, db, lb ? 1.0f : 0.0f, msg, dns);
+        }
     }
     msg.reduce_across_groups();
     dns.reduce_across_groups();
@@ -435,15 +486,15 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     }
 }
 
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool REC>
 __global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
 {
     __shared__ __align__(16) int lds[WAVES][512];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
-    if (b < a.nbA) s_role_wave<VEC, G, R>(a, b, lw, true);
-    else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
-    else s_role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+    if (b < a.nbA) s_role_wave<VEC, G, R, REC>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R, REC>(a, b - a.nbA, lw, false);
+    else s_role_small<VEC, G, R, REC>(a, b - a.nbA - a.nbB, lw);
 }
 
 // split sources: one wave per source sums the tasks' partial rows, then finishes
@@ -471,10 +522,21 @@ __global__ __launch_bounds__(64) void k_bwd_s_fin(const BwdArgs a)
     s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
+static __global__ void k_clear_words(unsigned *__restrict__ p, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream_t st)
 {
     constexpr int RPW = 64 / G;
     BwdArgs a = a0;
+    // kept bits in CSC order: cleared, set by pass T, read by pass S.  (A kernel, not
+    // hipMemsetAsync: replayed from a captured HIP graph, the memset node did not stay ordered
+    // in front of pass T on this stack - ROCm 7.0 runtime under PyTorch 2.10 - and cleared bits
+    // that pass T had already set; tests/test_models_gpu.py::test_graphed_epoch_survives_... caught it.)
+    if (a.kmask_words > 0)
+        k_clear_words<<<(int)std::min<int64_t>(ceil_div(a.kmask_words, (int64_t)256), 1024), 256, 0, st>>>(a.kmask, a.kmask_words);
     // pass T (targets)
     a.nbA = ceil_div(a.n_tasks, WAVES);
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
@@ -485,7 +547,7 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
     nbC = ceil_div(a.Ntot - a.n_smed_end, (int64_t)WAVES * RPW);
-    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R, false><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
     if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

@@ -32,6 +32,14 @@ extern "C" int sngnn_profile_last_forward(float *norm_ms, float *main_ms, float 
     return SNGNN_OK;
 }
 
+static __global__ void k_fill_sel(int32_t *__restrict__ src, float *__restrict__ w, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        src[i] = -1;
+        w[i] = 0.f;
+    }
+}
+
 static int normalize_dispatch(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm,
                               hipStream_t st)
 {
@@ -61,8 +69,10 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     if (top_k > (1 << 20)) top_k = 1 << 20;     // more than any row can use
 
     if (sel_src && top_k > 0) {
-        SN_HIP(hipMemsetAsync(sel_src, 0xFF, (size_t)g->N * top_k * 4, st));
-        SN_HIP(hipMemsetAsync(sel_w, 0, (size_t)g->N * top_k * 4, st));
+        // (a kernel, not hipMemsetAsync: inside a captured HIP graph a memset node was seen to
+        // race with the kernel nodes behind it on this stack - see agg_bwd_impl.h)
+        const int64_t nw = g->N * (int64_t)top_k;
+        k_fill_sel<<<(int)std::min<int64_t>((nw + 255) / 256, 2048), 256, 0, st>>>(sel_src, sel_w, nw);
     }
 
     FwdArgs a;

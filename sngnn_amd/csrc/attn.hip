@@ -57,6 +57,7 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     // workspace layout (sngnn_graph_workspace_bytes): wd (2 floats per edge) | dnT | partT (2C+4 per task) | partS
     float *ws = (float *)workspace;
     a.wd = (float2 *)ws;
+    a.kmask = nullptr; a.kmask_words = 0; a.inv_deg = nullptr;
     const size_t ds_len = (2 * (size_t)g->Ep + 3) / 4 * 4;
     a.dnT = ws + ds_len;
     a.partT = a.dnT + (size_t)g->N * C;

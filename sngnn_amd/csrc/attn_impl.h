@@ -393,7 +393,7 @@ template <int VEC, int G, int R> int launch_attn_bwd(const BwdArgs &a0, hipStrea
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
     nbC = ceil_div(a.Ntot - a.n_smed_end, (int64_t)WAVES * RPW);
-    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
+    if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R, true><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
     if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

@@ -93,6 +93,7 @@ struct sngnn_graph {
     int32_t *rperm = nullptr, *sperm = nullptr;
     int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, 0}
     int4 *sdesc = nullptr;     // [Ntot] per slot of sperm: {source, first CSC entry, out-degree, 0}
+    float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch

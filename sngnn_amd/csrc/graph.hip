@@ -92,6 +92,12 @@ __global__ void k_lower_bound(const int32_t *__restrict__ keys, int64_t n, int64
     ptr[i] = (int32_t)lo;
 }
 
+__global__ void k_inv_deg(const int32_t *__restrict__ rowptr, int64_t N, float *__restrict__ out)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < N) out[i] = 1.0f / (float)max(rowptr[i + 1] - rowptr[i], 1);
+}
+
 __global__ void k_row_desc(const int32_t *__restrict__ rperm, const int32_t *__restrict__ rowptr,
                            int64_t N, int4 *__restrict__ desc)
 {
@@ -274,6 +280,8 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     g->max_in_deg = N ? g->rdeg[0] : 0;
     if ((rc = dev_alloc(&g->rdesc, N))) return rc;
     if (N > 0) k_row_desc<<<grid1(N), 256, 0, st>>>(g->rperm, g->rowptr, N, g->rdesc);
+    if ((rc = dev_alloc(&g->inv_deg, N))) return rc;
+    if (N > 0) k_inv_deg<<<grid1(N), 256, 0, st>>>(g->rowptr, N, g->inv_deg);
 
     // 6. CSC by source: stable sort of CSR positions by col
     if (Ep > 0) {
@@ -356,7 +364,7 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->rperm,
-                    g->sperm, g->rdesc, g->sdesc, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
+                    g->sperm, g->rdesc, g->sdesc, g->inv_deg, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
