@@ -359,6 +359,10 @@ def main():
             # from a HIP graph (sngnn_amd/train.py:GraphedEpoch)
             result["epoch_ms_eager"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k,
                                                      args.thr, seed=args.seed)
+            # epoch_ms: validation and test read ONE eval-mode forward (train.py:92-117 run the
+            # same forward twice); epoch_ms_3fwd replays the reference's three forwards
+            result["epoch_ms_3fwd"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
+                                                    seed=args.seed, graphed=True, share_eval_forward=False)
             result["epoch_ms"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
                                                seed=args.seed, graphed=True)
         if not args.no_cpu_baseline:

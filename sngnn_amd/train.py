@@ -83,14 +83,20 @@ class GraphedEpoch:
     and on host synchronisations: boolean-mask indexing (a ``nonzero`` each),
     ``.item()`` after every step (train.py:83,100,114).  Here the masks become index
     tensors once, the six metrics stay on the device, Adam runs ``capturable`` and the
-    whole epoch - 3 forwards, 1 backward, the optimizer step - replays as one graph;
+    whole epoch - the training forward and backward, the optimizer step, the eval-mode forward
+    (one for validation and test: see ``share_eval_forward``) - replays as one graph;
     the host reads one 6-float tensor per epoch (needed for early stopping on the
     validation loss, train.py:150-158).  Same arithmetic as :func:`train_step` /
     :func:`eval_step`.
     """
 
-    def __init__(self, model, data, optimizer, warmup: int = 3):
+    def __init__(self, model, data, optimizer, warmup: int = 3, share_eval_forward: bool = True):
         self.model, self.data, self.opt = model, data, optimizer
+        # validate_step and test_step (train.py:92-117) run the SAME eval-mode forward - same
+        # parameters, same data, no dropout, batch-norm on its running statistics - and differ only
+        # in the mask their metrics read; these kernels are deterministic, so one forward serves
+        # both, bit for bit.  False replays the reference's two passes.
+        self.share_eval_forward = share_eval_forward
         dev = data.x.device
         from . import ops
         self._ops = ops
@@ -147,15 +153,20 @@ class GraphedEpoch:
                     if group.get("amsgrad", False):
                         st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
-    def _loss(self, which):
+    def _forward(self):
+        return self.model.forward_logits(self.data) if self.fused else self.model(self.data)
+
+    def _loss(self, which, out=None):
         """(mean NLL, correct count) on one mask: the fused head kernel on the model's
-        logits, or the reference expressions for a model without ``forward_logits``."""
+        logits, or the reference expressions for a model without ``forward_logits``.
+        ``out``: the forward's result when the caller already has it."""
+        if out is None:
+            out = self._forward()
         if self.fused:
             # the kernel writes (loss, correct) straight into this split's slots of the metrics
             slot = {"train": 0, "val": 2, "test": 4}[which]
-            return self._ops.head_nll(self.model.forward_logits(self.data), self.data.y,
+            return self._ops.head_nll(out, self.data.y,
                                       self.mask[which], self.count[which], out=self.metrics[slot:slot + 2])
-        out = self.model(self.data)
         m = self.mask[which].bool()
         return (F.nll_loss(out[m], self.data.y[m]),
                 (out[m].max(dim=1)[1] == self.data.y[m]).sum().float())
@@ -178,8 +189,9 @@ class GraphedEpoch:
         self.opt.step()
         with torch.no_grad():
             self.model.eval()
-            vl, vc = self._loss("val")
-            tl, tc = self._loss("test")
+            shared = self._forward() if self.share_eval_forward else None
+            vl, vc = self._loss("val", shared)
+            tl, tc = self._loss("test", shared)
             if not self.fused:
                 torch.stack([loss.detach(), correct, vl, vc, tl, tc], out=self.metrics)   # one kernel
 
@@ -218,10 +230,11 @@ def train_graphed(model, data, optimizer, epochs: int, patience: int) -> Dict:
 def epoch_time_ms(workload: str, x: torch.Tensor, edge_index: torch.Tensor, n: int,
                   classes: int, top_k: int, thr: float, *, seed: int = 1234, lr: float = 0.01,
                   weight_decay: float = 5e-4, epochs: int = 30, warmup: int = 5,
-                  graphed: bool = False) -> float:
-    """Mean wall time of train + validation + test steps (3 forwards, 1 backward,
-    Adam) of a 1-layer SNGNN_Plus, device-synchronised - the quantity train.py:135-143
-    logs as ``Time(s)``.  ``graphed`` replays the epoch from a HIP graph."""
+                  graphed: bool = False, share_eval_forward: bool = True) -> float:
+    """Mean wall time of train + validation + test steps of a 1-layer SNGNN_Plus,
+    device-synchronised - the quantity train.py:135-143 logs as ``Time(s)``.  Eager: the
+    reference's loop (3 forwards, 1 backward, Adam).  ``graphed`` replays the epoch from a HIP
+    graph (``share_eval_forward``: one eval forward for the validation and test metrics)."""
     from .models import SNGNN_Plus
     gen = torch.Generator().manual_seed(seed)
     y = torch.randint(0, classes, (n,), generator=gen).to(x.device)
@@ -234,7 +247,7 @@ def epoch_time_ms(workload: str, x: torch.Tensor, edge_index: torch.Tensor, n: i
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
 
     if graphed:
-        ge = GraphedEpoch(model, data, opt)
+        ge = GraphedEpoch(model, data, opt, share_eval_forward=share_eval_forward)
         one_epoch = ge.run
     else:
         def one_epoch():

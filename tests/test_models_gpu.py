@@ -146,6 +146,26 @@ def test_graphed_epoch_survives_graph_cache_eviction(cuda):
             assert abs(ra[k] - rb[k]) <= 1e-6 * max(1.0, abs(ra[k])), (k, ra[k], rb[k])
 
 
+def test_graphed_epoch_one_eval_forward_equals_two(cuda):
+    """validate_step and test_step (train.py:92-117) run the same eval-mode forward; the graphed
+    epoch runs it once by default.  Every metric must be bit-identical to the two-pass replay."""
+    import sngnn_amd
+    from sngnn_amd import train as T
+    from sngnn_amd import synth
+    data = synth.make_dataset("cora", scale=0.5).to(cuda)
+    n, f = data.x.shape
+
+    def run(share):
+        torch.manual_seed(11)
+        model = sngnn_amd.SNGNN_Plus(f, 16, 7, n, 2, 3, 0.1, 1, 0.5, bn=True).to(cuda)
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
+        ge = T.GraphedEpoch(model, data, opt, warmup=0, share_eval_forward=share)
+        return [ge.run() for _ in range(5)]
+
+    a, b = run(True), run(False)
+    assert a == b
+
+
 @pytest.mark.parametrize("kind,args,name", [
     ("SNGNN_Plus", lambda f, n: (f, 16, 7, n, 2, 3, 0.1, 1, 0.0), "plus_2layer"),
     ("SNGNN_Plus_Plus", lambda f, n: (f, 16, 7, n, 1, 4, 0.2, 0.3, 1, 0.0), "plusplus_1layer"),
