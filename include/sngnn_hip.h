@@ -285,6 +285,15 @@ int sngnn_head_nll(const float *logits, const int64_t *y, const unsigned char *r
                    int64_t N, int C, int64_t n_masked, float *grad_logits,
                    float *loss_and_correct, void *workspace, void *stream);
 /*
+ * The same for TWO splits read off one forward: validate_step and test_step (train.py:92-117)
+ * run the same eval-mode forward and differ in their mask.  row_sets dev u8 [N]: bit 0 = the row
+ * is in split A, bit 1 = in split B; out4 dev f32 [4] = {mean NLL A, correct A, mean NLL B,
+ * correct B}.  C <= 64.  Same per-row arithmetic and summation order as sngnn_head_nll.
+ */
+int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *row_sets,
+                    int64_t N, int C, int64_t n_a, int64_t n_b, float *out4, void *workspace,
+                    void *stream);
+/*
  * Replaces: autograd of self.lin w.r.t. its parameters (models.py:121,237,324):
  *   grad_weight [C, F] = grad_out^T [C, N] . x [N, F],  grad_bias [C] = sum_i grad_out[i]
  * (grad_bias may be NULL).  workspace: sngnn_linear_wgrad_workspace_bytes(N, C, F).

@@ -55,6 +55,7 @@ SIGNATURES = {
     "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_head_workspace_bytes": (_i64, [_i64]),
     "sngnn_head_nll": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "sngnn_head_nll2": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "sngnn_linear_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "sngnn_linear_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "sngnn_linear_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),

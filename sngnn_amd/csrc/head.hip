@@ -42,17 +42,20 @@ constexpr int HEAD_MAX_BLOCKS = 2048;      // persistent grid: partials stay few
 // time in three 6-step shuffle reductions per row).  A row is 4 C contiguous bytes: every
 // byte of every line a lane touches is used, by that lane.  Same arithmetic per row as
 // the wave-per-row form (max, exp(z - max) summed in channel order, first maximum wins).
-template <bool VEC4>
+// TWO: sel[i] is a bit set - bit 0: the row belongs to split A, bit 1: to split B (the
+// validation and test masks read off one eval-mode forward); part[] then holds 4 values per block.
+template <bool VEC4, bool TWO = false>
 __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, const int64_t *__restrict__ y,
                                                    const unsigned char *__restrict__ sel, int64_t N, int C,
                                                    float scale, float *__restrict__ grad,
                                                    float *__restrict__ part)
 {
-    __shared__ float s_loss[4], s_corr[4];
+    __shared__ float s_loss[4], s_corr[4], s_lossb[4], s_corrb[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float loss = 0.f, corr = 0.f;
+    float loss = 0.f, corr = 0.f, lossb = 0.f, corrb = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-        const bool on = sel[i] != 0;
+        const unsigned char sv = sel[i];
+        const bool on = sv != 0;
         float *gi = grad ? grad + i * C : nullptr;
         if (!on) {
             if (gi) {
@@ -91,8 +94,14 @@ __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, 
 #pragma unroll
         for (int c = 0; c < 64; ++c)
             if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
-        loss += -(zy - mx - logf(se));
-        corr += (arg == yi) ? 1.f : 0.f;
+        const float row_loss = -(zy - mx - logf(se)), row_corr = (arg == yi) ? 1.f : 0.f;
+        if constexpr (TWO) {
+            if (sv & 1) { loss += row_loss; corr += row_corr; }
+            if (sv & 2) { lossb += row_loss; corrb += row_corr; }
+        } else {
+            loss += row_loss;
+            corr += row_corr;
+        }
         if (gi) {
             const float inv = scale / se;
 #pragma unroll
@@ -114,9 +123,15 @@ __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, 
     }
     loss = wsum(loss);
     corr = wsum(corr);
-    if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; }
+    if constexpr (TWO) { lossb = wsum(lossb); corrb = wsum(corrb); }
+    if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; s_lossb[wave] = lossb; s_corrb[wave] = corrb; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && TWO) {
+        part[4 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        part[4 * blockIdx.x + 1] = (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+        part[4 * blockIdx.x + 2] = (s_lossb[0] + s_lossb[1]) + (s_lossb[2] + s_lossb[3]);
+        part[4 * blockIdx.x + 3] = (s_corrb[0] + s_corrb[1]) + (s_corrb[2] + s_corrb[3]);
+    } else if (threadIdx.x == 0) {
         part[2 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
         part[2 * blockIdx.x + 1] = (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
     }
@@ -204,13 +219,19 @@ __global__ __launch_bounds__(256) void k_head(const float *__restrict__ z, const
     }
 }
 
-// fixed-order sum of the per-block partials: out[0] = loss_sum * scale, out[1] = correct
+// fixed-order sum of the per-block partials: out[0] = loss_sum * scale, out[1] = correct.
+// Block b of the launch reduces the pair at offset 2 b of every `stride`-float partial
+// (stride 2: one split; stride 4, two blocks: splits A and B with their own scales).
 __global__ __launch_bounds__(256) void k_head_reduce(const float *__restrict__ part, int nblocks,
-                                                     float scale, float *__restrict__ out)
+                                                     float scale, float scale_b, int stride,
+                                                     float *__restrict__ out)
 {
     __shared__ double s[2][256];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    part += 2 * blockIdx.x;
+    out += 2 * blockIdx.x;
+    if (blockIdx.x == 1) scale = scale_b;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += part[(size_t)stride * i]; b += part[(size_t)stride * i + 1]; }
     s[0][threadIdx.x] = a;
     s[1][threadIdx.x] = b;
     __syncthreads();
@@ -340,7 +361,26 @@ using namespace sngnn;
 extern "C" int64_t sngnn_head_workspace_bytes(int64_t N)
 {
     (void)N;
-    return (int64_t)HEAD_MAX_BLOCKS * 8 + 256;
+    return (int64_t)HEAD_MAX_BLOCKS * 16 + 256;
+}
+
+extern "C" int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *row_sets,
+                               int64_t N, int C, int64_t n_a, int64_t n_b, float *out4, void *workspace,
+                               void *stream)
+{
+    SN_REQUIRE(N >= 0 && C >= 1 && C <= 64, SNGNN_EINVAL, "sngnn_head_nll2 needs 1 <= C <= 64");
+    SN_REQUIRE(logits && y && row_sets && out4 && workspace, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)std::min<int64_t>((N + 255) / 256, HEAD_MAX_BLOCKS);
+    const float sa = 1.0f / (float)(n_a > 0 ? n_a : 1), sb = 1.0f / (float)(n_b > 0 ? n_b : 1);
+    const bool vec4 = C % 4 == 0 && (uintptr_t)logits % 16 == 0;
+    if (nb > 0 && vec4)
+        k_head_rows<true, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
+    else if (nb > 0)
+        k_head_rows<false, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
+    k_head_reduce<<<2, 256, 0, st>>>((const float *)workspace, nb, sa, sb, 4, out4);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
 }
 
 extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsigned char *row_mask,
@@ -361,7 +401,7 @@ extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsig
         k_head_rows<false><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
     else if (nb > 0)
         k_head<<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
-    k_head_reduce<<<1, 256, 0, st>>>((const float *)workspace, nb, scale, loss_and_correct);
+    k_head_reduce<<<1, 256, 0, st>>>((const float *)workspace, nb, scale, scale, 2, loss_and_correct);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }

@@ -512,6 +512,32 @@ def head_nll_with_grad(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch
     return (out[0], out[1]), grad
 
 
+@torch.no_grad()
+def head_nll2(logits: torch.Tensor, y: torch.Tensor, row_sets_u8: torch.Tensor, n_a: int, n_b: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``sngnn_head_nll2``: (mean NLL, n_correct) of TWO splits read off one forward - the
+    validation and test metrics of train.py:92-117.  ``row_sets_u8``: uint8 [N], bit 0 = split A,
+    bit 1 = split B.  Returns fp32 [4] = (loss A, correct A, loss B, correct B) (``out`` if
+    given).  No autograd (evaluation); C <= 64."""
+    if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
+        raise ValueError("logits must be a float32 GPU tensor [N, C]")
+    if y.dtype != torch.int64 or row_sets_u8.dtype != torch.uint8:
+        raise ValueError("y must be int64 and row_sets uint8")
+    if out is None:
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+    elif out.dtype != torch.float32 or out.numel() != 4 or not out.is_contiguous() or out.device != logits.device:
+        raise ValueError("out must be a contiguous float32 tensor of 4 elements on the logits' device")
+    lib = _lib.load()
+    z = logits.detach().contiguous()
+    n, c = z.shape
+    ws = _workspace("head", lib.sngnn_head_workspace_bytes(n), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(lib.sngnn_head_nll2(z.data_ptr(), y.contiguous().data_ptr(), row_sets_u8.contiguous().data_ptr(),
+                                       n, c, int(n_a), int(n_b), out.data_ptr(), ws.data_ptr(), _stream(z.device)),
+                   "sngnn_head_nll2")
+    return out
+
+
 def head_nll(logits: torch.Tensor, y: torch.Tensor, row_mask_u8: torch.Tensor, n_masked: int,
              out: Optional[torch.Tensor] = None):
     """(loss, n_correct) of the masked rows: fused log_softmax + nll_loss + accuracy

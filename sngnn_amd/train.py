@@ -103,6 +103,7 @@ class GraphedEpoch:
         self.mask = {k: getattr(data, k + "_mask").to(torch.uint8).contiguous()
                      for k in ("train", "val", "test")}
         self.count = {k: max(int(m.sum()), 1) for k, m in self.mask.items()}
+        self._eval_sets = (self.mask["val"] | (self.mask["test"] << 1)).contiguous()   # bit 0: val, bit 1: test
         self.fused = hasattr(model, "forward_logits")
         self.metrics = torch.zeros(6, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
@@ -190,6 +191,11 @@ class GraphedEpoch:
         with torch.no_grad():
             self.model.eval()
             shared = self._forward() if self.share_eval_forward else None
+            if shared is not None and self.fused and shared.size(1) <= 64:
+                # both splits' metrics in one pass over the logits, straight into metrics[2:6]
+                self._ops.head_nll2(shared, self.data.y, self._eval_sets, self.count["val"],
+                                    self.count["test"], out=self.metrics[2:6])
+                return
             vl, vc = self._loss("val", shared)
             tl, tc = self._loss("test", shared)
             if not self.fused:

@@ -31,6 +31,25 @@ def test_head_matches_log_softmax_nll_and_accuracy(cuda, n, c):
     assert float(l2) == float(loss) and int(c2) == corr_ref
 
 
+@pytest.mark.parametrize("n,c", [(5000, 40), (777, 7), (70001, 47), (300, 64), (1, 3)])
+def test_head_two_splits_equal_two_calls(cuda, n, c):
+    """sngnn_head_nll2 (validation + test metrics off one forward, train.py:92-117) gives exactly
+    what two sngnn_head_nll calls give - overlapping, disjoint and empty splits."""
+    from sngnn_amd import ops
+    g = torch.Generator().manual_seed(n + c)
+    z = (torch.randn(n, c, generator=g) * 3).to(cuda)
+    y = torch.randint(0, c, (n,), generator=g).to(cuda)
+    r = torch.rand(n, generator=g)
+    for ma, mb in (((r < 0.3), (r > 0.6)), ((r < 0.7), (r > 0.4)), ((r < 2), (r < 0))):
+        ma, mb = ma.to(cuda).to(torch.uint8), mb.to(cuda).to(torch.uint8)
+        la, ca = ops.head_nll(z, y, ma, int(ma.sum()))
+        lb, cb = ops.head_nll(z, y, mb, int(mb.sum()))
+        out = ops.head_nll2(z, y, ma | (mb << 1), int(ma.sum()), int(mb.sum()))
+        assert out.tolist() == [float(la), float(ca), float(lb), float(cb)]
+    with pytest.raises(ValueError):
+        ops.head_nll2(torch.zeros(4, 65, device=cuda), y[:4], ma[:4], 1, 1)
+
+
 @pytest.mark.parametrize("n,f,c", [(3000, 128, 40), (2277, 2325, 5), (1000, 33, 47), (513, 200, 70),
                                    (9000, 128, 40), (5001, 77, 64), (4500, 1433, 7), (4100, 100, 33),
                                    # row-tile MFMA path: F in {16, 32, 64, 128}, every tile count
