@@ -171,7 +171,9 @@ int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float *n, const f
  * Deterministic: no floating-point atomics; every sum has a fixed order.
  *
  *   grad_out dev f32 [N, C]        dL/d out
- *   wsel                           as written by sngnn_agg_forward on the same h
+ *   wsel                           as written by sngnn_agg_forward on the same h (only WHICH
+ *                             edges were kept is read from it; the cosines are recomputed from
+ *                             the rows the passes gather anyway)
  *   grad_h   dev f32 [N_total, C]  dL/d h through all three routes (message
  *                             value, norm_i, norm_j) and F.normalize's Jacobian.
  *                             For a partition this is the rank's PARTIAL gradient
