@@ -46,7 +46,8 @@ struct FwdArgs {
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
-    const int4 *rdesc;     // per degree-sorted slot: {row, first edge, in-degree, 0}
+    const int32_t *col_s;       // col with the rows in slot order (rdesc.w = first entry)
+    const int4 *rdesc;     // per degree-sorted slot: {row, first edge, in-degree, first entry in col_s}
     int k;            // < 0: no selection
     float thr;
     float *out, *wsel, *inv_norm;
@@ -321,8 +322,8 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
             const int q = lane + 64 * m;
             const int r = q / SMALL_T, t = q % SMALL_T;
             // descriptor of row r of the set lives in the lanes of group r
-            const int rs = __shfl(d.y, r * G, 64), dg = __shfl(d.z, r * G, 64);
-            c[m] = (r < RPW && t < dg) ? a.col[rs + t] : 0;
+            const int rss = __shfl(d.w, r * G, 64), dg = __shfl(d.z, r * G, 64);
+            c[m] = (r < RPW && t < dg) ? a.col_s[rss + t] : 0;      // consecutive slots: one stream
         }
     };
     auto store_cols = [&](const int (&c)[CPL], int *dst) {
@@ -351,7 +352,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
-        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w == 0, lds_wave, lds_wave + SETW * buf);
+        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
         store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;

@@ -91,7 +91,8 @@ struct sngnn_graph {
     int32_t *cscptr = nullptr, *csc_eid = nullptr, *csc_dst = nullptr;
     int32_t *csc_pos = nullptr;       // [E'] CSR edge index -> its position in the CSC order (inverse of csc_eid)
     int32_t *rperm = nullptr, *sperm = nullptr;
-    int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, 0}
+    int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, first entry in col_s}
+    int32_t *col_s = nullptr;  // [E'] col with the rows in slot order (forward, small rows)
     int4 *sdesc = nullptr;     // [Ntot] per slot of sperm: {source, first CSC entry, out-degree, 0}
     float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm

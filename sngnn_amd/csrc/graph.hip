@@ -121,6 +121,24 @@ __global__ void k_class_key(int32_t *__restrict__ deg, int64_t N)
     if (i < N) deg[i] = max(deg[i], SMALL_T);
 }
 
+// col with the rows in SLOT order: the in-edges of slot p follow those of slot p - 1, so a
+// kernel that walks the slots reads the column ids of consecutive (short) rows as one
+// stream instead of one 128-byte line per row.  off[p] = first entry of slot p (also left in
+// rdesc[p].w); one thread per entry finds its slot by bisection.
+__global__ void k_slot_col(int4 *__restrict__ desc, const int32_t *__restrict__ off, int64_t N, int64_t Ep,
+                           const int32_t *__restrict__ col, int32_t *__restrict__ col_s)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < N) desc[q].w = off[q];
+    if (q >= Ep) return;
+    int64_t lo = 0, hi = N;                    // last slot with off[slot] <= q
+    while (hi - lo > 1) {
+        const int64_t m = (lo + hi) / 2;
+        if (off[m] <= q) lo = m; else hi = m;
+    }
+    col_s[q] = col[desc[lo].y + (int)(q - off[lo])];
+}
+
 __global__ void k_degree(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ deg)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +311,18 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     g->max_in_deg = N ? g->rdeg[0] : 0;
     if ((rc = dev_alloc(&g->rdesc, N))) return rc;
     if (N > 0) k_row_desc<<<grid1(N), 256, 0, st>>>(g->rperm, g->rowptr, N, g->rdesc);
+    {
+        std::vector<int32_t> off((size_t)N + 1, 0);
+        for (int64_t p = 0; p < N; ++p) off[p + 1] = off[p] + g->rdeg[p];
+        DevBuf d_off;
+        if (d_off.alloc(((size_t)N + 1) * 4)) { set_error("out of device memory (graph build)"); return SNGNN_ENOMEM; }
+        if ((rc = dev_alloc(&g->col_s, Ep))) return rc;
+        SN_HIP(hipMemcpyAsync(d_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+        const int64_t nthreads = std::max<int64_t>(N, Ep);
+        if (nthreads > 0)
+            k_slot_col<<<grid1(nthreads), 256, 0, st>>>(g->rdesc, d_off.as<int32_t>(), N, Ep, g->col, g->col_s);
+        SN_HIP(hipStreamSynchronize(st));      // off[] (host) and d_off go out of scope
+    }
     if ((rc = dev_alloc(&g->inv_deg, N))) return rc;
     if (N > 0) k_inv_deg<<<grid1(N), 256, 0, st>>>(g->rowptr, N, g->inv_deg);
 
@@ -377,7 +407,7 @@ int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int 
 void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
-    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->rperm,
+    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->col_s, g->rperm,
                     g->sperm, g->rdesc, g->sdesc, g->inv_deg, g->task_slot, g->task_chunk, g->split_soff, g->split_task0,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
