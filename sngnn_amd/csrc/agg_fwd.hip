@@ -77,7 +77,13 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
 
     FwdArgs a;
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
-    a.rowptr = g->rowptr; a.col = g->col; a.col_s = g->col_s; a.rperm = g->rperm; a.rdesc = g->rdesc;
+    // row order: calls that stream the small rows (deg <= SMALL_T <= top_k, or no top_k) take the
+    // bucket order, calls that rank inside them the exact degree order (graph.hip 5b)
+    const bool stream_small = top_k < 0 || top_k >= SMALL_T;
+    a.rowptr = g->rowptr; a.col = g->col;
+    a.col_s = stream_small ? g->col_s_b : g->col_s;
+    a.rperm = stream_small ? g->rperm_b : g->rperm;
+    a.rdesc = stream_small ? g->rdesc_b : g->rdesc;
     a.k = top_k < 0 ? -1 : top_k; a.thr = thr;
     a.out = out; a.wsel = wsel; a.inv_norm = inv_norm;
     a.sel_src = top_k > 0 ? sel_src : nullptr; a.sel_w = top_k > 0 ? sel_w : nullptr;

@@ -93,6 +93,9 @@ struct sngnn_graph {
     int32_t *rperm = nullptr, *sperm = nullptr;
     int4 *rdesc = nullptr;     // [N] per slot of rperm: {row, first edge, in-degree, first entry in col_s}
     int32_t *col_s = nullptr;  // [E'] col with the rows in slot order (forward, small rows)
+    // the same three for the forward's streaming order (small rows by 4-degree bucket, natural inside)
+    int32_t *rperm_b = nullptr, *col_s_b = nullptr;
+    int4 *rdesc_b = nullptr;
     int4 *sdesc = nullptr;     // [Ntot] per slot of sperm: {source, first CSC entry, out-degree, 0}
     float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
