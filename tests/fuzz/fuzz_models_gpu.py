@@ -21,7 +21,28 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
-cases = skipped = flipped = 0
+cases = skipped = flipped = ref32_off = 0
+
+
+def grads_match_fp64(kind, args, seed, x, ei, y, mod):
+    """The arbiter when the fp32 oracle and the GPU disagree on a gradient: the same oracle in
+    float64.  True when every GPU gradient is within the tolerance of the fp64 one (i.e. the
+    fp32 CPU autograd was the inaccurate side - a row whose norm nearly vanishes behind a
+    ReLU / batch norm makes F.normalize's backward cancel catastrophically in fp32)."""
+    torch.manual_seed(seed)
+    ref64 = getattr(O, kind)(*args)
+    if kind in ("SNGNN", "AGNN"):
+        ref64.dropout.p = 0.0
+    ref64 = ref64.double().train()
+    F.nll_loss(ref64(Data(x=x.double(), edge_index=ei)), y).backward()
+    for p64, q in zip(ref64.parameters(), mod.parameters()):
+        if p64.grad is None:
+            continue
+        sc = max(p64.grad.abs().max().item(), 1e-5)
+        if (q.grad.cpu().double() - p64.grad).abs().max().item() > 2e-3 * sc + 5e-6:
+            return False
+    return True
+
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     n = int(rng.integers(20, 500))
@@ -92,6 +113,9 @@ while time.time() < t_end:
                 if tie_prone and ge > gt:                  # a tie that flipped without moving the output
                     flipped += 1
                     break
+                if ge > gt and grads_match_fp64(kind, args, seed, x, ei, y, mod):
+                    ref32_off += 1                         # the GPU agrees with the fp64 oracle
+                    break
                 assert ge <= gt, f"grad {name}: err {ge:.2e} scale {sc:.2e}"
     except Exception as ex:      # noqa: BLE001
         print("FAIL", tag, "->", repr(ex)[:300], flush=True)
@@ -100,4 +124,5 @@ while time.time() < t_end:
     seed += 1
     if cases % 50 == 0:
         print(f"{cases} cases ok (last {tag})", flush=True)
-print(f"done: {cases} random models passed ({skipped} skipped, {flipped} with near-tie flips in deep selecting models), next seed {seed}")
+print(f"done: {cases} random models passed ({skipped} skipped, {flipped} with near-tie flips in deep selecting models, "
+      f"{ref32_off} where the fp32 oracle's gradient was off and the fp64 oracle sided with the GPU), next seed {seed}")
