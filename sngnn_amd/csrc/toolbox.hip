@@ -56,31 +56,43 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float *__restrict__ 
 // S = diag(inv) X X^T diag(inv) with fp32 MFMA.  Workgroup = 256 threads = 2x2
 // waves, 128x128 output tile, each wave 64x64 = 2x2 MFMA blocks of 32x32.
 //   * S is symmetric: only tiles with row block <= column block are computed, each
-//     writes its mirror image as well (half the flops of the reference's full mm);
-//   * panels [128][32] of the row block and of the column block go through LDS with
-//     a padded stride of 33 floats (lane -> (row l & 31, k = l >> 5) reads hit 32
-//     different banks); global loads are coalesced 128-byte row segments and the
-//     NEXT k-step's panels are already in registers while the current one is
-//     multiplied (one LDS buffer, register double buffering).
+//     writes its mirror image as well (half the flops of the reference's full mm); the
+//     mirror goes through an LDS transpose so that both images leave as 128-byte rows.
+//   * Panels [128][32] of the row block and of the column block go through LDS with a
+//     stride of 36 floats.  The k order of a contraction is free: MFMA j of a K-step takes
+//     k = j from the lanes' lower half and k = 16 + j from the upper half, so a lane's 16
+//     operands of a step are 16 CONSECUTIVE floats of its row - four ds_read_b128 per block
+//     row instead of sixteen ds_read_b32, bank-conflict-free at that stride.
+//   * x is read as 16-byte vectors from rows of `ld` floats (ld % 4 == 0, zero-padded: the
+//     launcher makes a padded copy when F is not a multiple of 4), unconditionally (clamped
+//     row, value zeroed at staging time), one K-step ahead: the NEXT step's panels travel
+//     while the current one is multiplied.
+//   * The prefetch registers are NAMED ext-vector variables in straight-line code.  Round 2
+//     found the first version (float4 structs filled by a lambda over a small array, a bounds
+//     select on the loaded value) keeping them in stack slots: every load was followed by a
+//     scratch store - i.e. waited for on the spot, in front of the MFMAs it was meant to
+//     travel behind.  tools/micro/cosine_mfma_bench.hip: 1.40 -> 0.63 ms at Actor's size with
+//     nothing else changed; the MFMAs alone take 0.44 ms.
 // ---------------------------------------------------------------------------
-constexpr int TB_M = 128, TB_K = 32, TB_LD = TB_K + 1, TB_LOADS = TB_M * TB_K / 256;
+constexpr int TB_M = 128, TB_K = 32, TB_LD = TB_K + 4;
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 // Few tiles (N of a few thousand: 171 upper-triangle tiles at Chameleon's size for 256 CUs):
 // the contraction is split over ks workgroups per tile, each writes its raw partial tile
 // (both orientations) to part[s] and k_cosine_reduce adds the ks partials in a fixed order
 // and applies the inverse norms.
 __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x, int64_t N,
-                                                     int64_t F, const float *__restrict__ inv,
+                                                     int64_t ld, const float *__restrict__ inv,
                                                      float *__restrict__ S, int nb, int ks, int64_t k_per,
                                                      float *__restrict__ part)
 {
-    __shared__ float sA[TB_M * TB_LD];
-    __shared__ float sB[TB_M * TB_LD];
+    __shared__ __align__(16) float sA[TB_M * TB_LD];
+    __shared__ __align__(16) float sB[TB_M * TB_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;          // wave's 64x64 quadrant
     // linear workgroup id -> (by <= bx) of the upper triangle, row by row
     const int split = blockIdx.x % ks;
-    const int64_t k_begin = (int64_t)split * k_per, k_end = min(F, k_begin + k_per);
+    const int64_t k_begin = (int64_t)split * k_per, k_end = min(ld, k_begin + k_per);
     int by = 0, rem = blockIdx.x / ks;
     while (rem >= nb - by) { rem -= nb - by; ++by; }
     const int bx = by + rem;
@@ -94,67 +106,109 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // staging: thread t owns column t & 31 of rows (t >> 5) + 8 u, u = 0..15
-    const int sc = tid & 31, sr = tid >> 5;
-    float ra[TB_LOADS], rb[TB_LOADS];
-    auto fetch = [&](int64_t k0) {
-        const int64_t k = k0 + sc;
-#pragma unroll
-        for (int u = 0; u < TB_LOADS; ++u) {
-            const int64_t r_a = row0 + sr + 8 * u, r_b = col0 + sr + 8 * u;
-            ra[u] = (r_a < N && k < k_end) ? x[r_a * F + k] : 0.f;
-            rb[u] = diag ? ra[u] : ((r_b < N && k < k_end) ? x[r_b * F + k] : 0.f);
-        }
-    };
-    fetch(k_begin);
+    // staging: thread t owns the 16-byte vector (t & 7) of rows (t >> 3) + 32 u, u = 0..3
+    const int kq = tid & 7, r0 = tid >> 3;
+    f4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+    const float *ga0 = x + min(row0 + r0, N - 1) * ld + 4 * kq, *ga1 = x + min(row0 + r0 + 32, N - 1) * ld + 4 * kq;
+    const float *ga2 = x + min(row0 + r0 + 64, N - 1) * ld + 4 * kq, *ga3 = x + min(row0 + r0 + 96, N - 1) * ld + 4 * kq;
+    const float *gb0 = x + min(col0 + r0, N - 1) * ld + 4 * kq, *gb1 = x + min(col0 + r0 + 32, N - 1) * ld + 4 * kq;
+    const float *gb2 = x + min(col0 + r0 + 64, N - 1) * ld + 4 * kq, *gb3 = x + min(col0 + r0 + 96, N - 1) * ld + 4 * kq;
+    const bool oa0 = row0 + r0 < N, oa1 = row0 + r0 + 32 < N, oa2 = row0 + r0 + 64 < N, oa3 = row0 + r0 + 96 < N;
+    const bool ob0 = col0 + r0 < N, ob1 = col0 + r0 + 32 < N, ob2 = col0 + r0 + 64 < N, ob3 = col0 + r0 + 96 < N;
+    float *wa = sA + r0 * TB_LD + 4 * kq, *wb = sB + r0 * TB_LD + 4 * kq;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    // (a 16-byte vector of a row is entirely below k_end or entirely beyond: ld, k_per % 4 == 0)
+#define SN_FETCH(K0)                                                                         \
+    {                                                                                        \
+        const int64_t kk_ = (4 * kq + (K0) < k_end) ? (K0) : k_begin;                        \
+        va0 = *(const f4 *)(ga0 + kk_); va1 = *(const f4 *)(ga1 + kk_);                      \
+        va2 = *(const f4 *)(ga2 + kk_); va3 = *(const f4 *)(ga3 + kk_);                      \
+        if (!diag) {                                                                         \
+            vb0 = *(const f4 *)(gb0 + kk_); vb1 = *(const f4 *)(gb1 + kk_);                  \
+            vb2 = *(const f4 *)(gb2 + kk_); vb3 = *(const f4 *)(gb3 + kk_);                  \
+        }                                                                                    \
+    }
+#define SN_STAGE(K0)                                                                         \
+    {                                                                                        \
+        const bool kin_ = 4 * kq + (K0) < k_end;                                             \
+        const f4 s0 = (oa0 && kin_) ? va0 : z, s1 = (oa1 && kin_) ? va1 : z;                 \
+        const f4 s2 = (oa2 && kin_) ? va2 : z, s3 = (oa3 && kin_) ? va3 : z;                 \
+        *(f4 *)(wa) = s0;              *(f4 *)(wa + 32 * TB_LD) = s1;                        \
+        *(f4 *)(wa + 64 * TB_LD) = s2; *(f4 *)(wa + 96 * TB_LD) = s3;                        \
+        if (diag) {                                                                          \
+            *(f4 *)(wb) = s0;              *(f4 *)(wb + 32 * TB_LD) = s1;                    \
+            *(f4 *)(wb + 64 * TB_LD) = s2; *(f4 *)(wb + 96 * TB_LD) = s3;                    \
+        } else {                                                                             \
+            *(f4 *)(wb) = (ob0 && kin_) ? vb0 : z;              *(f4 *)(wb + 32 * TB_LD) = (ob1 && kin_) ? vb1 : z; \
+            *(f4 *)(wb + 64 * TB_LD) = (ob2 && kin_) ? vb2 : z; *(f4 *)(wb + 96 * TB_LD) = (ob3 && kin_) ? vb3 : z; \
+        }                                                                                    \
+    }
+    vb0 = vb1 = vb2 = vb3 = z;
+    SN_FETCH(k_begin)
+    const int li = lane & 31, lh = lane >> 5;
+    const float *pa0 = sA + (wr * 64 + li) * TB_LD + 16 * lh, *pa1 = pa0 + 32 * TB_LD;
+    const float *pb0 = sB + (wc * 64 + li) * TB_LD + 16 * lh, *pb1 = pb0 + 32 * TB_LD;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += TB_K) {
         __syncthreads();                                  // previous step's LDS reads are done
-#pragma unroll
-        for (int u = 0; u < TB_LOADS; ++u) {
-            sA[(sr + 8 * u) * TB_LD + sc] = ra[u];
-            sB[(sr + 8 * u) * TB_LD + sc] = rb[u];
-        }
+        SN_STAGE(k0)
         __syncthreads();
-        if (k0 + TB_K < k_end) fetch(k0 + TB_K);          // in flight during the MFMAs below
+        if (k0 + TB_K < k_end) SN_FETCH(k0 + TB_K)        // in flight during the MFMAs below
 #pragma unroll
-        for (int kk = 0; kk < TB_K; kk += 2) {
-            float a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // 32x32x2: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]
-                a[t] = sA[(wr * 64 + t * 32 + (lane & 31)) * TB_LD + kk + (lane >> 5)];
-                b[t] = sB[(wc * 64 + t * 32 + (lane & 31)) * TB_LD + kk + (lane >> 5)];
-            }
-#pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const f4 ca0 = *(const f4 *)(pa0 + 4 * q), ca1 = *(const f4 *)(pa1 + 4 * q);
+            const f4 cb0 = *(const f4 *)(pb0 + 4 * q), cb1 = *(const f4 *)(pb1 + 4 * q);
+#define SN_MFMA4(E)                                                                             \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0.E, cb0.E, acc[0][0], 0, 0, 0);    \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0.E, cb1.E, acc[0][1], 0, 0, 0);    \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1.E, cb0.E, acc[1][0], 0, 0, 0);    \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1.E, cb1.E, acc[1][1], 0, 0, 0);
+            SN_MFMA4(x) SN_MFMA4(y) SN_MFMA4(z) SN_MFMA4(w)
+#undef SN_MFMA4
         }
     }
-    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#undef SN_FETCH
+#undef SN_STAGE
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    // The tile itself leaves with the lanes along a row of S; its mirror image is transposed
+    // through LDS (the panels are dead) so that it leaves the same way.
+    __syncthreads();
+    float *T = sA + wave * (32 * 33);                     // [32][33] per wave (4 * 1056 <= 128 * 36)
+    float *dst = ks == 1 ? S : part + (size_t)split * N * N;
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const int64_t c = col0 + wc * 64 + tb * 32 + (lane & 31);
-            const float ic = c < N ? inv[c] : 0.f;
+            const int64_t cb = col0 + wc * 64 + tb * 32, rb0 = row0 + wr * 64 + ta * 32;
+            const int64_t c = cb + li;
+            const float ic = (ks == 1 && c < N) ? inv[c] : 1.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t rr = row0 + wr * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (rr < N && c < N) {
-                    if (ks == 1) {
-                        const float v = acc[ta][tb][r] * (inv[rr] * ic);
-                        S[rr * N + c] = v;
-                        if (!diag) S[c * N + rr] = v;     // mirror image of an off-diagonal tile
-                    } else {
-                        float *P = part + (size_t)split * N * N;
-                        P[rr * N + c] = acc[ta][tb][r];
-                        if (!diag) P[c * N + rr] = acc[ta][tb][r];
-                    }
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int64_t rr = rb0 + rl;
+                float v = acc[ta][tb][r];
+                if (ks == 1) v *= (rr < N ? inv[rr] : 0.f) * ic;
+                if (rr < N && c < N) dst[rr * N + c] = v;
+                if (!diag) T[li * 33 + rl] = v;           // transposed: T[column][row]
+            }
+            if (!diag) {                                  // (workgroup-uniform)
+                __syncthreads();
+#pragma unroll
+                for (int cc = 0; cc < 32; cc += 2) {
+                    const int64_t mc = cb + cc + lh, mr = rb0 + li;     // element (mr, mc) of S -> S[mc][mr]
+                    if (mc < N && mr < N) dst[mc * N + mr] = T[(cc + lh) * 33 + li];
                 }
+                __syncthreads();
             }
         }
+}
+
+// rows of F floats -> rows of ld floats (ld % 4 == 0), zero padding behind column F
+__global__ void k_pad_rows(const float *__restrict__ x, int64_t N, int64_t F, int64_t ld, float *__restrict__ xp)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * ld) return;
+    const int64_t r = t / ld, c = t % ld;
+    xp[t] = c < F ? x[r * F + c] : 0.f;
 }
 
 // S = (sum of the ks partial products, in split order) * inv_r * inv_c; workgroup = one row segment
@@ -288,16 +342,25 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(), nullptr);
     const int nb = (int)((N + TB_M - 1) / TB_M);
     const int tiles = nb * (nb + 1) / 2;
+    // the kernel reads 16-byte vectors from rows of ld floats: a zero-padded copy when the rows
+    // of x do not allow that (F % 4 != 0 - Cora's 1433, Chameleon's 2325 - or a misaligned base)
+    const int64_t ld = (F + 3) / 4 * 4;
+    AsyncBuf xpad(st);
+    const float *xs = x;
+    if (ld != F || (uintptr_t)x % 16 != 0) {
+        SN_REQUIRE(xpad.alloc((size_t)N * ld * 4) == 0, SNGNN_ENOMEM, "out of device memory");
+        k_pad_rows<<<(unsigned)((N * ld + 255) / 256), 256, 0, st>>>(x, N, F, ld, xpad.as<float>());
+        xs = xpad.as<float>();
+    }
     // tiles for at most three quarters of the CUs: split the contraction (at least two K-steps per
-    // split).  Measured: Chameleon's 171 tiles 570 -> 480 us with 3 splits; at Cora's 253 tiles (one
-    // per CU already) splitting only added the reduction pass (355 -> 391 us), hence the bound.
+    // split); the partial tiles are added in split order by k_cosine_reduce (deterministic)
     int ks = 1;
-    if (tiles <= 192) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, F / (2 * TB_K)));
-    const int64_t k_per = ((F + ks - 1) / ks + TB_K - 1) / TB_K * TB_K;
-    ks = (int)((F + k_per - 1) / k_per);
+    if (tiles <= 96) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, ld / (2 * TB_K)));
+    const int64_t k_per = ((ld + ks - 1) / ks + TB_K - 1) / TB_K * TB_K;
+    ks = (int)((ld + k_per - 1) / k_per);
     AsyncBuf part(st);
     if (ks > 1) SN_REQUIRE(part.alloc((size_t)ks * N * N * 4) == 0, SNGNN_ENOMEM, "out of device memory");
-    k_cosine_mfma<<<tiles * ks, 256, 0, st>>>(x, N, F, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
+    k_cosine_mfma<<<tiles * ks, 256, 0, st>>>(xs, N, ld, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
     if (ks > 1) {
         SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "internal: split contraction is for small N only");
         k_cosine_reduce<<<dim3((unsigned)std::min<int64_t>((N + 255) / 256, 8), (unsigned)N), 256, 0, st>>>(
