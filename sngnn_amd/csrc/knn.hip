@@ -23,7 +23,8 @@
 namespace sngnn {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int KN_M = 128, KN_K = 32, KN_LD = KN_K + 1, KN_LOADS = KN_M * KN_K / 256;
+constexpr int KN_M = 128, KN_K = 32, KN_LD = KN_K + 4, KN_LOADS = KN_M * KN_K / 256;   // (stride 36: 16-byte rows, conflict-free b128 reads)
+typedef float knn_f4 __attribute__((ext_vector_type(4)));
 constexpr int KNN_MAX_K = 32;
 
 // k-th largest of the (unique, non-zero) keys held two per lane; at least k keys are set
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         }
     }
 
+    knn_f4 rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0, rb2 = rb0, rb3 = rb0;      // the column panel in flight (FH > 0)
     for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
         const int64_t col0 = ct * KN_M;
         f32x16 acc[4];
@@ -113,33 +115,50 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         if constexpr (FH > 0) {
-            float rb[KN_LOADS];
-            // k-step = 16 steps of each half: columns [s0, s0 + 16) and [FH + s0, FH + s0 + 16)
-            const int kc = sc < 16 ? sc : FH + sc - 16;
-            auto fetchb = [&](int s0) {
-#pragma unroll
-                for (int u = 0; u < KN_LOADS; ++u) {
-                    const int64_t r_b = min(col0 + sr + 8 * u, N - 1);
-                    rb[u] = x[r_b * F + s0 + kc];
-                }
-            };
-            fetchb(0);
+            // k-step = 16 steps of each half: columns [s0, s0 + 16) and [FH + s0, FH + s0 + 16) of
+            // the column block's rows, as 16-byte vectors: thread t owns vector (t & 7) - four
+            // of each half - of rows (t >> 3) + 32 u.  The panel of the NEXT step travels while
+            // this one is multiplied, and the first panel of the NEXT TILE while this tile's
+            // cosines go through the selection below.  (Named registers: see toolbox.hip,
+            // k_cosine_mfma - a private array that lives across the tile loop's back edge goes
+            // to scratch memory and its loads are waited for at once.)
+            const int seg = tid & 7, pr = tid >> 3;
+            const int kseg = seg < 4 ? 4 * seg : FH + 4 * (seg - 4);
+#define SN_KNN_FETCH(COL0, S0)                                                                            \
+            {                                                                                             \
+                const float *g_ = x + (S0) + kseg;                                                        \
+                rb0 = *(const knn_f4 *)(g_ + min((COL0) + pr, N - 1) * F);                                \
+                rb1 = *(const knn_f4 *)(g_ + min((COL0) + pr + 32, N - 1) * F);                           \
+                rb2 = *(const knn_f4 *)(g_ + min((COL0) + pr + 64, N - 1) * F);                           \
+                rb3 = *(const knn_f4 *)(g_ + min((COL0) + pr + 96, N - 1) * F);                           \
+            }
+            if (ct == ct_begin) SN_KNN_FETCH(col0, 0)
+            float *wb = sB + pr * KN_LD + 4 * seg;
+            const float *pb = sB + l32 * KN_LD + half * 16;
 #pragma unroll
             for (int s0 = 0; s0 < FH; s0 += 16) {
                 __syncthreads();
-#pragma unroll
-                for (int u = 0; u < KN_LOADS; ++u) sB[(sr + 8 * u) * KN_LD + sc] = rb[u];
+                *(knn_f4 *)(wb) = rb0;
+                *(knn_f4 *)(wb + 32 * KN_LD) = rb1;
+                *(knn_f4 *)(wb + 64 * KN_LD) = rb2;
+                *(knn_f4 *)(wb + 96 * KN_LD) = rb3;
                 __syncthreads();
-                if (s0 + 16 < FH) fetchb(s0 + 16);
+                if (s0 + 16 < FH) SN_KNN_FETCH(col0, s0 + 16)
+                else if (ct + 1 < ct_end) SN_KNN_FETCH(col0 + KN_M, 0)
 #pragma unroll
-                for (int ss = 0; ss < 16; ++ss) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const float bv = sB[(b * 32 + l32) * KN_LD + half * 16 + ss];
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + ss], bv, acc[b], 0, 0, 0);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const knn_f4 b0 = *(const knn_f4 *)(pb + 4 * q), b1 = *(const knn_f4 *)(pb + 32 * KN_LD + 4 * q);
+                    const knn_f4 b2 = *(const knn_f4 *)(pb + 64 * KN_LD + 4 * q), b3 = *(const knn_f4 *)(pb + 96 * KN_LD + 4 * q);
+#define SN_KNN_MFMA(E, SS)                                                                                \
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + 4 * q + SS], b0.E, acc[0], 0, 0, 0);  \
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + 4 * q + SS], b1.E, acc[1], 0, 0, 0);  \
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + 4 * q + SS], b2.E, acc[2], 0, 0, 0);  \
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s0 + 4 * q + SS], b3.E, acc[3], 0, 0, 0);
+                    SN_KNN_MFMA(x, 0) SN_KNN_MFMA(y, 1) SN_KNN_MFMA(z, 2) SN_KNN_MFMA(w, 3)
+#undef SN_KNN_MFMA
                 }
             }
+#undef SN_KNN_FETCH
         } else {
         float ra[KN_LOADS], rb[KN_LOADS];
         auto fetch = [&](int64_t k0) {
