@@ -111,8 +111,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 
+// (one wave per SIMD is what is launched; the widest configuration - 64 output columns of 128
+// inputs: W^T alone is 128 registers - is allowed the whole register file, the others keep the
+// two-wave budget they were tuned with: at 256 registers the wide one spilled and took 65 us
+// instead of 36 us; rocBLAS: 83 us)
 template <int NT, int FQ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NT == 4 && FQ == 8) ? 1 : 2, (NT == 4 && FQ == 8) ? 1 : 2)))
 void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                    int N, int C, float *__restrict__ h, int ntiles)
 {
