@@ -82,6 +82,13 @@ def _lin_aligned(x: torch.Tensor, lin: nn.Linear):
     return ops._Linear.apply(x, lin.weight, lin.bias, cp), c
 
 
+def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
+    """Drop the zero channels `_lin_aligned` appended - only when it did: a full-range slice is
+    still an autograd node whose backward zero-fills a [N, C] tensor and copies the gradient
+    into it (two passes over 27-43 MB per layer at arxiv size for nothing)."""
+    return out if out.size(1) == c else out[:, :c]
+
+
 def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float) -> torch.Tensor:
     """Fused aggregation of the local rows; under a node-range partition the feature rows
     the rank's in-edges reference are exchanged first (RCCL), see sngnn_amd/dist.py."""
@@ -113,7 +120,7 @@ class SNConv(nn.Module):
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, False)
         h, c = _lin_aligned(x, self.lin)
-        out = _aggregate(h, graph, shard, None, 0.0)[:, :c]
+        out = _true_width(_aggregate(h, graph, shard, None, 0.0), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -140,7 +147,7 @@ class AGNNConv(nn.Module):
         h, c = _lin_aligned(x, self.lin)
         if shard is not None:
             h = shard.table(h)
-        return ops.attention(h, graph)[:, :c]
+        return _true_width(ops.attention(h, graph), c)
 
 
 class SNConv_plus(nn.Module):
@@ -171,7 +178,7 @@ class SNConv_plus(nn.Module):
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         h, c = _lin_aligned(x, self.lin)
-        out = _aggregate(h, graph, shard, int(self.top_k), float(self.thr))[:, :c]
+        out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr)), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -319,7 +326,7 @@ class SNConv_plus_plus(nn.Module):
                 graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
                                              row_range=(part.row_begin, part.row_end))
                 out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
-        out_1 = _aggregate(h, graph, shard, int(self.top_k), float(self.thr))[:, :c]
+        out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr)), c)
         out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias
