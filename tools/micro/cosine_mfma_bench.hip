@@ -1,7 +1,7 @@
 // Micro-benchmark: where the time of the symmetric fp32-MFMA cosine tile kernel goes.
 // Variants of the 128x128-tile kernel with parts switched off (results are then wrong; timing only):
 //   MODE 0 full   1 no global loads (panels staged once)   2 no LDS reads (constant operands)
-//   3 MFMAs only (no staging, no LDS, no barriers)
+//   3 MFMAs only (no staging, no LDS, no barriers)   4 full, panels prefetched two K-steps ahead
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/cosine_mfma_bench.hip -o /tmp/cosb && /tmp/cosb [N] [F]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // lambdas, no arrays, no struct float4): anything the compiler keeps in a stack slot across
     // the loop's back edge is written to scratch memory right behind its load - which waits for it
     f4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
+    f4 vc0, vc1, vc2, vc3, vd0, vd1, vd2, vd3;      // MODE 4: second prefetch stage
     const float *ga0 = x + min(row0 + r0, N - 1) * F + 4 * kq, *ga1 = x + min(row0 + r0 + 32, N - 1) * F + 4 * kq;
     const float *ga2 = x + min(row0 + r0 + 64, N - 1) * F + 4 * kq, *ga3 = x + min(row0 + r0 + 96, N - 1) * F + 4 * kq;
     const float *gb0 = x + min(col0 + r0, N - 1) * F + 4 * kq, *gb1 = x + min(col0 + r0 + 32, N - 1) * F + 4 * kq;
@@ -57,7 +58,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *(f4 *)(wb) = (ob0 && kin_) ? vb0 : z;              *(f4 *)(wb + 32 * TB_LD) = (ob1 && kin_) ? vb1 : z; \
         *(f4 *)(wb + 64 * TB_LD) = (ob2 && kin_) ? vb2 : z; *(f4 *)(wb + 96 * TB_LD) = (ob3 && kin_) ? vb3 : z; \
     }
+#define SN_FETCH2(K0)                                                                        \
+    {                                                                                        \
+        const int64_t kk_ = (4 * kq + (K0) < F) ? (K0) : -(int64_t)(4 * kq);                 \
+        vc0 = *(const f4 *)(ga0 + kk_); vc1 = *(const f4 *)(ga1 + kk_);                      \
+        vc2 = *(const f4 *)(ga2 + kk_); vc3 = *(const f4 *)(ga3 + kk_);                      \
+        vd0 = *(const f4 *)(gb0 + kk_); vd1 = *(const f4 *)(gb1 + kk_);                      \
+        vd2 = *(const f4 *)(gb2 + kk_); vd3 = *(const f4 *)(gb3 + kk_);                      \
+    }
+#define SN_STAGE2(K0)                                                                        \
+    {                                                                                        \
+        const bool kin_ = 4 * kq + (K0) < F;                                                 \
+        *(f4 *)(wa) = (oa0 && kin_) ? vc0 : z;              *(f4 *)(wa + 32 * TB_LD) = (oa1 && kin_) ? vc1 : z; \
+        *(f4 *)(wa + 64 * TB_LD) = (oa2 && kin_) ? vc2 : z; *(f4 *)(wa + 96 * TB_LD) = (oa3 && kin_) ? vc3 : z; \
+        *(f4 *)(wb) = (ob0 && kin_) ? vd0 : z;              *(f4 *)(wb + 32 * TB_LD) = (ob1 && kin_) ? vd1 : z; \
+        *(f4 *)(wb + 64 * TB_LD) = (ob2 && kin_) ? vd2 : z; *(f4 *)(wb + 96 * TB_LD) = (ob3 && kin_) ? vd3 : z; \
+    }
+    vc0 = vc1 = vc2 = vc3 = vd0 = vd1 = vd2 = vd3 = z;
     SN_FETCH(0)
+    if (MODE == 4) SN_FETCH2(TB_K)
     if (MODE == 1 || MODE == 2) { SN_STAGE(0) __syncthreads(); }
     const int li = lane & 31, lh = lane >> 5;
     for (int64_t k0 = 0; k0 < F; k0 += TB_K) {
@@ -67,12 +86,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             if (k0 + TB_K < F) SN_FETCH(k0 + TB_K)
         }
+        if (MODE == 4) {                                  // two steps ahead, register sets alternate
+            __syncthreads();
+            if ((k0 / TB_K) & 1) { SN_STAGE2(k0) } else { SN_STAGE(k0) }
+            __syncthreads();
+            if (k0 + 2 * TB_K < F) { if ((k0 / TB_K) & 1) { SN_FETCH2(k0 + 2 * TB_K) } else { SN_FETCH(k0 + 2 * TB_K) } }
+        }
         const float *pa0 = sA + (wr * 64 + li) * TB_LD + 16 * lh, *pa1 = pa0 + 32 * TB_LD;
         const float *pb0 = sB + (wc * 64 + li) * TB_LD + 16 * lh, *pb1 = pb0 + 32 * TB_LD;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f4 ca0, ca1, cb0, cb1;
-            if (MODE <= 1) {
+            if (MODE <= 1 || MODE == 4) {
                 ca0 = *(const f4 *)(pa0 + 4 * q);
                 ca1 = *(const f4 *)(pa1 + 4 * q);
                 cb0 = *(const f4 *)(pb0 + 4 * q);
@@ -125,6 +150,8 @@ int main(int argc, char **argv)
     hipMemcpy(x, h.data(), N * F * 4, hipMemcpyHostToDevice);
     const double gf = (double)N * N * F / 1e9;      // flops actually done (upper triangle): N^2 F
     const float t0 = run<0>(x, N, F, S, 10), t1 = run<1>(x, N, F, S, 10), t2 = run<2>(x, N, F, S, 10), t3 = run<3>(x, N, F, S, 10);
+    const float t4 = run<4>(x, N, F, S, 10);
+    printf("  prefetch two K-steps ahead: %.3f ms (%.1f TF)\n", t4, gf / t4);
     printf("N=%lld F=%lld (%.1f GF done)  full %.3f ms (%.1f TF)   no-global %.3f   no-LDS-reads %.3f   MFMA-only %.3f ms (%.1f TF)\n",
            (long long)N, (long long)F, gf, t0, gf / t0, t1, t2, t3, gf / t3);
     return 0;
