@@ -632,3 +632,117 @@ def node_similarity_dense_large_parted(x: Tensor):
 def class_similarity_dense_large(x: Tensor, y: Tensor) -> Tensor:
     """dense.py:104-130: block sums / block sizes == the small variant's means."""
     return class_similarity_dense_small(x, y)[0]
+
+
+def sort_edge_index(edge_index: Tensor, num_nodes: Optional[int] = None) -> Tensor:
+    """PyG 2.0.4 ``torch_geometric.utils.sort_edge_index(edge_index)`` as called at
+    dense.py:34,66 and sparse.py:86: ``idx = row * num_nodes + col`` with
+    ``num_nodes = edge_index.max() + 1``, ``perm = idx.argsort()``, columns permuted
+    (sorted by source, then target)."""
+    if num_nodes is None:
+        num_nodes = int(edge_index.max()) + 1 if edge_index.numel() else 0
+    idx = edge_index[0] * num_nodes + edge_index[1]
+    return edge_index[:, idx.argsort(stable=True)]
+
+
+def _out_neighbour_lists(edge_index: Tensor, num_nodes: int) -> List[Tensor]:
+    """The scan of dense.py:38-48 (= :70-80, sparse.py:55-65, :91-101) on a SOURCE-SORTED
+    edge list: node i's list is the run of edges whose source is i that starts at the scan
+    cursor; the cursor only moves when a run is closed by an edge of a different source."""
+    src = edge_index[0].tolist()
+    dst = edge_index[1].tolist()
+    lists, k, e = [], 0, len(src)
+    for i in range(num_nodes):
+        cur, j = [], k
+        while j < e:
+            if src[j] == i:
+                cur.append(dst[j])
+                j += 1
+            else:
+                k = j
+                break
+        lists.append(torch.tensor(cur, dtype=torch.long))
+    return lists
+
+
+def linked_node_similarity_dense_large(x: Tensor, edge_index: Tensor):
+    """dense.py:33-62: S[k, linked(k)] listed node by node over the source-sorted edges."""
+    ei = sort_edge_index(edge_index)
+    norm = F.normalize(x, p=2., dim=-1)
+    all_sim = []
+    for k, linked in enumerate(_out_neighbour_lists(ei, norm.shape[0])):
+        all_sim.append(torch.mm(norm[k, :].reshape(1, -1), norm.T).reshape(-1)[linked])
+    all_sim = torch.concat(all_sim, -1)
+    return all_sim.reshape(-1, 1), torch.mean(all_sim.reshape(-1, 1))
+
+
+def neighborhood_similarity_dense_large(x: Tensor, edge_index: Tensor):
+    """dense.py:65-101: per node the mean of S[k, linked(k)] (0 for a node without
+    out-edges: ``sum(empty) / 1``), and ``sum_k avg_k * (1 / N)`` over ALL nodes."""
+    ei = sort_edge_index(edge_index)
+    norm = F.normalize(x, p=2., dim=-1)
+    n = norm.shape[0]
+    all_sim, mean_tmp = [], 0
+    for k, linked in enumerate(_out_neighbour_lists(ei, n)):
+        if linked.numel():
+            avg = torch.sum(torch.mm(norm[k, :].reshape(1, -1), norm.T).reshape(-1)[linked]) / linked.numel()
+        else:
+            avg = torch.zeros(())
+        mean_tmp = mean_tmp + avg * (1 / n)
+        all_sim.append(avg)
+    return torch.stack(all_sim).reshape(-1, 1), mean_tmp
+
+
+# SimGFAToolbox/sparse.py: the arithmetic is scikit-learn's ``normalize(axis=0)`` (column
+# L2 norms in float64, a zero column keeps norm 1) and scipy's sparse product, both float64;
+# restated densely in float64 numpy, then read out the way the reference reads its rows
+# (``torch.Tensor(sim.getrow(m).toarray())``: a cast to float32).
+
+def cosine_similarity_sparse(mat):
+    """sparse.py:8-14 for a scipy matrix or a dense array ``mat`` [rows, cols]:
+    returns the dense float64 [cols, cols] array of ``Mn.T @ Mn``."""
+    import numpy as np
+    m = np.asarray(mat.todense() if hasattr(mat, "todense") else mat, dtype=np.float64)
+    nrm = np.sqrt((m * m).sum(axis=0))
+    nrm[nrm == 0.0] = 1.0
+    mn = m / nrm
+    return mn.T @ mn
+
+
+def node_similarity_sparse(x):
+    """sparse.py:17-42: all entries (diagonal included) as fp32 [N*N, 1] and their mean."""
+    sim = torch.from_numpy(cosine_similarity_sparse(x)).to(torch.float32)
+    return sim.reshape(-1, 1), torch.sum(sim) / sim.numel()
+
+
+def linked_node_similarity_sparse(x, edge_index: Tensor):
+    """sparse.py:45-77 (the edge list is NOT sorted there: source-sorted input expected)."""
+    sim = torch.from_numpy(cosine_similarity_sparse(x)).to(torch.float32)
+    all_sim = [sim[k][linked] for k, linked in enumerate(_out_neighbour_lists(edge_index, sim.shape[0]))]
+    all_sim = torch.concat(all_sim, -1)
+    return all_sim.reshape(-1, 1), torch.mean(all_sim.reshape(-1, 1))
+
+
+def neighborhood_similarity_sparse(x, edge_index: Tensor):
+    """sparse.py:80-120."""
+    ei = sort_edge_index(edge_index)
+    sim = torch.from_numpy(cosine_similarity_sparse(x)).to(torch.float32)
+    n = sim.shape[0]
+    all_sim, mean_tmp = [], 0
+    for k, linked in enumerate(_out_neighbour_lists(ei, n)):
+        avg = torch.sum(sim[k][linked]) / linked.numel() if linked.numel() else torch.zeros(())
+        mean_tmp = mean_tmp + avg * (1 / n)
+        all_sim.append(avg)
+    return torch.stack(all_sim).reshape(-1, 1), mean_tmp
+
+
+def class_similarity_sparse(x, y: Tensor) -> Tensor:
+    """sparse.py:123-152: block sums / block sizes per ordered class pair."""
+    sim = torch.from_numpy(cosine_similarity_sparse(x)).to(torch.float32)
+    n_classes = len(torch.unique(y))
+    out = torch.zeros(n_classes, n_classes)
+    for i in range(n_classes):
+        for j in range(n_classes):
+            blk = sim[torch.where(y == i)[0], :][:, torch.where(y == j)[0]]
+            out[i, j] = torch.sum(blk) / blk.numel()
+    return out

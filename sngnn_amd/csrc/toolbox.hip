@@ -36,7 +36,7 @@ __device__ __forceinline__ double wave_sum_d(double v)
 // inv[i] = 1 / max(||x_i||, eps)   (one wave per row; F.normalize semantics)
 __global__ __launch_bounds__(256) void k_row_inv_norm(const float *__restrict__ x, int64_t N,
                                                       int64_t F, float *__restrict__ inv,
-                                                      double *__restrict__ diag_sum)
+                                                      double *__restrict__ diag)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,8 +48,25 @@ __global__ __launch_bounds__(256) void k_row_inv_norm(const float *__restrict__ 
     const float r = 1.0f / fmaxf(sqrtf(ss), EPS_NORM);
     if (lane == 0) {
         inv[row] = r;
-        if (diag_sum) atomicAdd(diag_sum, (double)ss * (double)r * (double)r);   // <n_i, n_i>
+        if (diag) diag[row] = (double)ss * (double)r * (double)r;                // <n_i, n_i>
     }
+}
+
+// out[0] += sum of v[0..n) in a FIXED order (one workgroup: thread t adds v[t], v[t + 1024], ...
+// in sequence, then a tree over the threads) - the same bits on every run
+__global__ __launch_bounds__(1024) void k_sum_fixed_d(const double *__restrict__ v, int64_t n,
+                                                      double *__restrict__ out)
+{
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] += sh[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -120,7 +137,9 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
     // (a 16-byte vector of a row is entirely below k_end or entirely beyond: ld, k_per % 4 == 0)
 #define SN_FETCH(K0)                                                                         \
     {                                                                                        \
-        const int64_t kk_ = (4 * kq + (K0) < k_end) ? (K0) : k_begin;                        \
+        /* a vector beyond the split's range is never used (zeroed at staging): read the  */ \
+        /* row's [k_begin, k_begin + 4) instead - always inside the row, whatever kq      */ \
+        const int64_t kk_ = (4 * kq + (K0) < k_end) ? (K0) : k_begin - 4 * kq;               \
         va0 = *(const f4 *)(ga0 + kk_); va1 = *(const f4 *)(ga1 + kk_);                      \
         va2 = *(const f4 *)(ga2 + kk_); va3 = *(const f4 *)(ga3 + kk_);                      \
         if (!diag) {                                                                         \
@@ -227,7 +246,11 @@ __global__ __launch_bounds__(256) void k_cosine_reduce(const float *__restrict__
 
 // ---------------------------------------------------------------------------
 // Class sums: rows visited in class order (order[] = stable argsort of y); thread
-// = one feature column, flushes its running f64 sum whenever the class changes.
+// = one feature column of one segment of CS_ROWS sorted positions, one running f64 sum per
+// class run.  No atomics (the sums are order-dependent in f64 too): a run whose class begins
+// AND ends inside the segment is that class's whole sum and is stored to M directly; the
+// segment's first / last run may continue in a neighbouring segment and goes to
+// P[segment][0 / 1][f]; k_class_join adds a class's pieces in ascending segment order.
 // ---------------------------------------------------------------------------
 constexpr int CS_ROWS = 256;      // rows per workgroup (in class order)
 
@@ -235,24 +258,62 @@ __global__ __launch_bounds__(256) void k_class_row_sums(const float *__restrict_
                                                         int64_t F, const float *__restrict__ inv,
                                                         const int32_t *__restrict__ order,
                                                         const int32_t *__restrict__ y_sorted,
-                                                        double *__restrict__ M)
+                                                        double *__restrict__ M, double *__restrict__ P)
 {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t p0 = (int64_t)blockIdx.y * CS_ROWS, p1 = min(N, p0 + CS_ROWS);
+    const int64_t seg = blockIdx.y;
+    const int64_t p0 = seg * CS_ROWS, p1 = min(N, p0 + CS_ROWS);
     if (f >= F || p0 >= N) return;
     int cls = y_sorted[p0];
+    int64_t a = p0;                                   // start of the current run
     double run = 0.0;
+    double *Ps = P + (size_t)seg * 2 * F;
+    Ps[f] = 0.0;
+    Ps[F + f] = 0.0;
+    auto flush = [&](int64_t b) {                     // run of class cls over [a, b)
+        const bool starts = a > p0 || p0 == 0 || y_sorted[p0 - 1] != cls;
+        const bool ends = b < p1 || p1 == N || y_sorted[p1] != cls;
+        if (starts && ends) M[(int64_t)cls * F + f] = run;
+        else Ps[(a == p0 ? 0 : F) + f] = run;
+    };
     for (int64_t p = p0; p < p1; ++p) {
         const int c = y_sorted[p];
         if (c != cls) {
-            atomicAdd(&M[(int64_t)cls * F + f], run);
+            flush(p);
             run = 0.0;
             cls = c;
+            a = p;
         }
         const int64_t i = order[p];
         run += (double)(x[i * F + f] * inv[i]);
     }
-    atomicAdd(&M[(int64_t)cls * F + f], run);
+    flush(p1);
+}
+
+// classes that span several segments: M[c][f] = their pieces in ascending segment order
+__global__ __launch_bounds__(256) void k_class_join(const int32_t *__restrict__ y_sorted, int64_t N, int64_t F,
+                                                    const double *__restrict__ P, double *__restrict__ M)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (f >= F) return;
+    int64_t lo = 0, hi = N;                           // first position with y_sorted >= c
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (y_sorted[m] < c) lo = m + 1; else hi = m; }
+    const int64_t c_lo = lo;
+    hi = N;                                           // first position with y_sorted > c
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (y_sorted[m] <= c) lo = m + 1; else hi = m; }
+    const int64_t c_hi = lo;
+    if (c_hi <= c_lo) return;                         // empty class: M stays 0
+    const int64_t s_lo = c_lo / CS_ROWS, s_hi = (c_hi - 1) / CS_ROWS;
+    if (s_lo == s_hi) return;                         // inside one segment: stored by k_class_row_sums
+    double acc = 0.0;
+    for (int64_t sg = s_lo; sg <= s_hi; ++sg) {
+        // in its first segment the class is the last run unless it starts at the segment's
+        // first position; in every later segment it is the first run
+        const int slot = (sg == s_lo && c_lo > sg * CS_ROWS) ? 1 : 0;
+        acc += P[((size_t)sg * 2 + slot) * F + f];
+    }
+    M[(int64_t)c * F + f] = acc;
 }
 
 // class_sum[a][b] = <M_a, M_b>   (one workgroup per pair)
@@ -379,9 +440,11 @@ extern "C" int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, con
     if (N == 0) return SNGNN_OK;
     SN_REQUIRE(x && y && class_sum, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    AsyncBuf inv(st), iota(st), order(st), ys(st), M(st), bad(st), tmp(st);
+    AsyncBuf inv(st), iota(st), order(st), ys(st), M(st), bad(st), tmp(st), P(st), dg(st);
+    const int64_t n_seg = (N + CS_ROWS - 1) / CS_ROWS;
     SN_REQUIRE(!inv.alloc((size_t)N * 4) && !iota.alloc((size_t)N * 4) && !order.alloc((size_t)N * 4) &&
-                   !ys.alloc((size_t)N * 4) && !M.alloc((size_t)n_classes * F * 8) && !bad.alloc(4),
+                   !ys.alloc((size_t)N * 4) && !M.alloc((size_t)n_classes * F * 8) && !bad.alloc(4) &&
+                   !P.alloc((size_t)n_seg * 2 * F * 8) && !dg.alloc(diag_sum ? (size_t)N * 8 : 8),
                SNGNN_ENOMEM, "out of device memory");
     SN_HIP(hipMemsetAsync(bad.p, 0, 4, st));
     SN_HIP(hipMemsetAsync(M.p, 0, (size_t)n_classes * F * 8, st));
@@ -391,7 +454,9 @@ extern "C" int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, con
     SN_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
     SN_HIP(hipStreamSynchronize(st));
     SN_REQUIRE(!h_bad, SNGNN_ERANGE, "label outside [0, n_classes)");
-    k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(), diag_sum);
+    k_row_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv.as<float>(),
+                                                            diag_sum ? dg.as<double>() : nullptr);
+    if (diag_sum) k_sum_fixed_d<<<1, 1024, 0, st>>>(dg.as<double>(), N, diag_sum);
     k_iota32<<<gn, 256, 0, st>>>(iota.as<int32_t>(), N);
     size_t tb = 0;
     SN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, y, ys.as<int32_t>(), iota.as<int32_t>(),
@@ -399,9 +464,12 @@ extern "C" int sngnn_cosine_class_sums(const float *x, int64_t N, int64_t F, con
     SN_REQUIRE(tmp.alloc(tb) == 0, SNGNN_ENOMEM, "out of device memory");
     SN_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, y, ys.as<int32_t>(), iota.as<int32_t>(),
                                               order.as<int32_t>(), (int)N, 0, 32, st));
-    dim3 grid((unsigned)((F + 255) / 256), (unsigned)((N + CS_ROWS - 1) / CS_ROWS));
+    SN_REQUIRE(n_seg <= 65535, SNGNN_EINVAL, "too many rows (grid.y)");
+    dim3 grid((unsigned)((F + 255) / 256), (unsigned)n_seg);
     k_class_row_sums<<<grid, 256, 0, st>>>(x, N, F, inv.as<float>(), order.as<int32_t>(),
-                                           ys.as<int32_t>(), M.as<double>());
+                                           ys.as<int32_t>(), M.as<double>(), P.as<double>());
+    k_class_join<<<dim3((unsigned)((F + 255) / 256), (unsigned)n_classes), 256, 0, st>>>(
+        ys.as<int32_t>(), N, F, P.as<double>(), M.as<double>());
     k_class_gram<<<n_classes * n_classes, 256, 0, st>>>(M.as<double>(), n_classes, F, class_sum);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

@@ -3,8 +3,8 @@ under the reference's function names and return conventions, computed by
 libsngnn_hip (no Python row / block loops, no N x N temporaries unless the function's
 contract is to return them).  Inputs are GPU tensors; there is no CPU path.
 
-Not covered: SimGFAToolbox/sparse.py (scipy CSC on the host - stays the comparison
-baseline) and plot.py.
+SimGFAToolbox/sparse.py's five functions are covered too (second half of this file: the
+column-normalised input stays sparse on the GPU); plot.py is not (matplotlib, out of scope).
 """
 from __future__ import annotations
 

@@ -18,3 +18,16 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Model-level near-tie flips the parity tests tolerated (tests/helpers.model_selection_report):
+    rows whose selection differs between the GPU model and the oracle model because the two
+    ``lin`` results differ in the last ulp - counted and reported, not hidden in a tolerance."""
+    from tests import helpers
+    if helpers.NEAR_TIE_LOG:
+        tot = sum(d for _, d, _ in helpers.NEAR_TIE_LOG)
+        rows = sum(r for _, _, r in helpers.NEAR_TIE_LOG)
+        terminalreporter.write_line(f"near-tie selection rows tolerated at model level: {tot} of {rows} rows compared")
+        for label, d, r in helpers.NEAR_TIE_LOG:
+            terminalreporter.write_line(f"  {label}: {d} of {r}")

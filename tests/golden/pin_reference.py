@@ -105,6 +105,18 @@ def _softmax(src, index, ptr=None, num_nodes=None):
     return O.segment_softmax(src, index, num_nodes)
 
 
+def _scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+    """torch_scatter.scatter_mean at SimGFAToolbox/dense.py:163 (no dim_size: length max+1)."""
+    assert dim == 0 and out is None and dim_size is None and src.dim() == 1
+    return O.scatter_mean_1d(src, index)
+
+
+def _sort_edge_index(edge_index, edge_attr=None, num_nodes=None, sort_by_row=True):
+    """torch_geometric.utils.sort_edge_index at dense.py:34,66 / sparse.py:86."""
+    assert edge_attr is None and num_nodes is None and sort_by_row
+    return O.sort_edge_index(edge_index)
+
+
 def _zeros(t):
     """torch_geometric.nn.inits.zeros (Appendix A-8): no-op on None."""
     if t is not None:
@@ -174,7 +186,7 @@ def install_stubs():
     mod("torch_geometric.nn.conv")
     mod("torch_geometric.nn.conv.gcn_conv", gcn_norm=_Absent("gcn_norm"))
     tg_utils = mod("torch_geometric.utils", softmax=_softmax, remove_self_loops=_remove_self_loops,
-                   add_self_loops=_add_self_loops,
+                   add_self_loops=_add_self_loops, sort_edge_index=_sort_edge_index,
                    **absent("degree", "remove_isolated_nodes", "contains_isolated_nodes",
                             "dense_to_sparse", prefix="torch_geometric.utils"))
     mod("torch_geometric.utils.num_nodes", maybe_num_nodes=_Absent("maybe_num_nodes"))
@@ -182,7 +194,7 @@ def install_stubs():
     mod("torch_geometric.typing", **{n: object for n in typing_names})
     mod("torch_geometric", nn=tg_nn, utils=tg_utils)
     mod("torch_scatter", scatter=_scatter, scatter_max=_scatter_max, scatter_add=_Absent("scatter_add"),
-        scatter_mean=_Absent("scatter_mean"))
+        scatter_mean=_scatter_mean)
     mod("torch_sparse", SparseTensor=_SparseTensor, matmul=_Absent("torch_sparse.matmul"),
         masked_select_nnz=_Absent("masked_select_nnz"))
     # the reference's own `utils` package drags in its logger / dataset readers, none of
@@ -203,6 +215,23 @@ def import_reference_models():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
+
+
+def import_reference_toolbox():
+    """Import /root/reference/SimGFAToolbox/dense.py and sparse.py themselves under the stubs.
+    Only two third-party NAMES are stubbed for them (``sort_edge_index``, ``scatter_mean``);
+    sparse.py's arithmetic - scikit-learn's ``normalize`` and scipy's sparse product - is the
+    REAL library code (both installed here), dense.py's is core torch."""
+    import importlib.util
+    install_stubs()
+    mods = []
+    for name in ("dense", "sparse"):
+        spec = importlib.util.spec_from_file_location(f"sngnn_reference_toolbox_{name}",
+                                                      os.path.join(REFERENCE, "SimGFAToolbox", f"{name}.py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods.append(m)
+    return mods
 
 
 # ---------------------------------------------------------------------------
@@ -526,6 +555,135 @@ def make_actor_real(R, write):
                             **{"init." + k: v for k, v in init.items() if not k.endswith("w.weight")}, **final)
 
 
+def _toolbox_inputs(n, f, e, classes, seed, density):
+    """Bag-of-words rows (the real datasets' feature kind) with two duplicate rows and an
+    all-zero row, a coalesced (source-sorted) edge list whose last nodes have no out-edge,
+    labels with every class present."""
+    from tests.helpers import random_graph
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, f, generator=g) < density).float() * torch.randint(1, 4, (n, f), generator=g).float()
+    x[3] = x[4]
+    x[7] = 0.0
+    ei = random_graph(n, e, seed + 1)
+    ei = ei[:, ei[0] < n - 5]
+    y = torch.randint(0, classes, (n,), generator=g)
+    y[:classes] = torch.arange(classes)
+    return x, ei, y
+
+
+def _near(a, b, what, tol):
+    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    d = (a - b).abs().max().item() if a.numel() else 0.0
+    if not d <= tol:
+        raise AssertionError(f"{what}: reference run vs oracle, max |diff| = {d} > {tol}")
+    return d
+
+
+def pin_toolbox(write):
+    """a13-a15: every function of SimGFAToolbox/dense.py:9-179 and sparse.py:8-152 run here,
+    on seeded inputs, by the reference's own files; compared with the oracle's toolbox
+    restatement (bit-for-bit where the oracle issues the same core-torch expressions - the
+    "small" variants; to a stated tolerance where the reference sums in another order - its
+    row-by-row / block loops, scipy's float64 sparse product) and written out as
+    tests/golden/toolbox_*.npz = inputs + the REFERENCE's outputs."""
+    import contextlib
+    import io
+    from scipy import sparse as sp
+    D, S = import_reference_toolbox()
+    print("imported", D.__file__, "and", S.__file__)
+    quiet = contextlib.redirect_stdout(io.StringIO())      # the reference prints progress lines
+
+    # --- dense, small graph: the full S travels ---------------------------------------------
+    x, ei, y = _toolbox_inputs(257, 120, 1500, 4, seed=31, density=0.06)
+    out = {}
+    with quiet:
+        out["cosine"] = D.cosine_similarity_dense_small(x)
+        out["node_sim"], out["node_mean"] = D.node_similarity_dense_small(x)
+        out["linked_sim"], out["linked_mean"] = D.linked_node_similarity_dense_small(x, ei)
+        out["nbr_weight"], out["nbr_mean"] = D.neighborhood_similarity_dense_small(x, ei)
+        out["class_mat"], out["class_mean"] = D.class_similarity_dense_small(x, y)
+        _, out["parted_mean"] = D.node_similarity_dense_large_parted(x)
+        out["linked_large_sim"], out["linked_large_mean"] = D.linked_node_similarity_dense_large(x, ei)
+        out["nbr_large_sim"], out["nbr_large_mean"] = D.neighborhood_similarity_dense_large(x, ei)
+        out["class_large_mat"] = D.class_similarity_dense_large(x, y)
+    _eq(out["cosine"], O.cosine_similarity_dense_small(x), "dense.cosine_similarity_dense_small")
+    for key, val in zip(("node_sim", "node_mean"), O.node_similarity_dense_small(x)):
+        _eq(out[key], val, f"dense.node_similarity_dense_small.{key}")
+    for key, val in zip(("linked_sim", "linked_mean"), O.linked_node_similarity_dense_small(x, ei)):
+        _eq(out[key], val, f"dense.linked_node_similarity_dense_small.{key}")
+    for key, val in zip(("nbr_weight", "nbr_mean"), O.neighborhood_similarity_dense_small(x, ei)):
+        _eq(out[key], val, f"dense.neighborhood_similarity_dense_small.{key}")
+    for key, val in zip(("class_mat", "class_mean"), O.class_similarity_dense_small(x, y)):
+        _eq(out[key], val, f"dense.class_similarity_dense_small.{key}")
+    # "large" variants: same statistics, the reference's own summation order (row-by-row
+    # [1,F]x[F,N] products, 1000-row blocks)
+    d = [_near(out["parted_mean"], O.node_similarity_dense_large_parted(x)[1], "dense.large_parted", 2e-3)]
+    for key, val in zip(("linked_large_sim", "linked_large_mean"), O.linked_node_similarity_dense_large(x, ei)):
+        d.append(_near(out[key], val, f"dense.linked_large.{key}", 1e-6))
+    for key, val in zip(("nbr_large_sim", "nbr_large_mean"), O.neighborhood_similarity_dense_large(x, ei)):
+        d.append(_near(out[key], val, f"dense.nbr_large.{key}", 1e-6))
+    d.append(_near(out["class_large_mat"], O.class_similarity_dense_large(x, y), "dense.class_large", 1e-6))
+    # the large variants ARE the small ones listed differently (SURVEY.md 8c)
+    _near(out["linked_large_sim"], out["linked_sim"], "linked large vs small (sorted input)", 1e-6)
+    _near(out["class_large_mat"], out["class_mat"], "class large vs small", 1e-6)
+    print(f"  dense.py on [257 x 120]: 5 small variants == oracle bit for bit; 4 large variants within {max(d):.2e}")
+    if write:
+        np.savez_compressed(os.path.join(OUT, "toolbox_dense_small.npz"), x=x.numpy(), edge_index=ei.numpy(),
+                            y=y.numpy(), **{k: torch.as_tensor(v).detach().numpy() for k, v in out.items()})
+
+    # --- dense, more than one 1000-row block: statistics only ---------------------------------
+    x, ei, y = _toolbox_inputs(1100, 40, 6000, 5, seed=32, density=0.15)
+    out = {}
+    with quiet:
+        _, out["node_mean"] = D.node_similarity_dense_small(x)
+        _, out["parted_mean"] = D.node_similarity_dense_large_parted(x)
+        out["linked_large_sim"], out["linked_large_mean"] = D.linked_node_similarity_dense_large(x, ei)
+        out["nbr_large_sim"], out["nbr_large_mean"] = D.neighborhood_similarity_dense_large(x, ei)
+        out["nbr_weight"], out["nbr_mean"] = D.neighborhood_similarity_dense_small(x, ei)
+        out["class_large_mat"] = D.class_similarity_dense_large(x, y)
+        out["class_mat"], out["class_mean"] = D.class_similarity_dense_small(x, y)
+    d = [_near(out["parted_mean"], O.node_similarity_dense_large_parted(x)[1], "dense.large_parted (2 blocks)", 5e-2)]
+    for key, val in zip(("linked_large_sim", "linked_large_mean"), O.linked_node_similarity_dense_large(x, ei)):
+        d.append(_near(out[key], val, f"dense.linked_large.{key}", 1e-6))
+    for key, val in zip(("nbr_large_sim", "nbr_large_mean"), O.neighborhood_similarity_dense_large(x, ei)):
+        d.append(_near(out[key], val, f"dense.nbr_large.{key}", 1e-6))
+    d.append(_near(out["class_large_mat"], O.class_similarity_dense_large(x, y), "dense.class_large", 1e-6))
+    _eq(out["class_mat"], O.class_similarity_dense_small(x, y)[0], "dense.class_small (1100)")
+    _eq(out["nbr_weight"], O.neighborhood_similarity_dense_small(x, ei)[0], "dense.nbr_small (1100)")
+    print(f"  dense.py on [1100 x 40] (two 1000-row blocks): large variants within {max(d[1:]):.2e} "
+          f"(parted mean, a sum of 1.2 M terms in fp32: {d[0]:.2e} of {float(out['parted_mean']):.1f})")
+    if write:
+        np.savez_compressed(os.path.join(OUT, "toolbox_dense_parted.npz"), x=x.numpy(), edge_index=ei.numpy(),
+                            y=y.numpy(), **{k: torch.as_tensor(v).detach().numpy() for k, v in out.items()})
+
+    # --- sparse.py on the adjacency (toolbox-example.py:28-29) -------------------------------
+    n = 300
+    x, ei, y = _toolbox_inputs(n, 8, 2500, 4, seed=33, density=0.5)
+    # SimGFAToolbox/utils.py:5-11 (edge_index_to_sparse_csc_tensor): ones, duplicates add
+    adj = sp.csc_matrix((np.full(ei.size(1), 1), (ei[0].numpy(), ei[1].numpy())), shape=(n, n))
+    out = {}
+    with quiet:
+        out["cosine"] = torch.from_numpy(np.asarray(S.cosine_similarity_sparse(adj).todense())).float()
+        out["node_sim"], out["node_mean"] = S.node_similarity_sparse(adj)
+        out["linked_sim"], out["linked_mean"] = S.linked_node_similarity_sparse(adj, ei)
+        out["nbr_sim"], out["nbr_mean"] = S.neighborhood_similarity_sparse(adj, ei)
+        out["class_mat"] = S.class_similarity_sparse(adj, y)
+    d = [_near(out["cosine"], O.cosine_similarity_sparse(adj), "sparse.cosine_similarity_sparse", 1e-7)]
+    for key, val in zip(("node_sim", "node_mean"), O.node_similarity_sparse(adj)):
+        d.append(_near(out[key], val, f"sparse.node_similarity_sparse.{key}", 1e-7))
+    for key, val in zip(("linked_sim", "linked_mean"), O.linked_node_similarity_sparse(adj, ei)):
+        d.append(_near(out[key], val, f"sparse.linked.{key}", 1e-7))
+    for key, val in zip(("nbr_sim", "nbr_mean"), O.neighborhood_similarity_sparse(adj, ei)):
+        d.append(_near(out[key], val, f"sparse.nbr.{key}", 1e-7))
+    d.append(_near(out["class_mat"], O.class_similarity_sparse(adj, y), "sparse.class", 1e-7))
+    print(f"  sparse.py on the [300 x 300] adjacency (real scipy + scikit-learn): 5 functions within {max(d):.2e}")
+    if write:
+        np.savez_compressed(os.path.join(OUT, "toolbox_sparse_adj.npz"), edge_index=ei.numpy(), y=y.numpy(),
+                            n=np.array([n], np.int64),
+                            **{k: torch.as_tensor(v).detach().numpy() for k, v in out.items()})
+
+
 def main():
     global USE_LOOP_SCATTER_MAX
     ap = argparse.ArgumentParser()
@@ -550,6 +708,8 @@ def main():
     make_trajectories(R, write=not args.check)
     print("real Actor, published hyper-parameters:")
     make_actor_real(R, write=not args.check)
+    print("Sim-GFA toolbox (SimGFAToolbox/dense.py, sparse.py):")
+    pin_toolbox(write=not args.check)
     print("OK: the reference's in-tree lines agree with the oracle bit for bit; "
           "Appendix A (third-party kernels) remains unpinned")
 

@@ -104,3 +104,48 @@ def assert_close(got: torch.Tensor, want: torch.Tensor, what="out", rtol=RTOL, a
 def oracle_aggregate(h, ei, add_loops, remove_loops, top_k, thr):
     return O.aggregate_reference(h, ei, add_loops=add_loops, remove_loops=remove_loops,
                                  top_k=top_k, thr=thr)
+
+
+NEAR_TIE_LOG = []       # (test id, rows that needed the near-tie rule, rows compared): printed by conftest
+
+
+def model_selection_report(ours, ref, data_cpu, data_gpu, label):
+    """Per selecting conv layer of a model pair (GPU module / oracle module, same parameters):
+    compare the rows' selections on each side's OWN ``h = lin(x)`` - the two ``lin`` results
+    differ in the last ulp (rocBLAS / MFMA vs the CPU's GEMM), which is where a model-level
+    near-tie flip comes from.  A differing row must pass ``check_selection``'s near-tie rule
+    (oracle cosines within TIE_TOL, no structural tie involved).  Returns and logs
+    (rows that differ, rows compared)."""
+    from sngnn_amd import conv as CV
+    from sngnn_amd import ops
+    from sngnn_amd.graph import GLOBAL_CACHE
+    cap_g, cap_r = {}, {}
+    hooks = []
+    for li, (cg, cr) in enumerate(zip(ours.lins, ref.lins)):
+        hooks.append(cg.register_forward_pre_hook(lambda m, a, li=li: cap_g.__setitem__(li, a[0].detach())))
+        hooks.append(cr.register_forward_pre_hook(lambda m, a, li=li: cap_r.__setitem__(li, a[0].detach())))
+    was = ours.training, ref.training
+    ours.eval(), ref.eval()
+    with torch.no_grad():
+        ours(data_gpu), ref(data_cpu)
+    ours.train(was[0]), ref.train(was[1])
+    for hk in hooks:
+        hk.remove()
+    differ = rows = 0
+    for li, (cg, cr) in enumerate(zip(ours.lins, ref.lins)):
+        k = getattr(cr, "top_k", None)
+        if k is None:
+            continue
+        rem = bool(cr.is_remove_self_loops)
+        with torch.no_grad():
+            h_r = cr.lin(cap_r[li])
+            h_g, _ = CV._lin_aligned(cap_g[li], cg.lin)
+        res = O.aggregate_reference(h_r, data_cpu.edge_index, add_loops=True, remove_loops=rem,
+                                    top_k=int(k), thr=float(cr.thr))
+        g = GLOBAL_CACHE.get(data_gpu.edge_index, h_g.size(0), True, rem)
+        _, _, _, sel_src, sel_w = ops.aggregate_forward(g, h_g.contiguous(), int(k), float(cr.thr),
+                                                        want_selection=True)
+        differ += check_selection(res, sel_src, sel_w, int(k), float(cr.thr), strict=False, h=h_r)
+        rows += h_r.size(0)
+    NEAR_TIE_LOG.append((label, differ, rows))
+    return differ, rows

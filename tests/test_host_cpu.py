@@ -204,3 +204,31 @@ def test_ogb_raw_layout_loader(tmp_path):
     dump(root / "raw" / "edge.csv.gz", bad, "%d")
     with pytest.raises(ValueError):
         DS.load_ogb_raw(str(root))
+
+
+def test_cosine_tile_prefetch_addresses_stay_inside_the_row():
+    """Index arithmetic of k_cosine_mfma's prefetch (csrc/toolbox.hip, SN_FETCH) replayed on the
+    host with the launcher's split rule: for every lane vector kq and every K-step of every
+    split, the 16-byte read lies inside [0, ld) of its row - also when the step is out of the
+    split's range (its value is discarded, the read is real).  ADVICE r2 (medium)."""
+    TB_K = 32
+    for n, f in [(40, 4), (130, 16), (300, 28), (1500, 200), (1664, 200), (2277, 2325), (100, 33), (513, 96)]:
+        ld = (f + 3) // 4 * 4
+        nb = (n + 127) // 128
+        tiles = nb * (nb + 1) // 2
+        ks = 1
+        if tiles <= 96:
+            ks = min(min(8, (512 + tiles - 1) // tiles), max(1, ld // (2 * TB_K)))
+        k_per = ((ld + ks - 1) // ks + TB_K - 1) // TB_K * TB_K
+        ks = (ld + k_per - 1) // k_per
+        for split in range(ks):
+            k_begin = split * k_per
+            k_end = min(ld, k_begin + k_per)
+            assert k_begin < ld
+            k0 = k_begin
+            while k0 < k_end:
+                for kq in range(8):
+                    kk = k0 if 4 * kq + k0 < k_end else k_begin - 4 * kq
+                    first = 4 * kq + kk                      # offset of the vector inside the row
+                    assert 0 <= first and first + 4 <= ld, (n, f, split, k0, kq, first, ld)
+                k0 += TB_K

@@ -189,3 +189,65 @@ def test_attention_golden_vectors_reproduce(path):
     assert np.array_equal(res["ei"].numpy(), z["ei_prime"])
     np.testing.assert_allclose(res["out"].numpy(), z["out"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(res["alpha"].numpy(), z["alpha"], rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# Sim-GFA toolbox: the oracle's restatement against fixtures that hold the outputs of the
+# reference's OWN SimGFAToolbox/dense.py and sparse.py (tests/golden/pin_reference.py)
+# ---------------------------------------------------------------------------
+def _z(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_oracle_toolbox_dense_small_fixture_bit_exact():
+    z = _z("toolbox_dense_small.npz")
+    x, ei, y = _t(z["x"]), _t(z["edge_index"]), _t(z["y"])
+    assert torch.equal(O.cosine_similarity_dense_small(x), _t(z["cosine"]))
+    for got, key in zip(O.node_similarity_dense_small(x), ("node_sim", "node_mean")):
+        assert torch.equal(got, _t(z[key])), key
+    for got, key in zip(O.linked_node_similarity_dense_small(x, ei), ("linked_sim", "linked_mean")):
+        assert torch.equal(got, _t(z[key])), key
+    for got, key in zip(O.neighborhood_similarity_dense_small(x, ei), ("nbr_weight", "nbr_mean")):
+        assert torch.equal(got, _t(z[key])), key
+    for got, key in zip(O.class_similarity_dense_small(x, y), ("class_mat", "class_mean")):
+        assert torch.equal(got, _t(z[key])), key
+
+
+@pytest.mark.parametrize("name", ["toolbox_dense_small.npz", "toolbox_dense_parted.npz"])
+def test_oracle_toolbox_dense_large_fixtures(name):
+    """The "large" variants sum in the reference's own order (row-by-row products, 1000-row
+    blocks); the restatement agrees to 1e-6 on a cosine and 1e-6 relative on the big sum."""
+    z = _z(name)
+    x, ei, y = _t(z["x"]), _t(z["edge_index"]), _t(z["y"])
+    want = float(z["parted_mean"])
+    assert abs(float(O.node_similarity_dense_large_parted(x)[1]) - want) <= 1e-6 * abs(want)
+    for got, key in zip(O.linked_node_similarity_dense_large(x, ei), ("linked_large_sim", "linked_large_mean")):
+        np.testing.assert_allclose(got.numpy(), z[key], atol=1e-6)
+    for got, key in zip(O.neighborhood_similarity_dense_large(x, ei), ("nbr_large_sim", "nbr_large_mean")):
+        np.testing.assert_allclose(torch.as_tensor(got).numpy(), z[key], atol=1e-6)
+    np.testing.assert_allclose(O.class_similarity_dense_large(x, y).numpy(), z["class_large_mat"], atol=1e-6)
+    # the quirk of dense.py:28 is in the fixture: (sum - N) / (N - 1) * N, not a mean
+    # (sum = off-diagonal sum + trace; the trace is N minus the all-zero rows)
+    n = x.size(0)
+    zero_rows = int((x.abs().sum(1) == 0).sum())
+    assert abs(want - (float(z["node_mean"]) * n * (n - 1) - zero_rows) / (n - 1) * n) <= 2e-4 * abs(want)
+
+
+def test_oracle_toolbox_sparse_fixture():
+    """sparse.py's arithmetic is scikit-learn + scipy (real, float64): 1e-7."""
+    import scipy.sparse as sp
+    z = _z("toolbox_sparse_adj.npz")
+    ei, y, n = _t(z["edge_index"]), _t(z["y"]), int(z["n"][0])
+    adj = sp.csc_matrix((np.full(ei.size(1), 1), (ei[0].numpy(), ei[1].numpy())), shape=(n, n))
+    np.testing.assert_allclose(O.cosine_similarity_sparse(adj), z["cosine"], atol=1e-7)
+    for got, key in zip(O.node_similarity_sparse(adj), ("node_sim", "node_mean")):
+        np.testing.assert_allclose(got.numpy(), z[key], atol=1e-7)
+    for got, key in zip(O.linked_node_similarity_sparse(adj, ei), ("linked_sim", "linked_mean")):
+        np.testing.assert_allclose(got.numpy(), z[key], atol=1e-7)
+    for got, key in zip(O.neighborhood_similarity_sparse(adj, ei), ("nbr_sim", "nbr_mean")):
+        np.testing.assert_allclose(torch.as_tensor(got).numpy(), z[key], atol=1e-7)
+    np.testing.assert_allclose(O.class_similarity_sparse(adj, y).numpy(), z["class_mat"], atol=1e-7)

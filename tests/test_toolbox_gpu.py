@@ -254,3 +254,114 @@ def test_sparse_statistics_never_form_the_product(cuda):
     assert (cm.double() - want).abs().max() <= 1e-5 * want.abs().max()
     with pytest.raises(ValueError, match="does not fit"):
         T.cosine_similarity_sparse(adj, device=cuda)
+
+
+# ---------------------------------------------------------------------------
+# a13-a15 against fixtures made by the reference's OWN SimGFAToolbox/dense.py and sparse.py
+# (tests/golden/pin_reference.py:pin_toolbox; inputs + the reference's outputs)
+# ---------------------------------------------------------------------------
+import os
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+COS_TOL = 2e-6          # fp32 cosine: |s| <= 1, a few ulps of accumulated rounding in the dot products
+
+
+def _fx(name, cuda):
+    z = np.load(os.path.join(GOLDEN, name))
+    dev = {k: torch.from_numpy(z[k]).to(cuda) for k in ("x", "edge_index", "y") if k in z}
+    return z, dev
+
+
+def _close(got, want, tol=COS_TOL):
+    got = torch.as_tensor(got).detach().cpu().double().numpy()
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+
+
+def test_dense_small_variants_against_reference_fixture(cuda):
+    """dense.py:138-179 run by the reference's own file -> toolbox_dense_small.npz."""
+    from sngnn_amd import toolbox as T
+    z, d = _fx("toolbox_dense_small.npz", cuda)
+    x, ei, y = d["x"], d["edge_index"], d["y"]
+    _close(T.cosine_similarity_dense_small(x), z["cosine"])
+    sim, mean = T.node_similarity_dense_small(x)
+    _close(sim, z["node_sim"]), _close(mean, z["node_mean"], 1e-6)
+    sim, mean = T.linked_node_similarity_dense_small(x, ei)
+    _close(sim, z["linked_sim"]), _close(mean, z["linked_mean"], 1e-6)
+    w, mean = T.neighborhood_similarity_dense_small(x, ei)
+    _close(w, z["nbr_weight"]), _close(mean, z["nbr_mean"], 1e-6)
+    mat, mean = T.class_similarity_dense_small(x, y)
+    _close(mat, z["class_mat"], 1e-6), _close(mean, z["class_mean"], 1e-6)
+
+
+@pytest.mark.parametrize("name", ["toolbox_dense_small.npz", "toolbox_dense_parted.npz"])
+def test_dense_large_variants_against_reference_fixture(cuda, name):
+    """dense.py:9-130 (Python row / block loops in the reference; 1 100 rows = two of its
+    1000-row blocks) -> the same statistics from the O(NF) / per-edge kernels."""
+    from sngnn_amd import toolbox as T
+    z, d = _fx(name, cuda)
+    x, ei, y = d["x"], d["edge_index"], d["y"]
+    _, q = T.node_similarity_dense_large_parted(x)
+    assert abs(float(q) - float(z["parted_mean"])) <= 1e-5 * abs(float(z["parted_mean"]))
+    sim, mean = T.linked_node_similarity_dense_large(x, ei)
+    _close(sim, z["linked_large_sim"]), _close(mean, z["linked_large_mean"], 1e-6)
+    per_node, mean_all = T.neighborhood_similarity_dense_large(x, ei)
+    _close(per_node, z["nbr_large_sim"]), _close(mean_all, z["nbr_large_mean"], 1e-6)
+    _close(T.class_similarity_dense_large(x, y), z["class_large_mat"], 1e-6)
+    _, c = T.node_similarity_dense_large_parted(x, corrected=True)
+    _close(c, z["node_mean"], 1e-6)
+
+
+def test_sparse_variants_against_reference_fixture(cuda):
+    """sparse.py:8-152 run by the reference's own file on real scipy + scikit-learn, on the
+    adjacency built as SimGFAToolbox/utils.py:5-11 builds it (toolbox-example.py:28-29)."""
+    from sngnn_amd import toolbox as T
+    z, d = _fx("toolbox_sparse_adj.npz", cuda)
+    ei, y = d["edge_index"], d["y"]
+    n = int(z["n"][0])
+    adj = T.edge_index_to_sparse_csc_tensor(torch.empty(n, 1), ei)
+    _close(T.cosine_similarity_sparse(adj, device=cuda), z["cosine"])
+    allsim, mean = T.node_similarity_sparse(adj, device=cuda)
+    _close(allsim, z["node_sim"]), _close(mean, z["node_mean"], 1e-6)
+    lv, lm = T.linked_node_similarity_sparse(adj, ei, device=cuda)
+    _close(lv, z["linked_sim"]), _close(lm, z["linked_mean"], 1e-6)
+    pn, pm = T.neighborhood_similarity_sparse(adj, ei, device=cuda)
+    _close(pn, z["nbr_sim"]), _close(pm, z["nbr_mean"], 1e-6)
+    _close(T.class_similarity_sparse(adj, y, device=cuda), z["class_mat"], 1e-6)
+
+
+@pytest.mark.parametrize("n,f", [(40, 4), (130, 16), (300, 28), (1500, 200), (700, 2325 % 200 + 7)])
+def test_cosine_dense_narrow_inputs_and_short_last_split(cuda, n, f):
+    """Shapes whose K range is narrower than one 32-float K-step somewhere: ld < 32, or a last
+    contraction split shorter than 32 (N <= 1664 with F = 200: k_begin 192 of ld 200).  The
+    prefetch of an out-of-range K-step must stay inside the row (it ran up to 112
+    bytes past the end of x for the clamped last row)."""
+    from sngnn_amd import toolbox as T
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(n + f))
+    x[1] = 0.0
+    S = T.cosine_similarity_dense_small(x.to(cuda)).cpu()
+    ref = O.cosine_similarity_dense_small(x)
+    assert (S - ref).abs().max() < 2e-6
+
+
+def test_class_sums_are_deterministic_and_atomics_free(cuda):
+    """The class statistics add in a fixed order: two runs give the same bits; classes that are
+    tiny, that span many 256-row segments, that start exactly on a segment boundary, and an
+    empty class."""
+    from sngnn_amd import toolbox as T
+    n, f = 5000, 70
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f, generator=g)
+    y = torch.empty(n, dtype=torch.int64)
+    sizes = [256, 3, 1, 2000, 252, 1024, 0, 1464]            # class 6 is empty
+    assert sum(sizes) == n
+    y[torch.randperm(n, generator=g)] = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    a, da = T.class_block_sums(x.to(cuda), y.to(cuda), len(sizes))
+    b, db = T.class_block_sums(x.to(cuda), y.to(cuda), len(sizes))
+    assert torch.equal(a, b) and torch.equal(da, db)
+    xn = torch.nn.functional.normalize(x.double(), dim=1)
+    m = torch.zeros(len(sizes), f, dtype=torch.float64).index_add_(0, y, xn)
+    want = m @ m.t()
+    assert (a.cpu() - want).abs().max() <= 1e-6 * want.abs().max()
+    assert abs(float(da) - n) < 1e-3
