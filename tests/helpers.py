@@ -53,31 +53,41 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None):
         srcs, sc = ei[0][pos], s[pos]
         got = sel_g[i][sel_g[i] >= 0]
         # scores (oracle's) of what the GPU picked, by matching sources in edge order
-        picked = []
+        picked, picked_edges = [], []
         used = np.zeros(pos.size, bool)
         for j in got:
             cand = np.flatnonzero((srcs == j) & ~used)
             assert cand.size, f"row {i}: GPU selected source {j} that is not an in-neighbour"
-            # among duplicates take the best-scoring unused one
+            # among duplicates take the best-scoring unused one (the first of equals)
             c = cand[np.argmax(sc[cand])]
             used[c] = True
             picked.append(sc[c])
+            picked_edges.append(c)
         picked = np.asarray(picked, np.float32)
         assert picked.size <= top_k
-        # A STRUCTURAL exact tie - the two sources' products with the target's unit row are
-        # the same bits channel by channel (duplicate rows, power-of-two multiples, rows with
-        # one non-zero channel, C == 1), so the cosines are equal in ANY summation order - is
-        # decided by the edge position on both sides: the kernel scores normalise-then-dot
-        # like the reference.  (Two unrelated cosines that merely round to the same float in
-        # one summation order are an ordinary near tie.)
+        # A STRUCTURAL exact tie - two in-edges whose sources' products with the target's unit
+        # row are the same bits channel by channel (duplicate rows, power-of-two multiples, rows
+        # with one non-zero channel, C == 1), so the cosines are equal in ANY summation order -
+        # is decided by the edge position on both sides: the kernel scores normalise-then-dot
+        # like the reference.  Inside such a group the GPU must therefore have taken a PREFIX in
+        # edge-position order, and list it in that order - whatever near ties with unrelated
+        # sources shift the ranks around it.  (Two unrelated cosines that merely round to the
+        # same float in one summation order are an ordinary near tie.)
         if unit is not None:
-            want = sel_o[i][sel_o[i] >= 0]
-            for r in range(min(want.size, got.size)):
-                if want[r] != got[r]:
-                    pw, pg = unit[i] * unit[int(want[r])], unit[i] * unit[int(got[r])]
-                    assert not np.array_equal(pw, pg), \
-                        f"row {i} rank {r}: structural tie between sources {want[r]} and {got[r]} " \
-                        "broken differently from the reference"
+            groups = {}
+            for q in range(pos.size):                       # pos ascending = edge-position order
+                groups.setdefault((unit[i] * unit[int(srcs[q])]).tobytes(), []).append(q)
+            rank_of = {int(c): r for r, c in enumerate(picked_edges)}
+            for members in groups.values():
+                if len(members) < 2:
+                    continue
+                taken = [q for q in members if q in rank_of]
+                assert taken == members[:len(taken)], \
+                    f"row {i}: structural tie among sources {srcs[members].tolist()} not broken by edge position " \
+                    f"(GPU took {srcs[taken].tolist()})"
+                ranks = [rank_of[q] for q in taken]
+                assert ranks == sorted(ranks), \
+                    f"row {i}: structurally tied sources {srcs[taken].tolist()} listed out of edge-position order"
         assert (picked >= thr32 - TIE_TOL).all(), f"row {i}: kept an edge below thr"
         assert (np.diff(picked) <= TIE_TOL).all(), f"row {i}: not in rank order"
         rest = sc[~used]
