@@ -161,6 +161,35 @@ int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
  */
 int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm,
                          void *stream);
+/*
+ * Filter rows (no reference counterpart; csrc/agg_fwd_filter.h).  For C % 4 == 0, C > 32 the
+ * selecting forward first scores the edges of a row with more than top_k in-edges against an
+ * fp16 copy of the unit rows, one 128-byte-aligned entry of sngnn_filter_row_bytes(C) bytes per
+ * node, and fetches the fp32 unit row only of the edges that can still be among the top_k
+ * (approximate cosine within a proven bound of the k-th); the selection itself is made on exact
+ * fp32 cosines, so indices and weights are those of the unfiltered path, bit for bit.
+ * sngnn_filter_row_bytes returns 0 when the filter is not used for this C.
+ * sngnn_normalize_rows_filter is sngnn_normalize_rows that also writes the filter rows
+ * (filt: dev, rows * sngnn_filter_row_bytes(C) bytes, 16-byte aligned; NULL to skip).
+ * sngnn_agg_forward_prepared is sngnn_agg_forward_normalized for a caller that holds them
+ * (filt == NULL: they are built inside the workspace by one more pass over n).
+ * sngnn_filter_enable(mode): 0 = never, 1 = when it is expected to pay (default: a selective
+ * threshold, thr >= 0.25, or top_k <= 8), 2 = whenever it applies.  Results do not depend on it.
+ */
+int64_t sngnn_filter_row_bytes(int C);
+int sngnn_normalize_rows_filter(const float *h, int64_t rows, int C, float *n, float *nrm,
+                                void *filt, void *stream);
+int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const float *nrm,
+                               const void *filt, int C, int top_k, float thr, float *out,
+                               float *wsel, float *inv_norm, int32_t *sel_src, float *sel_w,
+                               void *workspace, void *stream);
+int sngnn_filter_enable(int mode);
+/* measurement aid: knob 0 = row classes the main forward kernel runs (bit 0 split-row tasks,
+ * 1 wave rows, 2 small rows; default 7 - anything else leaves the output incomplete) */
+int sngnn_tuning_set(int which, int value);
+/* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
+int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,
+                             int64_t n_pairs, float *out, void *stream);
 int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float *n, const float *nrm,
                                  int C, int top_k, float thr, float *out, float *wsel,
                                  float *inv_norm, int32_t *sel_src, float *sel_w,

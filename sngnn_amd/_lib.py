@@ -37,6 +37,13 @@ SIGNATURES = {
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),
     "sngnn_agg_forward": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_normalize_rows": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "sngnn_filter_row_bytes": (_i64, [_i32]),
+    "sngnn_normalize_rows_filter": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sngnn_agg_forward_prepared": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp]),
+    "sngnn_filter_enable": (_i32, [_i32]),
+    "sngnn_tuning_set": (_i32, [_i32, _i32]),
+    "sngnn_filter_pair_scores": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     "sngnn_agg_forward_normalized": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -41,16 +41,39 @@ static __global__ void k_fill_sel(int32_t *__restrict__ src, float *__restrict__
 }
 
 static int normalize_dispatch(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm,
-                              hipStream_t st)
+                              void *filt, hipStream_t st)
 {
     switch (cfg.vec) {
-    case 1: return launch_normalize_v1(cfg, h, rows, C, n, nrm, st);
-    case 2: return launch_normalize_v2(cfg, h, rows, C, n, nrm, st);
-    default: return launch_normalize_v4(cfg, h, rows, C, n, nrm, st);
+    case 1: return launch_normalize_v1(cfg, h, rows, C, n, nrm, filt, st);
+    case 2: return launch_normalize_v2(cfg, h, rows, C, n, nrm, filt, st);
+    default: return launch_normalize_v4(cfg, h, rows, C, n, nrm, filt, st);
     }
 }
 
-extern "C" int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, void *stream)
+// fp16 filter: 0 = never, 1 = when it is expected to pay (default), 2 = whenever it applies
+static int g_filter_mode = 1;
+// measurement aids: the fp16 filter can be switched off (the selections are the same either
+// way); sngnn_tuning_set(0, mask) runs only some row classes of the main kernel (bit 0 split-row
+// tasks, 1 wave rows, 2 small rows; results are then incomplete - timing only)
+static int g_role_mask = 7;
+extern "C" int sngnn_tuning_set(int which, int value)
+{
+    SN_REQUIRE(which == 0, SNGNN_EINVAL, "unknown tuning knob");
+    g_role_mask = value & 7;
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_filter_enable(int mode)
+{
+    SN_REQUIRE(mode >= 0 && mode <= 2, SNGNN_EINVAL, "filter mode must be 0 (off), 1 (auto) or 2 (always)");
+    g_filter_mode = mode;
+    return SNGNN_OK;
+}
+
+extern "C" int64_t sngnn_filter_row_bytes(int C) { return filter_row_bytes(C); }
+
+extern "C" int sngnn_normalize_rows_filter(const float *h, int64_t rows, int C, float *n, float *nrm, void *filt,
+                                           void *stream)
 {
     SN_REQUIRE(rows >= 0, SNGNN_EINVAL, "negative row count");
     SN_REQUIRE(rows == 0 || (h && n && nrm), SNGNN_EINVAL, "h/n/nrm is NULL");
@@ -58,12 +81,60 @@ extern "C" int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL, "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
     SN_REQUIRE(((uintptr_t)h % (cfg.vec * 4)) == 0 && ((uintptr_t)n % (cfg.vec * 4)) == 0, SNGNN_EINVAL,
                "h/n must be aligned to the row vector width");
-    return normalize_dispatch(cfg, h, rows, C, n, nrm, (hipStream_t)stream);
+    SN_REQUIRE(filt == nullptr || filter_row_bytes(C) > 0, SNGNN_EINVAL,
+               "no filter rows for this C (sngnn_filter_row_bytes(C) == 0)");
+    SN_REQUIRE(((uintptr_t)filt % 16) == 0, SNGNN_EINVAL, "filt must be 16-byte aligned");
+    return normalize_dispatch(cfg, h, rows, C, n, nrm, filt, (hipStream_t)stream);
+}
+
+extern "C" int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, void *stream)
+{
+    return sngnn_normalize_rows_filter(h, rows, C, n, nrm, nullptr, stream);
+}
+
+// approximate cosine of node pairs straight from filter rows (the instruction sequence of the
+// forward's filter pass) - lets a test check the error bound FILT_EPS on the hardware
+template <int GF>
+static __global__ __launch_bounds__(BLOCK) void k_filter_pair_scores(const uint4 *__restrict__ filt,
+                                                                     const int64_t *__restrict__ pa,
+                                                                     const int64_t *__restrict__ pb, int64_t n_pairs,
+                                                                     float *__restrict__ out)
+{
+    constexpr int NGF = 64 / GF;
+    const int lane = lane_id();
+    const int gid = lane / GF, lf = lane % GF;
+    const int64_t w = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int64_t p = w * NGF + gid;
+    const int64_t q = p < n_pairs ? p : n_pairs - 1;
+    const uint4 fa = filt[(size_t)pa[q] * GF + lf], fb = filt[(size_t)pb[q] * GF + lf];
+    const float s = group_sum<GF>(fdot8(fa, fb)) * FILT_UNSCALE;
+    if (p < n_pairs && lf == 0) out[p] = s;
+}
+
+extern "C" int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,
+                                        int64_t n_pairs, float *out, void *stream)
+{
+    SN_REQUIRE(filter_row_bytes(C) > 0, SNGNN_EINVAL, "no filter rows for this C");
+    SN_REQUIRE(n_pairs >= 0, SNGNN_EINVAL, "negative pair count");
+    if (n_pairs == 0) return SNGNN_OK;
+    SN_REQUIRE(filt && pair_a && pair_b && out, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int gf = (int)(filter_row_bytes(C) / 16);
+    const int grid = ceil_div(n_pairs, (64 / gf) * WAVES);
+    const uint4 *f = (const uint4 *)filt;
+    switch (gf) {
+    case 8: k_filter_pair_scores<8><<<grid, BLOCK, 0, st>>>(f, pair_a, pair_b, n_pairs, out); break;
+    case 16: k_filter_pair_scores<16><<<grid, BLOCK, 0, st>>>(f, pair_a, pair_b, n_pairs, out); break;
+    case 32: k_filter_pair_scores<32><<<grid, BLOCK, 0, st>>>(f, pair_a, pair_b, n_pairs, out); break;
+    default: k_filter_pair_scores<64><<<grid, BLOCK, 0, st>>>(f, pair_a, pair_b, n_pairs, out); break;
+    }
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
 }
 
 // everything after the unit rows exist
 static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const float *n, const float *nrm,
-                              int C, int top_k, float thr, float *out, float *wsel, float *inv_norm,
+                              const void *filt, int C, int top_k, float thr, float *out, float *wsel, float *inv_norm,
                               int32_t *sel_src, float *sel_w, void *scratch, hipEvent_t *ev, hipStream_t st)
 {
     if (top_k > (1 << 20)) top_k = 1 << 20;     // more than any row can use
@@ -77,6 +148,8 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
 
     FwdArgs a;
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
+    a.filt = (const uint4 *)filt;
+    a.role_mask = g_role_mask;
     // row order: calls that stream the small rows (deg <= SMALL_T <= top_k, or no top_k) take the
     // bucket order, calls that rank inside them the exact degree order (graph.hip 5b)
     const bool stream_small = top_k < 0 || top_k >= SMALL_T;
@@ -91,6 +164,7 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.n_med_end = g->rows_gt(SMALL_T);
     a.n_tasks = g->n_tasks;
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk;
+    a.task_order = g->task_order;
     a.split_soff = g->split_soff; a.split_task0 = g->split_task0;
     a.scores = (float *)scratch;
     a.partial = a.scores ? a.scores + (g->split_edges + 3) / 4 * 4 : nullptr;   // 16-B aligned rows
@@ -127,6 +201,24 @@ static int check_forward_args(const sngnn_graph_t *g, const float *rows, int C, 
     return SNGNN_OK;
 }
 
+// the filter region of the workspace, and whether a call uses it: rows that rank (in-degree >
+// top_k) above the small class must exist, otherwise nothing would read the table
+static void *ws_filter(void *workspace, int64_t Ntot, int C)
+{
+    return (char *)workspace + (Ntot * (int64_t)C * 4 + 255) / 256 * 256 + (Ntot * 4 + 255) / 256 * 256;
+}
+static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
+{
+    if (g_filter_mode == 0 || top_k < 0 || filter_row_bytes(C) == 0 || g->rows_gt(std::max(top_k, SMALL_T)) == 0)
+        return false;
+    // The filter prunes the edges that cannot reach thr and, in rows much longer than top_k, the
+    // ones far below the k-th; it costs one more table to write (+3 us at arxiv size) and a
+    // second phase per row.  Measured at config 4: thr 0.9 or top_k 1 -> -7 us
+    // per forward; top_k 16 with thr 0.0 (a wave row keeps 16 of ~38, every kept row is
+    // fetched in fp32 anyway) -> +2 us.  Hence: on for a selective threshold or a small top_k.
+    return g_filter_mode == 2 || thr >= 0.25f || top_k <= 8;
+}
+
 extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
                                  float thr, float *out, float *wsel, float *inv_norm,
                                  int32_t *sel_src, float *sel_w, void *workspace, void *stream)
@@ -136,14 +228,47 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(workspace != nullptr, SNGNN_EINVAL, "workspace is NULL");
     hipStream_t st = (hipStream_t)stream;
-    // workspace: unit rows [Ntot, C] | norms [Ntot] | scratch of the split rows
+    // workspace: unit rows [Ntot, C] | norms [Ntot] | fp16 filter rows | scratch of the split rows
     float *n = (float *)workspace;
     float *nrm = (float *)((char *)workspace + (g->Ntot * (int64_t)C * 4 + 255) / 256 * 256);
     void *scratch = (char *)workspace + fwd_table_bytes(g->Ntot, C);
+    void *filt = use_filter(g, C, top_k, thr) ? ws_filter(workspace, g->Ntot, C) : nullptr;
     hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
-    if (int rc = normalize_dispatch(cfg, h, g->Ntot, C, n, nrm, st)) return rc;
-    return forward_normalized(g, cfg, n, nrm, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
+    if (int rc = normalize_dispatch(cfg, h, g->Ntot, C, n, nrm, filt, st)) return rc;
+    return forward_normalized(g, cfg, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
+                              ev ? ev + 1 : nullptr, st);
+}
+
+extern "C" int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                          const void *filt, int C, int top_k, float thr, float *out, float *wsel,
+                                          float *inv_norm, int32_t *sel_src, float *sel_w, void *workspace,
+                                          void *stream)
+{
+    RowCfg cfg;
+    if (int rc = check_forward_args(g, n, C, top_k, out, sel_src, sel_w, cfg)) return rc;
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(nrm != nullptr, SNGNN_EINVAL, "nrm is NULL");
+    SN_REQUIRE(workspace != nullptr || (g->n_tasks == 0 && (filt != nullptr || !use_filter(g, C, top_k, thr))),
+               SNGNN_EINVAL, "workspace is NULL");
+    SN_REQUIRE(filt == nullptr || filter_row_bytes(C) > 0, SNGNN_EINVAL,
+               "no filter rows for this C (sngnn_filter_row_bytes(C) == 0)");
+    SN_REQUIRE(((uintptr_t)filt % 16) == 0, SNGNN_EINVAL, "filt must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    // same workspace layout as sngnn_agg_forward; the unit-row region stays unused
+    void *scratch = workspace ? (char *)workspace + fwd_table_bytes(g->Ntot, C) : nullptr;
+    hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
+    if (ev) { SN_HIP(hipEventRecord(ev[0], st)); }
+    const void *f = nullptr;
+    if (use_filter(g, C, top_k, thr)) {
+        f = filt;
+        if (!f) {       // the caller holds no filter rows: one more pass over its unit rows
+            void *wf = ws_filter(workspace, g->Ntot, C);
+            if (int rc = launch_filter_v4(cfg, n, g->Ntot, C, wf, st)) return rc;
+            f = wf;
+        }
+    }
+    return forward_normalized(g, cfg, n, nrm, f, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
                               ev ? ev + 1 : nullptr, st);
 }
 
@@ -151,16 +276,6 @@ extern "C" int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float 
                                             int top_k, float thr, float *out, float *wsel, float *inv_norm,
                                             int32_t *sel_src, float *sel_w, void *workspace, void *stream)
 {
-    RowCfg cfg;
-    if (int rc = check_forward_args(g, n, C, top_k, out, sel_src, sel_w, cfg)) return rc;
-    if (g->N == 0) return SNGNN_OK;
-    SN_REQUIRE(nrm != nullptr, SNGNN_EINVAL, "nrm is NULL");
-    SN_REQUIRE(workspace != nullptr || g->n_tasks == 0, SNGNN_EINVAL, "workspace is NULL");
-    hipStream_t st = (hipStream_t)stream;
-    // same workspace layout as sngnn_agg_forward; the table region stays unused
-    void *scratch = workspace ? (char *)workspace + fwd_table_bytes(g->Ntot, C) : nullptr;
-    hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
-    if (ev) { SN_HIP(hipEventRecord(ev[0], st)); }
-    return forward_normalized(g, cfg, n, nrm, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
-                              ev ? ev + 1 : nullptr, st);
+    return sngnn_agg_forward_prepared(g, n, nrm, nullptr, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w,
+                                      workspace, stream);
 }

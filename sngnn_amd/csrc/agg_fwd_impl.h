@@ -36,6 +36,7 @@
 // The kernels are HBM/Infinity-Cache bound gathers of 4*C-byte rows; each lane
 // group reads one whole source row per load (VEC*4 B per lane, coalesced).
 #pragma once
+#include "agg_fwd_filter.h"
 #include "device_utils.h"
 
 namespace sngnn {
@@ -43,6 +44,7 @@ namespace sngnn {
 struct FwdArgs {
     const float *n;       // [Ntot, C] unit rows (k_normalize_rows)
     const float *nrm;     // [Ntot]    max(|h|_2, eps)
+    const uint4 *filt;    // [Ntot, filter_row_halfs(C)] fp16 filter rows (agg_fwd_filter.h) or nullptr
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
@@ -56,12 +58,14 @@ struct FwdArgs {
     int n_split, n_med_end;     // slots [0,n_split) split, [n_split,n_med_end) wave, rest small
     int n_tasks;
     const int32_t *task_slot, *task_chunk, *split_soff, *split_task0;
+    const int32_t *task_order;      // position in the dealing order -> task (graph.hip 7b)
     float *scores, *partial;    // workspace
     unsigned long long *cand_key;   // [n_tasks, k]  chunk-local top-k keys of split rows
     int32_t *cand_src;              // [n_tasks, k]  their source ids (saves the finalize a dependent load)
     int use_cand;                   // split rows keep chunk-local candidates (k <= CAND_MAX_K and they fit LDS)
     int lowbits;                    // bits needed for a row-local edge index
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
+    int role_mask;              // measurement aid (sngnn_tuning_set): bit 0 tasks, 1 wave rows, 2 small rows
 };
 
 #ifndef SNGNN_FWD_WAVES
@@ -87,7 +91,8 @@ template <int G> struct WaveLds {
 // ---------------------------------------------------------------------------
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) void k_normalize_rows(const float *__restrict__ h, int64_t rows, int C,
-                                                          float *__restrict__ n, float *__restrict__ nrm)
+                                                          float *__restrict__ n, float *__restrict__ nrm,
+                                                          uint2 *__restrict__ filt)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int RPW = 64 / G;
@@ -112,13 +117,24 @@ __global__ __launch_bounds__(BLOCK) void k_normalize_rows(const float *__restric
             if (r < rows) {
                 x[u].store(n + r * C, C, lg);
                 if (lg == 0) nrm[r] = d;
+                if constexpr (VEC == 4) {
+                    // fp16 filter row (agg_fwd_filter.h): the lanes' 4-channel vectors cover exactly
+                    // filter_row_halfs(C) = 4 G R channels, the ones beyond C hold zeros
+                    if (filt) {
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+                            filt[(size_t)r * (G * R) + q * G + lg] =
+                                make_uint2(pack_half2(x[u].x[q][0] * FILT_SCALE, x[u].x[q][1] * FILT_SCALE),
+                                           pack_half2(x[u].x[q][2] * FILT_SCALE, x[u].x[q][3] * FILT_SCALE));
+                    }
+                }
             }
         }
     }
 }
 
 template <int VEC, int G, int R>
-int launch_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st)
+int launch_normalize_rows(const float *h, int64_t rows, int C, float *n, float *nrm, void *filt, hipStream_t st)
 {
     constexpr int RPW = 64 / G;
     constexpr int U = Unroll<R>::U >= 2 ? 2 : 1;
@@ -127,9 +143,50 @@ int launch_normalize_rows(const float *h, int64_t rows, int C, float *n, float *
     // grid-stride beyond), so the launch drains evenly
     const int64_t steps = (rows + RPW * U - 1) / (RPW * U);
     const int grid = (int)std::min<int64_t>(ceil_div(steps, WAVES), 256 * 8 * 4);
-    k_normalize_rows<VEC, G, R><<<grid, BLOCK, 0, st>>>(h, rows, C, n, nrm);
+    if (filt && !(VEC == 4 && filter_row_bytes(C) == 8 * G * R)) {
+        set_error("internal: filter rows need 16-byte row vectors");
+        return SNGNN_EINVAL;
+    }
+    k_normalize_rows<VEC, G, R><<<grid, BLOCK, 0, st>>>(h, rows, C, n, nrm, (uint2 *)filt);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
+}
+
+// fp16 filter rows from unit rows the caller already holds (sngnn_agg_forward_normalized)
+template <int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_filter_rows(const float *__restrict__ n, int64_t rows, int C,
+                                                       uint2 *__restrict__ filt)
+{
+    using RowT = Row<4, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int64_t nw = (int64_t)gridDim.x * WAVES;
+    for (int64_t r = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW + gid; r < rows; r += nw * RPW) {
+        RowT x;
+        x.load(n + r * C, C, lg);
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            filt[(size_t)r * (G * R) + q * G + lg] =
+                make_uint2(pack_half2(x.x[q][0] * FILT_SCALE, x.x[q][1] * FILT_SCALE),
+                           pack_half2(x.x[q][2] * FILT_SCALE, x.x[q][3] * FILT_SCALE));
+    }
+}
+
+template <int VEC, int G, int R>
+int launch_filter_rows(const float *n, int64_t rows, int C, void *filt, hipStream_t st)
+{
+    if constexpr (VEC == 4) {
+        if (rows <= 0) return SNGNN_OK;
+        if (filter_row_bytes(C) != 8 * G * R) { set_error("internal: filter row layout"); return SNGNN_EINVAL; }
+        const int grid = (int)std::min<int64_t>(ceil_div(rows, (64 / G) * WAVES), 256 * 8 * 4);
+        k_filter_rows<G, R><<<grid, BLOCK, 0, st>>>(n, rows, C, (uint2 *)filt);
+        SN_HIP(hipGetLastError());
+        return SNGNN_OK;
+    } else {
+        set_error("internal: filter rows need 16-byte row vectors");
+        return SNGNN_EINVAL;
+    }
 }
 
 // per-edge cosine of two unit rows (fma chain over the lane's channels, fixed-order
@@ -428,10 +485,74 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, 
     }
 }
 
+// Exact scores of the listed edges (list[q] = chunk-local edge index, ids[idx] = its source):
+// sc[idx] = <n_i, n_j>.  U rows per lane group in flight; a slot past the end repeats the
+// last listed edge and stores nothing.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void score_list(const FwdArgs &a, const Row<VEC, G, R> &ni, const int *list, int ncand,
+                                           const int *ids, float *sc)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+#ifndef SNGNN_LIST_U
+#define SNGNN_LIST_U 1
+#endif
+    constexpr int U = Unroll<R>::U * (R == 1 ? SNGNN_LIST_U : 1);     // the usual k + a few candidates: one trip
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    for (int q0 = 0; q0 < ncand; q0 += NG * U) {
+        RowT x[U];
+        int idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + u * NG + gid;
+            idx[u] = list[min(q, ncand - 1)];
+            x[u].load(a.n + (size_t)ids[idx[u]] * a.C, a.C, lg);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float s = unit_dot<VEC, G, R>(ni, x[u]);
+            if (q0 + u * NG + gid < ncand && lg == 0) sc[idx[u]] = s;
+        }
+    }
+}
+
+// The filtered form of "score the edges [e0, e1) and select" for a ranking row (deg > top_k):
+// approximate scores of all n = e1 - e0 <= 128 edges from the fp16 filter rows, exact scores
+// of the candidates only (agg_fwd_filter.h), exact selection among them.  On return sc[t]
+// holds the exact score of every candidate (in particular of every kept edge), ids[t] the
+// source of every edge, and the returned keys / flags are what wave_select would have given
+// on exact scores of all edges.  list[] is scratch.
+template <int VEC, int G, int R>
+__device__ __forceinline__ WaveSel filtered_select(const FwdArgs &a, const Row<VEC, G, R> &ni, int self, int rs,
+                                                   int e0, int e1, float *sc, int *list, int *ids, int lowbits)
+{
+    constexpr int GF = G * R / 2;                    // 16-byte lanes per filter row (VEC == 4)
+    const int lane = lane_id();
+    const int n = e1 - e0;
+    filter_scores<GF>(a.filt, a.col, self, rs, e0, e1, sc, ids);
+    wave_lds_sync();
+    bool c0, c1;
+    approx_candidates(sc, n, a.k, a.thr, c0, c1);
+    const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+    const int n0 = __popcll(m0), ncand = n0 + __popcll(m1);
+    if (c0) list[prefix_popc(m0)] = lane;
+    if (c1) list[n0 + prefix_popc(m1)] = lane + 64;
+    wave_lds_sync();
+    if (ncand > 0) score_list<VEC, G, R>(a, ni, list, ncand, ids, sc);
+    wave_lds_sync();
+    WaveSel r;
+    const float s0 = c0 ? sc[lane] : 0.f, s1 = c1 ? sc[lane + 64] : 0.f;
+    r.key0 = (c0 && s0 >= a.thr) ? sel_key(s0, e0 + lane) : 0ull;
+    r.key1 = (c1 && s1 >= a.thr) ? sel_key(s1, e0 + lane + 64) : 0ull;
+    wave_topk_keys(r.key0, r.key1, a.k, lowbits, r.kept0, r.kept1);
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool FILT>
 __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -455,12 +576,24 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 
     RowT acc;
     acc.zero();
-    score_edges<VEC, G, R>(a, self, rs, 0, deg, ni, !rank, need_sc ? s_sc : nullptr, 0, acc,
-                           rank ? s_ids : nullptr);
+    const bool filtered = FILT && rank;
+    if (!filtered)
+        score_edges<VEC, G, R>(a, self, rs, 0, deg, ni, !rank, need_sc ? s_sc : nullptr, 0, acc,
+                               rank ? s_ids : nullptr);
 
     if (need_sc) {
-        wave_lds_sync();
-        const WaveSel ws = wave_select(s_sc, deg, 0, a.k, a.thr, 7);
+        WaveSel ws;
+        if constexpr (FILT) {
+            if (filtered) {
+                ws = filtered_select<VEC, G, R>(a, ni, self, rs, 0, deg, s_sc, s_list, s_ids, 7);
+            } else {
+                wave_lds_sync();
+                ws = wave_select(s_sc, deg, 0, a.k, a.thr, 7);
+            }
+        } else {
+            wave_lds_sync();
+            ws = wave_select(s_sc, deg, 0, a.k, a.thr, 7);
+        }
         const int i0 = lane, i1 = lane + 64;
         // kept list in ascending position order
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
@@ -521,7 +654,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 // ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool FILT>
 __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -544,11 +677,18 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
     acc.zero();
     float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
     float *sc_glb = (!cand && (rank || emit)) ? a.scores + a.split_soff[p] : nullptr;   // HBM scratch
-    if (cand) score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, s_sc, e0, acc);          // LDS
+    if (FILT && cand) { /* scored below, through the filter */ }
+    else if (cand) score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, s_sc, e0, acc);     // LDS
     else score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, sc_glb, 0, acc);             // HBM / none
     if (cand) {
-        wave_lds_sync();
-        const WaveSel ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
+        WaveSel ws;
+        if constexpr (FILT) {
+            ws = filtered_select<VEC, G, R>(a, ni, self, rs, e0, e1, s_sc, lds_wave + CHUNK, lds_wave + 2 * CHUNK,
+                                            a.lowbits);
+        } else {
+            wave_lds_sync();
+            ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
+        }
         unsigned long long *ck = a.cand_key + (size_t)tq * CAND_MAX_K;
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
         const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
@@ -573,22 +713,24 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // Persistent waves: wave w of the grid takes work items w, w + n_waves, ... of the
 // list [split-row tasks | wave rows | small-row sets], each class in order of
 // descending degree, so every wave gets a similar mix and the grid drains evenly.
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool FILT>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
-    __shared__ int lds[WAVES][WaveLds<G>::WORDS];
+    __shared__ __align__(16) int lds[WAVES][WaveLds<G>::WORDS];
     const int wave = threadIdx.x >> 6;
     int *lw = lds[wave];
     const int nw = gridDim.x * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
-    for (; it < a.n_tasks; it += nw) role_task<VEC, G, R>(a, it, lw);
+    for (; it < a.n_tasks; it += nw)
+        if (a.role_mask & 1) role_task<VEC, G, R, FILT>(a, a.task_order[it], lw);
     it -= a.n_tasks;
-    for (; it < n_wave_rows; it += nw) role_wave<VEC, G, R>(a, it, lw);
+    for (; it < n_wave_rows; it += nw)
+        if (a.role_mask & 2) role_wave<VEC, G, R, FILT>(a, it, lw);
     it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    role_small<VEC, G, R>(a, it, nw, nsets, lw);
+    if (a.role_mask & 4) role_small<VEC, G, R>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -756,14 +898,12 @@ constexpr size_t FINC_LDS_BUDGET = 150 * 1024;
 inline size_t finc_lds_bytes(int C, int max_slots) { return ((size_t)FINC_WAVES * C + 1) * 4 + (size_t)max_slots * 24 + 16; }
 
 template <int VEC, int G, int R>
-__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
+__device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_slots, unsigned char *dyn)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
-    extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const int gid = lane / G, lg = lane % G;
-    const int p = blockIdx.x;
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
@@ -885,22 +1025,25 @@ __global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, in
     }
 }
 
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
+{
+    extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
+    fin_cand_row<VEC, G, R>(a, blockIdx.x, max_slots, dyn);
+}
+
 // The same finalize for split rows whose candidates fit one wave-level selection
 // ((tasks) * k <= 128, i.e. deg <= 8 * CHUNK at k = 16): one WAVE per row, no workgroup
-// barrier, 4 rows per workgroup.  On graphs with many moderately large rows
+// barrier.  On graphs with many moderately large rows
 // (products-like: ~10^5 split rows) the 1024-thread tournament above is mostly idle.
+// s_key_w / s_src_w: the wave's own CAND_MAX_K LDS slots.
 template <int VEC, int G, int R>
-__global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int first, int count)
+__device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned long long *s_key_w, int *s_src_w)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
-    __shared__ unsigned long long s_key[WAVES][CAND_MAX_K];
-    __shared__ int s_src[WAVES][CAND_MAX_K];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
-    const int q = blockIdx.x * WAVES + wave;
-    if (q >= count) return;                                   // wave-uniform
-    const int p = first + q;
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
@@ -929,8 +1072,8 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
     const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-    if (k0) { const int o = prefix_popc(m0); s_key[wave][o] = key0; s_src[wave][o] = src0; }
-    if (k1) { const int o = n0 + prefix_popc(m1); s_key[wave][o] = key1; s_src[wave][o] = src1; }
+    if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
+    if (k1) { const int o = n0 + prefix_popc(m1); s_key_w[o] = key1; s_src_w[o] = src1; }
     wave_lds_sync();
     RowT acc;
     acc.zero();
@@ -941,30 +1084,62 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int w = min(w0 + u * NG + gid, nsel - 1);
-            const int j = s_src[wave][w];
+            const int j = s_src_w[w];
             x[u].load(a.n + (size_t)j * a.C, a.C, lg);
             nj[u] = a.nrm[j];
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int w = w0 + u * NG + gid;
-            if (w < nsel) acc.axpy(key_score(s_key[wave][w]) * nj[u], x[u]);
+            if (w < nsel) acc.axpy(key_score(s_key_w[w]) * nj[u], x[u]);
         }
     }
     if (lane < nsel) {
-        const unsigned long long kq = s_key[wave][lane];
+        const unsigned long long kq = s_key_w[lane];
         const float sq = key_score(kq);
         if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
         if (emit) {
             int rk = 0;
-            for (int r = 0; r < nsel; ++r) rk += s_key[wave][r] > kq;
-            a.sel_src[(size_t)i * a.k + rk] = s_src[wave][lane];
+            for (int r = 0; r < nsel; ++r) rk += s_key_w[r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = s_src_w[lane];
             a.sel_w[(size_t)i * a.k + rk] = sq;
         }
     }
     acc.reduce_across_groups();
     acc.div((float)deg);
     if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
+}
+
+// 4 rows per 256-thread workgroup
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int first, int count)
+{
+    __shared__ unsigned long long s_key[WAVES][CAND_MAX_K];
+    __shared__ int s_src[WAVES][CAND_MAX_K];
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * WAVES + wave;
+    if (q >= count) return;                                   // wave-uniform
+    fin_wave_row<VEC, G, R>(a, first + q, s_key[wave], s_src[wave]);
+}
+
+// Both in ONE launch when the moderate split rows are few (arxiv-like graphs: a few hundred
+// split rows in all): workgroups [0, n_big) run the tournament of one big row each, the
+// others one moderate row per wave - 140 workgroups that all start at once instead of 825
+// tournaments of which 512 fit the chip (finalize 8.8 -> see DESIGN.md 4.1).
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split)
+{
+    extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
+    if ((int)blockIdx.x < n_big) {                         // (workgroup-uniform)
+        fin_cand_row<VEC, G, R>(a, blockIdx.x, max_slots, dyn);
+        return;
+    }
+    const int wave = threadIdx.x >> 6;
+    const int p = n_big + ((int)blockIdx.x - n_big) * FINC_WAVES + wave;
+    if (p >= n_split) return;                              // wave-uniform
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(dyn) + wave * CAND_MAX_K;
+    int *s_src = reinterpret_cast<int *>(dyn + FINC_WAVES * CAND_MAX_K * 8) + wave * CAND_MAX_K;
+    fin_wave_row<VEC, G, R>(a, p, s_key, s_src);
 }
 
 // whether split rows keep chunk-local candidates (else: scores to HBM scratch + k_agg_fin)
@@ -997,9 +1172,20 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
         // (no selection, k < 0: the split is by the number of partial rows to add, > 16 tasks -> workgroup)
         const int n_big = a.k < 0 ? a.n_split - n_wave
                                   : ((a.k > 0 && n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - n_wave : (a.k > 0 ? a.n_split : 0));
-        if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
-        if (a.n_split > n_big)
-            k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
+        const int n_big_true = a.n_split - n_wave;         // rows that need the tournament
+        if (a.k > 0 && n_big == a.n_split && n_wave > 0 && n_big_true < a.n_split) {
+            // few moderate rows: one mixed launch
+            const size_t dyn_mixed = std::max(dyn, (size_t)FINC_WAVES * CAND_MAX_K * 12);
+            if (dyn_mixed > 48 * 1024)
+                SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_mixed));
+            k_agg_fin_mixed<VEC, G, R><<<n_big_true + ceil_div(n_wave, FINC_WAVES), FINC_BLOCK, dyn_mixed, st>>>(
+                a, max_slots, n_big_true, a.n_split);
+        } else {
+            if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
+            if (a.n_split > n_big)
+                k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
+        }
     } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)std::min(std::max(a.k, 0), max_split_deg) * 4;
         const size_t budget = 120 * 1024;
@@ -1024,7 +1210,14 @@ int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStrea
     // persistent grid: what the chip holds at the kernel's occupancy, or less
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
-    if (grid > 0) k_agg_fwd<VEC, G, R><<<grid, BLOCK, 0, st>>>(a);
+    if (grid > 0) {
+        if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
+            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true><<<grid, BLOCK, 0, st>>>(a);
+            else k_agg_fwd<VEC, G, R, false><<<grid, BLOCK, 0, st>>>(a);
+        } else {
+            k_agg_fwd<VEC, G, R, false><<<grid, BLOCK, 0, st>>>(a);
+        }
+    }
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
     if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;
     if (ev) {
@@ -1042,8 +1235,12 @@ int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hi
                       hipStream_t st);
 int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
                       hipStream_t st);
-int launch_normalize_v1(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
-int launch_normalize_v2(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
-int launch_normalize_v4(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, hipStream_t st);
+int launch_normalize_v1(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, void *filt,
+                        hipStream_t st);
+int launch_normalize_v2(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, void *filt,
+                        hipStream_t st);
+int launch_normalize_v4(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm, void *filt,
+                        hipStream_t st);
+int launch_filter_v4(const RowCfg &cfg, const float *n, int64_t rows, int C, void *filt, hipStream_t st);
 
 }  // namespace sngnn

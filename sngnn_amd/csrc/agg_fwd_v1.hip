@@ -10,9 +10,9 @@ int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hi
 }
 
 int launch_normalize_v1(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm,
-                        hipStream_t st)
+                        void *filt, hipStream_t st)
 {
-    SNGNN_DISPATCH_GR(launch_normalize_rows, 1, cfg, h, rows, C, n, nrm, st)
+    SNGNN_DISPATCH_GR(launch_normalize_rows, 1, cfg, h, rows, C, n, nrm, filt, st)
 }
 
 }  // namespace sngnn

@@ -10,9 +10,14 @@ int launch_agg_fwd_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hi
 }
 
 int launch_normalize_v4(const RowCfg &cfg, const float *h, int64_t rows, int C, float *n, float *nrm,
-                        hipStream_t st)
+                        void *filt, hipStream_t st)
 {
-    SNGNN_DISPATCH_GR(launch_normalize_rows, 4, cfg, h, rows, C, n, nrm, st)
+    SNGNN_DISPATCH_GR(launch_normalize_rows, 4, cfg, h, rows, C, n, nrm, filt, st)
+}
+
+int launch_filter_v4(const RowCfg &cfg, const float *n, int64_t rows, int C, void *filt, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_filter_rows, 4, cfg, n, rows, C, filt, st)
 }
 
 }  // namespace sngnn

@@ -60,11 +60,22 @@ inline bool row_cfg(int C, RowCfg &cfg)
     return true;
 }
 
-// bytes of the forward's unit-row table + norms in front of its scratch inside the workspace
-// (256-byte aligned regions)
+// bytes of one fp16 filter row (agg_fwd_filter.h): whole 128-byte lines; 0 = no filter for this C
+// (it pays when a unit row is longer than one line and the rows are 16-byte vectors)
+inline int64_t filter_row_bytes(int C)
+{
+    if (C % 4 != 0 || C <= 32 || C > SNGNN_MAX_CHANNELS) return 0;
+    int64_t b = 128;                 // 2 bytes x (4 G R) channels of the row layout: 64, 128, 256 or 512
+    while (b < 2 * (int64_t)C) b <<= 1;
+    return b;
+}
+
+// bytes of the forward's unit-row table + norms + filter rows in front of its scratch inside
+// the workspace (256-byte aligned regions)
 inline int64_t fwd_table_bytes(int64_t Ntot, int C)
 {
-    return (Ntot * (int64_t)C * 4 + 255) / 256 * 256 + (Ntot * 4 + 255) / 256 * 256;
+    return (Ntot * (int64_t)C * 4 + 255) / 256 * 256 + (Ntot * 4 + 255) / 256 * 256 +
+           (Ntot * filter_row_bytes(C) + 255) / 256 * 256;
 }
 
 }  // namespace sngnn
@@ -100,6 +111,7 @@ struct sngnn_graph {
     float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
+    int32_t *task_order = nullptr;    // [n_tasks] dealing order of the forward's tasks (XCD-affine by source slice)
     int32_t *split_soff = nullptr;    // [n_split+1] offset of the row's scores in scratch
     int32_t *split_task0 = nullptr;   // [n_split+1] first task of the row
     // split sources (out-degree > WAVE_T) = the first n_ssplit slots of sperm

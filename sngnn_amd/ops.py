@@ -74,10 +74,30 @@ def normalize_rows(h: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return n, nrm
 
 
+def filter_row_bytes(c: int) -> int:
+    """``sngnn_filter_row_bytes``: bytes of one fp16 filter row for C channels, 0 = no filter."""
+    return int(_lib.load().sngnn_filter_row_bytes(int(c)))
+
+
+def normalize_rows_filter(h: torch.Tensor):
+    """``sngnn_normalize_rows_filter``: (unit rows, clamped norms, filter rows or None)."""
+    h = _check_rows(h, h.size(0), "h")
+    n = torch.empty_like(h)
+    nrm = torch.empty(h.size(0), dtype=torch.float32, device=h.device)
+    fb = filter_row_bytes(h.size(1))
+    filt = torch.empty((h.size(0), fb), dtype=torch.uint8, device=h.device) if fb else None
+    with torch.cuda.device(h.device):
+        rc = _lib.load().sngnn_normalize_rows_filter(h.data_ptr(), h.size(0), h.size(1), n.data_ptr(),
+                                                     nrm.data_ptr(), _lib.ptr(filt), _stream(h.device))
+    _lib.check(rc, "sngnn_normalize_rows_filter")
+    return n, nrm, filt
+
+
 def aggregate_forward_normalized(graph: Graph, n: torch.Tensor, nrm: torch.Tensor,
-                                 top_k: Optional[int], thr: float, *, want_selection: bool = False):
-    """``sngnn_agg_forward_normalized``: the aggregation on unit rows + norms that the caller
-    already holds.  Returns (out, sel_src, sel_w)."""
+                                 top_k: Optional[int], thr: float, *, want_selection: bool = False,
+                                 filt: Optional[torch.Tensor] = None):
+    """``sngnn_agg_forward_prepared``: the aggregation on unit rows + norms (+ filter rows)
+    that the caller already holds.  Returns (out, sel_src, sel_w)."""
     lib = _lib.load()
     n = _check_rows(n, graph.num_total_nodes, "n")
     if nrm.dtype != torch.float32 or nrm.numel() != graph.num_total_nodes or not nrm.is_cuda:
@@ -92,10 +112,10 @@ def aggregate_forward_normalized(graph: Graph, n: torch.Tensor, nrm: torch.Tenso
         sel_w = torch.empty((graph.num_nodes, k), dtype=torch.float32, device=n.device)
     ws = graph.workspace(c)
     with torch.cuda.device(n.device):
-        rc = lib.sngnn_agg_forward_normalized(graph.handle, n.data_ptr(), nrm.data_ptr(), c, k, float(thr),
-                                              out.data_ptr(), None, None, _lib.ptr(sel_src),
-                                              _lib.ptr(sel_w), ws.data_ptr(), _stream(n.device))
-    _lib.check(rc, "sngnn_agg_forward_normalized")
+        rc = lib.sngnn_agg_forward_prepared(graph.handle, n.data_ptr(), nrm.data_ptr(), _lib.ptr(filt), c, k,
+                                            float(thr), out.data_ptr(), None, None, _lib.ptr(sel_src),
+                                            _lib.ptr(sel_w), ws.data_ptr(), _stream(n.device))
+    _lib.check(rc, "sngnn_agg_forward_prepared")
     return out, sel_src, sel_w
 
 

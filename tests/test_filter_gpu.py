@@ -1,0 +1,93 @@
+"""The fp16 filter of the selecting forward (csrc/agg_fwd_filter.h): its error bound on the
+hardware, and that it never changes a result - selections, weights, outputs and saved
+selections with the filter are bit-identical to the unfiltered path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import random_graph
+
+pytestmark = pytest.mark.gpu
+FILT_EPS = 1.1e-3          # csrc/agg_fwd_filter.h
+
+
+def _rows(n, c, seed, kind):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "normal":
+        h = torch.randn(n, c, generator=g)
+    elif kind == "parallel":           # nearly parallel rows: every cosine within 1e-3 of 1
+        h = torch.randn(1, c, generator=g) + 1e-2 * torch.randn(n, c, generator=g)
+    elif kind == "tiny":               # components far below fp16's range before the scaling
+        h = torch.randn(n, c, generator=g) * torch.logspace(-30, 0, c).view(1, -1)
+    else:                              # sparse non-negative (bag-of-words after a ReLU)
+        h = torch.relu(torch.randn(n, c, generator=g) - 1.0)
+    h[5] = h[6]
+    h[9] = 0.0
+    return h
+
+
+@pytest.mark.parametrize("c", [36, 40, 48, 64, 100, 128, 256, 512])
+@pytest.mark.parametrize("kind", ["normal", "parallel", "tiny", "sparse"])
+def test_filter_error_bound_on_the_hardware(cuda, c, kind):
+    from sngnn_amd import _lib, ops
+    n = 3000
+    h = _rows(n, c, c, kind).to(cuda)
+    un, _, filt = ops.normalize_rows_filter(h)
+    assert filt is not None and filt.shape == (n, ops.filter_row_bytes(c)) and filt.size(1) % 128 == 0
+    g = torch.Generator().manual_seed(1)
+    pa = torch.randint(0, n, (200_000,), generator=g).to(cuda)
+    pb = torch.randint(0, n, (200_000,), generator=g).to(cuda)
+    out = torch.empty(pa.numel(), dtype=torch.float32, device=cuda)
+    _lib.check(_lib.load().sngnn_filter_pair_scores(filt.data_ptr(), c, pa.data_ptr(), pb.data_ptr(), pa.numel(),
+                                                    out.data_ptr(), torch.cuda.current_stream().cuda_stream), "pairs")
+    exact = (un[pa].double() * un[pb].double()).sum(-1)
+    err = (out.double() - exact).abs().max().item()
+    assert err <= 0.95 * FILT_EPS, err            # the proven bound leaves slack for the fp32 sums
+    # what the table holds: fl16(1024 * n), zero beyond C
+    f16 = filt.view(torch.float16)
+    assert f16.shape[1] >= c and (f16[:, c:] == 0).all()
+    assert torch.equal(f16[:, :c], (un * 1024.0).to(torch.float16))
+
+
+CASES = [
+    # n, e, C, hubs, top_k, thr, kind
+    (3000, 60000, 40, ((0, 2999), (3, 900), (9, 300)), 16, 0.0, "normal"),
+    (3000, 60000, 40, ((0, 2999), (3, 900)), 16, 0.9, "normal"),
+    (2000, 50000, 40, ((1, 1500),), 10, 0.0, "parallel"),
+    (2000, 50000, 64, ((1, 1500),), 1, 0.99, "sparse"),
+    (1500, 40000, 48, ((2, 1400), (7, 200)), 32, -1.0, "normal"),
+    (1500, 40000, 128, ((2, 1400),), 16, 0.0, "sparse"),
+    (1200, 30000, 256, ((2, 1100),), 4, 0.0, "tiny"),
+    (1000, 30000, 36, ((4, 999),), 16, 0.0, "sparse"),
+    (1000, 30000, 40, ((4, 999),), 0, 0.0, "normal"),
+]
+
+
+@pytest.mark.parametrize("n,e,c,hubs,k,thr,kind", CASES)
+def test_filter_changes_nothing(cuda, n, e, c, hubs, k, thr, kind):
+    from sngnn_amd import _lib, ops
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    ei = random_graph(n, e, seed=n + c, hubs=hubs).to(cuda)
+    h = _rows(n, c, 7 * c + k, kind).to(cuda)
+    g = Graph(ei, n, True, True)
+    res = []
+    try:
+        for on in (2, 0):                       # always / never (1 = auto is the default)
+            lib.sngnn_filter_enable(on)
+            out, wsel, _, _, _ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+            _, _, _, sel_src, sel_w = ops.aggregate_forward(g, h, k, thr, want_selection=True)
+            res.append((out, wsel, sel_src, sel_w))
+    finally:
+        lib.sngnn_filter_enable(1)
+    for a, b, what in zip(res[0], res[1], ("out", "wsel", "sel_src", "sel_w")):
+        assert torch.equal(a, b), what
+    # and through the entry for callers that hold the unit rows (+ filter rows)
+    un, nrm, filt = ops.normalize_rows_filter(h)
+    out_p, src_p, w_p = ops.aggregate_forward_normalized(g, un, nrm, k, thr, want_selection=True, filt=filt)
+    out_n, src_n, w_n = ops.aggregate_forward_normalized(g, un, nrm, k, thr, want_selection=True)
+    for a, b in ((out_p, res[0][0]), (out_n, res[0][0]), (src_p, res[0][2]), (src_n, res[0][2]),
+                 (w_p, res[0][3]), (w_n, res[0][3])):
+        assert torch.equal(a, b)

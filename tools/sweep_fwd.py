@@ -28,6 +28,12 @@ if os.environ.get("MODE") == "normalized":      # the caller holds the unit rows
     call = lambda k, thr: ops.aggregate_forward_normalized(g, un, unrm, k, thr)
 else:
     call = lambda k, thr: ops.aggregate_forward(g, h, k, thr)
+if os.environ.get("FILTER") is not None:          # A/B of the fp16 filter (csrc/agg_fwd_filter.h)
+    lib.sngnn_filter_enable(int(os.environ["FILTER"]))
+    print("filter mode", os.environ["FILTER"], "(0 never, 1 auto, 2 always)")
+if os.environ.get("ROLES") is not None:           # only some row classes of the main kernel (timing only)
+    lib.sngnn_tuning_set(0, int(os.environ["ROLES"]))
+    print("role mask", os.environ["ROLES"], "(1 tasks, 2 wave rows, 4 small rows)")
 for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
     res, wall = [], []
     for rnd in range(int(os.environ.get("ROUNDS", 4))):
