@@ -21,6 +21,24 @@ for a node-range partition); the line reports the bytes each exchange form moves
 SNGNN_Plus_Plus layer - adjacency branch (Linear(num_nodes, C) on the sparse adjacency) +
 aggregation + blend - at C = 48 (47 classes padded to 16-byte rows).
 
+The line's keys (beyond the driver's contract):
+  roofline        dominant kernel k_agg_fwd: SURVEY.md 8d's algorithmic bytes of one launch over its
+                  average launch duration, HIP events on the launch stream around BATCHES of 20
+                  back-to-back launches recorded inside the library (sngnn_profile_enable(20)), nothing
+                  subtracted; the single-launch event interval and the committed rocprofv3 average of
+                  the same command are printed beside it (kernel_ms_single_launch_events,
+                  kernel_ms_rocprofv3).  traffic = counter bytes per launch of the committed PMC
+                  passes (profiles/traffic.json), not re-measured in this run.
+  roofline_step   the same bytes over ms_per_step - the whole forward (normalise + main + finalize
+                  launches and the gaps between them), the gate BASELINE.md defines.
+  variants        BASELINE.md's other config-4 cases (C = 32; thr = 0.9) timed the same way.
+  epoch_ms        train + validation + test step replayed from one HIP graph, the reference's
+                  THREE forwards (train.py:134-143); epoch_ms_shared_eval = validation and test
+                  read one eval-mode forward (bit-identical metrics); epoch_ms_eager = the
+                  reference-style loop.
+  --workload products also prints the ++ layer's forward+backward, its backward roofline and the
+  Adam step over the dense 460 MB w (train.py:376).
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -100,6 +118,33 @@ def cpu_baseline(h_cpu, ei_cpu, top_k, thr, reps):
     return res, dt
 
 
+def profile_forward(lib, _lib, ops, graph, table, top_k, thr, calls, reps):
+    """Device time of the forward's three launches from HIP events recorded inside the library on
+    the launch stream: every launch issued `reps` times back to back between its two events
+    (sngnn_profile_enable(reps); reps = 1: the single-launch interval).  Means over `calls` calls:
+    (normalise, main, finalize, empty event interval) in ms."""
+    lib.sngnn_profile_enable(int(reps))
+    z, m, f, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    acc = []
+    for _ in range(calls):
+        ops.aggregate_forward(graph, table, top_k, thr)
+        _lib.check(lib.sngnn_profile_last_forward(C.byref(z), C.byref(m), C.byref(f), C.byref(e0)), "profile")
+        acc.append((z.value, m.value, f.value, e0.value))
+    lib.sngnn_profile_enable(0)
+    return tuple(float(v) for v in np.mean(np.array(acc[1:] if len(acc) > 1 else acc), axis=0))
+
+
+def time_loop(fn, warmup, steps, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return time.perf_counter() - t0, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,13 +159,15 @@ def main():
                     help="conv output width C (default: the dataset's class count, 40 for arxiv)")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
                     help="N > 1: how the feature rows reach the ranks that reference them")
-    ap.add_argument("--locality", type=float, default=0.8,
+    ap.add_argument("--locality", type=float, default=0.0,
                     help="N > 1: fraction of a row's sources drawn from the rank's own node range "
-                         "(default 0.8: the edge cut of a locality-preserving 8-way partition of a real "
-                         "graph is 15-30 %%; 0 = sources uniform over ALL ranks' nodes, the adversarial "
-                         "case for a node-range partition)")
+                         "(default 0: sources uniform over ALL ranks' nodes, SURVEY.md 8d's generator and "
+                         "the adversarial case for a node-range partition; the edge cut of a "
+                         "locality-preserving 8-way partition of a real graph is 15-30 %%, i.e. 0.7-0.85 - "
+                         "the line's `locality_0.8` sub-result is that case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
     # (before anything initialises the HIP runtime, which reads it once: the host driver only
@@ -151,127 +198,121 @@ def main():
     from sngnn_amd.graph import Graph
     lib = _lib.load()
 
-    part = None
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     plus_plus = args.workload == "products"          # config 5: one SNGNN_Plus_Plus layer
     if plus_plus and args.channels is None:
         args.channels = 48                           # 47 classes, rows padded to 16 bytes
     strong = plus_plus and world > 1                 # config 5 partitions ONE products graph
-    n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device,
-                                                 args.channels, args.scale / world if strong else args.scale,
-                                                 args.locality)
-    n_total = n * world
-    plan = plan_f = None
-    if world > 1:
-        part = sn_dist.Partition(rank, world, n, exchange=args.exchange)
-    if world > 1 and args.exchange == "halo":
-        plan = sn_dist.HaloPlan(ei, part)
-        graph = Graph(plan.edge_index, plan.table_rows, True, True, row_range=(0, n))
-        table = torch.empty((plan.table_rows, c), dtype=torch.float32, device=device)
-        table[:n] = h_local                          # the rank's own rows: resident, not exchanged
-    elif world > 1:
-        graph = Graph(ei, n_total, True, True, row_range=(rank * n, (rank + 1) * n))
-        table = torch.empty((n_total, c), dtype=torch.float32, device=device)
-    else:
-        graph = Graph(ei, n, True, True)
-        table = h_local
-    e_prime = graph.num_edges
 
-    def exchange_rows(rows_local, plan_, table_):
-        """rows the rank's edges reference arrive in table_ (RCCL; P2P over gloo in a rehearsal)"""
-        if plan_ is None:
-            dist.all_gather_into_tensor(table_, rows_local)
-        elif rehearsal:
-            table_[n:] = sn_dist._all_to_all_rows(rows_local.index_select(0, plan_.send_idx), plan_.send_counts,
-                                                  plan_.recv_counts, part)
-        else:
-            dist.all_to_all_single(table_[n:], rows_local.index_select(0, plan_.send_idx),
-                                   output_split_sizes=plan_.recv_counts, input_split_sizes=plan_.send_counts)
-
-    if plus_plus:
-        # the adjacency branch: W^T rows [n, C] of Linear(num_nodes, C), sharded by node range
-        gen = torch.Generator(device="cpu").manual_seed(args.seed + 1)
-        wt_local = (torch.randn(n, c, generator=gen) * 0.01).to(device)
-        w_bias = torch.zeros(c, device=device)
-        beta = torch.full((1,), 0.3, device=device)
+    def build_rank(locality, exchange):
+        """Inputs, partition, local graph(s) and the step function of this rank.  N > 1 runs the
+        SAME exchange + aggregation code the conv layers run (sngnn_amd/dist.py:halo_aggregate -
+        the halo rows received straight into a fresh [own | halo] table, interior rows aggregated
+        while they are in flight - or all_gather_rows + ops.aggregate)."""
+        n, c, ei, x, h_local, lin = make_rank_inputs(args.workload, rank, world, args.seed, device, args.channels,
+                                                     args.scale / world if strong else args.scale, locality)
+        R = dict(n=n, c=c, ei=ei, x=x, h_local=h_local, plan=None, plan_f=None)
         if world > 1:
-            ei_f = ei.flip(0).contiguous()
-            if args.exchange == "halo":
-                plan_f = sn_dist.HaloPlan(ei_f, part)
-                graph_f = Graph(plan_f.edge_index, plan_f.table_rows, True, True, row_range=(0, n))
-                table_w = torch.empty((plan_f.table_rows, c), dtype=torch.float32, device=device)
-                table_w[:n] = wt_local
+            part = sn_dist.Partition(rank, world, n, exchange=exchange)
+            R["part"] = part
+            if exchange == "halo":
+                plan = R["plan"] = sn_dist.HaloPlan(ei, part)
+                graph = Graph(plan.edge_index, plan.table_rows, True, True, row_range=(0, n))
             else:
-                graph_f = Graph(ei_f, n_total, True, True, row_range=(rank * n, (rank + 1) * n))
-                table_w = torch.empty((n_total, c), dtype=torch.float32, device=device)
-
-    @torch.no_grad()
-    def step():
-        if world > 1:
-            exchange_rows(h_local, plan, table)
-        out1 = ops.aggregate_forward(graph, table, args.top_k, args.thr)[0]
-        if not plus_plus:
-            return out1
-        if world > 1:
-            exchange_rows(wt_local, plan_f, table_w)
-            out0 = ops.gather_sum(table_w, w_bias, graph_f)
+                graph = Graph(ei, n * world, True, True, row_range=(rank * n, (rank + 1) * n))
         else:
-            out0 = ops.adj_linear_forward(graph, wt_local, w_bias)
-        return ops.blend(out0, out1, beta)
+            graph = Graph(ei, n, True, True)
+        R["graph"] = graph
+        if plus_plus:
+            # the adjacency branch: W^T rows [n, C] of Linear(num_nodes, C), sharded by node range
+            gen = torch.Generator(device="cpu").manual_seed(args.seed + 1)
+            R["wt_local"] = wt_local = (torch.randn(n, c, generator=gen) * 0.01).to(device)
+            R["w_bias"] = w_bias = torch.zeros(c, device=device)
+            R["beta"] = beta = torch.full((1,), 0.3, device=device)
+            if world > 1:
+                ei_f = ei.flip(0).contiguous()
+                if exchange == "halo":
+                    plan_f = R["plan_f"] = sn_dist.HaloPlan(ei_f, part)
+                    graph_f = Graph(plan_f.edge_index, plan_f.table_rows, True, True, row_range=(0, n))
+                else:
+                    graph_f = Graph(ei_f, n * world, True, True, row_range=(rank * n, (rank + 1) * n))
 
-    def sync_all():
+        @torch.no_grad()
+        def step():
+            if world == 1:
+                out1 = ops.aggregate_forward(graph, h_local, args.top_k, args.thr)[0]
+            elif exchange == "halo":
+                out1 = sn_dist.halo_aggregate(h_local, R["plan"], graph, args.top_k, args.thr)
+            else:
+                out1 = ops.aggregate(sn_dist.all_gather_rows(h_local, part), graph, args.top_k, args.thr)
+            if not plus_plus:
+                return out1
+            if world == 1:
+                out0 = ops.adj_linear_forward(graph, wt_local, w_bias)
+            elif exchange == "halo":
+                out0 = ops.gather_sum(sn_dist.halo_exchange(wt_local, R["plan_f"]), w_bias, graph_f)
+            else:
+                out0 = ops.gather_sum(sn_dist.all_gather_rows(wt_local, part), w_bias, graph_f)
+            return ops.blend(out0, out1, beta)
+        R["step"] = step
+        return R
+
+    def measure(R, steps, warmup):
+        dt, out = time_loop(R["step"], warmup, steps, sync_all)
+        e_prime = R["graph"].num_edges
+        halo_rows = (R["plan"].n_halo if R["plan"] is not None else R["n"] * (world - 1)) if world > 1 else 0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            es = torch.tensor([float(e_prime), float(halo_rows)], dtype=torch.float64, device=device)
+            dist.all_reduce(es)
+            return float(tt.item()), int(es[0].item()), int(es[1].item()), out
+        return dt, e_prime, 0, out
 
-    for _ in range(args.warmup):
-        out = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    sync_all()
-    dt = time.perf_counter() - t0
-    halo_rows = (plan.n_halo if plan is not None else n_total - n) if world > 1 else 0
-    tt = torch.tensor([dt, float(e_prime), float(halo_rows)], dtype=torch.float64, device=device)
-    if world > 1:
-        tmax = tt[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        esum = tt[1:].clone()
-        dist.all_reduce(esum)
-        dt, e_all, halo_all = float(tmax.item()), int(esum[0].item()), int(esum[1].item())
-    else:
-        e_all, halo_all = e_prime, 0
+    R = build_rank(args.locality, args.exchange)
+    n, c, ei, x, h_local, graph, plan = R["n"], R["c"], R["ei"], R["x"], R["h_local"], R["graph"], R["plan"]
+    e_prime = graph.num_edges
+    dt, e_all, halo_all, out = measure(R, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
 
+    # N > 1: the two exchange forms must agree on this rank's rows (RCCL all_to_all_single vs
+    # all_gather_into_tensor: a self-check of the collectives on the real node)
+    exchange_check = None
+    if world > 1 and not plus_plus:
+        other = build_rank(args.locality, "allgather" if args.exchange == "halo" else "halo")
+        diff = (other["step"]() - R["step"]()).abs().max()
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        exchange_check = float(diff.item())
+        if not exchange_check <= 1e-6:
+            raise SystemExit(f"halo and all-gather forms disagree: max |diff| = {exchange_check}")
+        del other
+
     result = None
+    table = h_local
+    if world > 1:       # the local table of this rank, as the timed step sees it (a collective: every rank)
+        with torch.no_grad():
+            table = (sn_dist.halo_exchange(h_local, plan) if plan is not None
+                     else sn_dist.all_gather_rows(h_local, R["part"]))
     if rank == 0:
-        # --- roofline leg: device time of the dominant kernel, HIP events on its stream
-        lib.sngnn_profile_enable(1)
-        norms, mains, fins, empties = [], [], [], []
-        z, m, f, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
-        for _ in range(min(args.steps, 100)):
-            ops.aggregate_forward(graph, table, args.top_k, args.thr)
-            _lib.check(lib.sngnn_profile_last_forward(C.byref(z), C.byref(m), C.byref(f), C.byref(e0)),
-                       "profile")
-            norms.append(z.value)
-            mains.append(m.value)
-            fins.append(f.value)
-            empties.append(e0.value)
-        lib.sngnn_profile_enable(0)
-        # an event pair itself adds a few microseconds to an interval: the empty interval the
-        # library records behind the last launch measures it, and it comes off every figure
-        pair_ms = float(np.mean(empties))
-        norm_ms, main_ms, fin_ms = (max(float(np.mean(v)) - pair_ms, 0.0) for v in (norms, mains, fins))
+        # --- roofline leg: the dominant kernel's average launch duration, HIP events on its stream
+        # around batches of 20 back-to-back launches (nothing subtracted); beside it the interval
+        # of a single launch between two events (which carries the event pair's own ~4.5 us)
+        norm_ms, main_ms, fin_ms, _ = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 6, 20)
+        _, main_single_ms, _, empty_ms = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 30, 1)
         b_alg = algorithmic_bytes(e_prime, n, c)
         achieved = b_alg / (main_ms * 1e-3) / 1e9
-        traffic = rocprof_us = None
+        traffic = rocprof_us = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -279,16 +320,17 @@ def main():
                 traffic = prof.get(f"{args.workload}_k{args.top_k}")
                 # the same kernel's average duration in the committed rocprofv3 run of this command
                 rocprof_us = prof.get(f"{args.workload}_k{args.top_k}_kernel_us_rocprofv3")
+                traffic_src = prof.get("source")
             except Exception:
                 traffic = rocprof_us = None
-        main_raw_ms = float(np.mean(mains))
         layer = ("one SNGNN_Plus_Plus layer forward (adjacency branch + aggregation + blend)" if plus_plus
                  else "SNGNN_Plus aggregation forward")
         if world == 1:
             parallelism = "single GPU"
         else:
             parallelism = ("node-range partition + RCCL " +
-                           ("halo exchange (all-to-all-v of the referenced rows)" if plan is not None
+                           ("halo exchange (all-to-all-v of the referenced rows, received into the [own | halo] "
+                            "table; interior rows aggregated while it is in flight)" if plan is not None
                             else "all-gather of h") + (", w sharded by node range" if plus_plus else ""))
         result = {
             "metric": "similarity-aggregation edges/sec",
@@ -306,20 +348,23 @@ def main():
                        "parallelism": parallelism},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "k_agg_fwd", "kernel_ms": main_ms,
                          "normalize_kernel_ms": norm_ms, "finalize_kernel_ms": fin_ms,
-                         "timer": "HIP events on the launch stream, recorded inside the library around "
-                                  "each launch, minus the duration of an empty event interval "
-                                  f"({pair_ms * 1e3:.1f} us) recorded behind the last launch",
+                         "timer": "HIP events on the launch stream, recorded inside the library around batches "
+                                  "of 20 back-to-back launches of each kernel; interval / 20, nothing subtracted",
                          "algorithmic_bytes": b_alg,
-                         # the two other readings of the same kernel, for whoever prefers them: the
-                         # event interval as recorded (no event-pair overhead taken off), and the
-                         # committed rocprofv3 kernel-trace average (dispatch to completion)
-                         "kernel_ms_events_raw": main_raw_ms,
-                         "frac_events_raw": b_alg / (main_raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernel_ms_single_launch_events": main_single_ms,
+                         "frac_single_launch_events": b_alg / (main_single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "empty_event_interval_ms": empty_ms,
                          "kernel_ms_rocprofv3": None if rocprof_us is None else rocprof_us * 1e-3,
                          "frac_rocprofv3": None if rocprof_us is None
                          else b_alg / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            # the whole forward (every launch of a step and the gaps between them) against the same
+            # bytes: BASELINE.md's gate B_fwd / t_fwd
+            "roofline_step": {"bound": "hbm", "algorithmic_bytes": b_alg, "ms": ms_per_step,
+                              "achieved": b_alg / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if plus_plus:
             # the whole ++ layer against its own byte model ("++ branch extra")
@@ -328,16 +373,48 @@ def main():
                                         "achieved": b_pp / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                         "unit": "GB/s", "frac": b_pp / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "what": "adjacency branch + aggregation + blend over the wall time of a step"}
-        if world > 1:
-            full = (n_total - n) * c * 4
-            result["exchange"] = {"form": args.exchange, "locality": args.locality,
-                                  "rows_received_per_rank": halo_all / world,
-                                  "bytes_received_per_rank": halo_all / world * c * 4,
-                                  "full_allgather_bytes_per_rank": full,
-                                  "fraction_of_allgather": halo_all / world * c * 4 / max(full, 1)}
+    if world > 1:
+        full = (n * world - n) * c * 4
+        exch = {"form": args.exchange, "locality": args.locality,
+                "rows_received_per_rank": halo_all / world,
+                "bytes_received_per_rank": halo_all / world * c * 4,
+                "full_allgather_bytes_per_rank": full,
+                "fraction_of_allgather": halo_all / world * c * 4 / max(full, 1),
+                "interior_rows_fraction": None if plan is None else 1.0 - plan.n_boundary / max(n, 1),
+                "forms_agree_max_abs_diff": exchange_check}
+        if rank == 0:
+            result["exchange"] = exch
+        # the same job on a graph with locality (what a node-range partition is for): second line
+        if not strong and args.locality != 0.8:
+            R2 = build_rank(0.8, args.exchange)
+            dt2, e2, halo2, _ = measure(R2, args.steps, max(args.warmup // 2, 2))
+            if rank == 0:
+                result["locality_0.8"] = {"value": e2 / (dt2 / args.steps), "unit": "edges/s",
+                                          "ms_per_step": dt2 / args.steps * 1e3,
+                                          "rows_received_per_rank": halo2 / world,
+                                          "bytes_received_per_rank": halo2 / world * c * 4,
+                                          "interior_rows_fraction": None if R2["plan"] is None
+                                          else 1.0 - R2["plan"].n_boundary / max(n, 1)}
+            del R2
 
-    # --- extras on one GPU: training-mode forward+backward and a full epoch
+    # --- extras on one GPU
     if world == 1 and rank == 0 and not plus_plus:
+        # BASELINE.md's other config-4 cases, timed the same way inside this run
+        if not args.no_variants and args.workload == "arxiv" and args.channels is None:
+            variants = {}
+            for name, (vc, vthr) in {"C32_thr0.0": (32, 0.0), "C40_thr0.9": (40, 0.9)}.items():
+                vn, vcc, vei, _, vh, _ = make_rank_inputs(args.workload, 0, 1, args.seed, device, vc, args.scale)
+                vg = graph if vc == c else Graph(vei, vn, True, True)
+                vdt, _ = time_loop(lambda: ops.aggregate_forward(vg, vh, args.top_k, vthr)[0], 5,
+                                   min(args.steps, 50), torch.cuda.synchronize)
+                vms = vdt / min(args.steps, 50) * 1e3
+                _, vmain, _, _ = profile_forward(lib, _lib, ops, vg, vh, args.top_k, vthr, 4, 20)
+                vb = algorithmic_bytes(vg.num_edges, vn, vcc)
+                variants[name] = {"channels": vcc, "thr": vthr, "ms_per_step": vms,
+                                  "edges_per_s": vg.num_edges / (vms * 1e-3), "algorithmic_bytes": vb,
+                                  "kernel_ms": vmain, "frac": vb / (vmain * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "frac_step": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            result["variants"] = variants
         hg = h_local.clone().requires_grad_(True)
         gout = torch.randn_like(h_local)
         for _ in range(5):
@@ -350,38 +427,19 @@ def main():
             ops.aggregate(hg, graph, args.top_k, args.thr).backward(gout)
         torch.cuda.synchronize()
         result["fwd_bwd_ms"] = (time.perf_counter() - t0) / reps * 1e3
-        # --- backward roofline (SURVEY.md 8d's B_bwd over the device time of the backward's
-        # launches: torch events on the launch stream, empty-pair overhead taken off)
-        _, wsel, *_ = ops.aggregate_forward(graph, h_local, args.top_k, args.thr, save_for_backward=True)
-        n_sel = int((wsel > -3.0).sum())
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        bw, emp = [], []
-        for _ in range(30):
-            ev[0].record()
-            ops.aggregate_backward(graph, h_local, gout, wsel)
-            ev[1].record()
-            ev[2].record()
-            ev[2].synchronize()
-            bw.append(ev[0].elapsed_time(ev[1]))
-            emp.append(ev[1].elapsed_time(ev[2]))
-        bwd_ms = max(float(np.mean(bw[5:])) - float(np.mean(emp[5:])), 1e-6)
-        b_bwd = backward_bytes(e_prime, n_sel, n, c)
-        result["roofline_bwd"] = {"bound": "hbm", "kernels": "k_bwd_t + k_bwd_s (+ split-row sums)",
-                                  "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd,
-                                  "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        result["roofline_bwd"] = backward_roofline(ops, graph, h_local, gout, args.top_k, args.thr, e_prime, n, c)
         if not args.no_epoch:
             from sngnn_amd.train import epoch_time_ms
-            # reference-style eager loop (train.py:73-143) and the same epoch replayed
-            # from a HIP graph (sngnn_amd/train.py:GraphedEpoch)
+            # reference-style eager loop (train.py:73-143) and the same epoch replayed from a HIP
+            # graph (sngnn_amd/train.py:GraphedEpoch).  epoch_ms = the reference's THREE forwards
+            # (train, validation, test: train.py:134-143); epoch_ms_shared_eval: validation and
+            # test read ONE eval-mode forward (bit-identical metrics)
             result["epoch_ms_eager"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k,
                                                      args.thr, seed=args.seed)
-            # epoch_ms: validation and test read ONE eval-mode forward (train.py:92-117 run the
-            # same forward twice); epoch_ms_3fwd replays the reference's three forwards
-            result["epoch_ms_3fwd"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
-                                                    seed=args.seed, graphed=True, share_eval_forward=False)
             result["epoch_ms"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
-                                               seed=args.seed, graphed=True)
+                                               seed=args.seed, graphed=True, share_eval_forward=False)
+            result["epoch_ms_shared_eval"] = epoch_time_ms(args.workload, x, ei, n, c, args.top_k, args.thr,
+                                                           seed=args.seed, graphed=True)
         if not args.no_cpu_baseline:
             h_cpu, ei_cpu = h_local.cpu(), ei.cpu()
             res, cpu_dt = cpu_baseline(h_cpu, ei_cpu, args.top_k, args.thr, reps=3)
@@ -394,11 +452,73 @@ def main():
             # the benchmarked output is the checked output
             err = (out.cpu() - res["out"]).abs().max().item()
             result["max_abs_err_vs_oracle"] = err
+    if world == 1 and rank == 0 and plus_plus:
+        result.update(products_training(ops, graph, R, args, e_prime, n, c))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
+    """SURVEY.md 8d's B_bwd over the device time of the backward's launches: torch events on the
+    launch stream around batches of 10 back-to-back backward calls, nothing subtracted."""
+    _, wsel, *_ = ops.aggregate_forward(graph, h, top_k, thr, save_for_backward=True)
+    n_sel = int((wsel > -3.0).sum())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    bw = []
+    for _ in range(8):
+        ev[0].record()
+        for _ in range(10):
+            ops.aggregate_backward(graph, h, gout, wsel)
+        ev[1].record()
+        ev[1].synchronize()
+        bw.append(ev[0].elapsed_time(ev[1]) / 10)
+    bwd_ms = float(np.mean(bw[2:]))
+    b_bwd = backward_bytes(e_prime, n_sel, n, c)
+    return {"bound": "hbm", "kernels": "k_bwd_clear + k_bwd_t + k_bwd_t_fin + k_bwd_s (one backward call)",
+            "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd,
+            "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "timer": "torch events on the launch stream around batches of 10 backward calls"}
+
+
+def products_training(ops, graph, R, args, e_prime, n, c):
+    """Config 5's layer in TRAINING mode on one GPU: forward + backward of the ++ layer
+    (adjacency branch over the dense [C, N] w, aggregation, blend) and the Adam step over w -
+    models.py:95,130 make w a 460 MB table whose dense gradient and optimizer step SURVEY.md 7
+    flags as the dominant cost of a products epoch (train.py:86, :376)."""
+    h = R["h_local"].clone().requires_grad_(True)
+    w = torch.nn.Parameter(R["wt_local"].t())             # reference-shaped [C, N], column-major storage
+    bias = torch.nn.Parameter(R["w_bias"].clone())
+    beta = torch.nn.Parameter(R["beta"].clone())
+    gout = torch.randn(n, c, device=h.device)
+    opt = torch.optim.Adam([w, bias, beta], lr=0.01, weight_decay=5e-4, fused=True)
+
+    def fwd_bwd():
+        for p in (h, w, bias, beta):
+            p.grad = None
+        out = ops.blend(ops.adj_linear(w, bias, graph), ops.aggregate(h, graph, args.top_k, args.thr), beta)
+        out.backward(gout)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    fb_ms = timed(fwd_bwd, 5)
+    adam_ms = timed(opt.step, 5)
+    extra = {"fwd_bwd_ms": fb_ms, "adam_step_w_ms": adam_ms,
+             "adam_bytes": int(w.numel()) * 4 * 7,       # read w, grad, m, v; write w, m, v
+             "adam_gbs": int(w.numel()) * 4 * 7 / (adam_ms * 1e-3) / 1e9,
+             "train_step_ms": fb_ms + adam_ms,
+             "roofline_bwd": backward_roofline(ops, graph, R["h_local"], gout, args.top_k, args.thr, e_prime, n, c)}
+    return extra
 
 
 if __name__ == "__main__":

@@ -184,6 +184,20 @@ int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const flo
                                float *wsel, float *inv_norm, int32_t *sel_src, float *sel_w,
                                void *workspace, void *stream);
 int sngnn_filter_enable(int mode);
+/* whether sngnn_agg_forward would use filter rows for this call (a caller that prepares the
+ * rows itself writes them only then) */
+int sngnn_filter_wanted(const sngnn_graph_t *g, int C, int top_k, float thr);
+/*
+ * sngnn_agg_forward_prepared restricted to the target rows i with row_flag[i] == row_want
+ * (row_flag: dev u8 [N]); the other rows of out / wsel / inv_norm are not touched.  Two calls
+ * with complementary flags equal one unrestricted call, bit for bit.  One rank of a node-range
+ * partition aggregates its INTERIOR rows (all sources local) while the halo rows its other
+ * rows need are still in flight (sngnn_amd/dist.py).  No reference counterpart.
+ */
+int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *nrm,
+                           const void *filt, int C, int top_k, float thr,
+                           const uint8_t *row_flag, int row_want, float *out, float *wsel,
+                           float *inv_norm, void *workspace, void *stream);
 /* measurement aid: knob 0 = row classes the main forward kernel runs (bit 0 split-row tasks,
  * 1 wave rows, 2 small rows; default 7 - anything else leaves the output incomplete) */
 int sngnn_tuning_set(int which, int value);
@@ -270,6 +284,10 @@ int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, flo
  * of the normalisation pass, of the main kernel and of what follows it on the caller's
  * stream (the split-row finalize launches), and of an EMPTY interval between two events -
  * what an event pair itself adds to each of the three figures on this stack.
+ * sngnn_profile_enable(reps) with reps > 1: every launch of the forward is issued reps times
+ * back to back between its two events (the launches are idempotent) and the three figures are
+ * the intervals divided by reps - the average launch duration with the event pair's own cost
+ * spread over reps launches.
  */
 int sngnn_profile_enable(int on);
 int sngnn_profile_last_forward(float *norm_ms, float *main_ms, float *fin_ms, float *empty_ms);

@@ -35,9 +35,11 @@ class _Shard:
             self.graph = GLOBAL_CACHE.get(edge_index, part.n_total, add_loops, remove_loops,
                                           row_range=(part.row_begin, part.row_end))
 
-    def table(self, rows_local: torch.Tensor) -> torch.Tensor:
+    def table(self, rows_local: torch.Tensor, table: torch.Tensor = None) -> torch.Tensor:
+        """The feature table the local graph's columns address.  ``table``: the preallocated
+        [own | halo] buffer whose head ``rows_local`` already is (halo form)."""
         if self.plan is not None:
-            return sn_dist.halo_exchange(rows_local, self.plan)
+            return sn_dist.halo_exchange(rows_local, self.plan, table)
         return sn_dist.all_gather_rows(rows_local, self.part)
 
 
@@ -69,17 +71,24 @@ def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remov
     return shard.graph, shard
 
 
-def _lin_aligned(x: torch.Tensor, lin: nn.Linear):
+def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None):
     """``h = lin(x)`` with the channel count rounded up to a multiple of 4 by zero
-    weights (returns h and the true width).  Rows of 4k floats are 16-byte aligned, so
-    the kernels read them with 16-byte lane loads (2.5x faster than the dword path at
-    C = 47); zero channels change neither a cosine nor a weighted sum, and their (zero)
-    gradients are dropped (ops._Linear: persistent padded buffers, no per-forward cat)."""
+    weights (returns h, the true width and the rank's feature table or None).  Rows of 4k
+    floats are 16-byte aligned, so the kernels read them with 16-byte lane loads (2.5x faster
+    than the dword path at C = 47); zero channels change neither a cosine nor a weighted sum,
+    and their (zero) gradients are dropped (ops._Linear: persistent padded buffers, no
+    per-forward cat).  Under a halo partition ``lin`` writes straight into the head of a fresh
+    [own | halo] table (no copy, no concatenation later)."""
     c = lin.out_features
     cp = (c + 3) // 4 * 4
-    if cp == c or c < 16 or not x.is_cuda:
-        return ops.linear(x, lin), c
-    return ops._Linear.apply(x, lin.weight, lin.bias, cp), c
+    pad = None if (cp == c or c < 16 or not x.is_cuda) else cp
+    if shard is None or shard.plan is None or not x.is_cuda or x.dtype != torch.float32:
+        if pad is None:
+            return ops.linear(x, lin), c, None
+        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None), c, None
+    table = sn_dist.new_table(shard.plan, pad or c, x)
+    head = table[:shard.plan.n_local]
+    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head)), c, table
 
 
 def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
@@ -89,12 +98,15 @@ def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
     return out if out.size(1) == c else out[:, :c]
 
 
-def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float) -> torch.Tensor:
-    """Fused aggregation of the local rows; under a node-range partition the feature rows
-    the rank's in-edges reference are exchanged first (RCCL), see sngnn_amd/dist.py."""
-    if shard is not None:
-        h = shard.table(h)
-    return ops.aggregate(h, graph, top_k, thr)
+def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float, table=None) -> torch.Tensor:
+    """Fused aggregation of the local rows; under a node-range partition the feature rows the
+    rank's in-edges reference are exchanged first (RCCL) - in the halo form overlapped with the
+    aggregation of the rows that need none of them (sngnn_amd/dist.py:halo_aggregate)."""
+    if shard is None:
+        return ops.aggregate(h, graph, top_k, thr)
+    if shard.plan is not None:
+        return sn_dist.halo_aggregate(h, shard.plan, graph, top_k, thr, table)
+    return ops.aggregate(shard.table(h), graph, top_k, thr)
 
 
 class SNConv(nn.Module):
@@ -119,8 +131,8 @@ class SNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, False)
-        h, c = _lin_aligned(x, self.lin)
-        out = _true_width(_aggregate(h, graph, shard, None, 0.0), c)
+        h, c, table = _lin_aligned(x, self.lin, shard)
+        out = _true_width(_aggregate(h, graph, shard, None, 0.0, table), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -144,9 +156,9 @@ class AGNNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, LOOPS_REPLACE)
-        h, c = _lin_aligned(x, self.lin)
+        h, c, table = _lin_aligned(x, self.lin, shard)
         if shard is not None:
-            h = shard.table(h)
+            h = shard.table(h, table)
         return _true_width(ops.attention(h, graph), c)
 
 
@@ -177,8 +189,8 @@ class SNConv_plus(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h, c = _lin_aligned(x, self.lin)
-        out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr)), c)
+        h, c, table = _lin_aligned(x, self.lin, shard)
+        out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -300,7 +312,7 @@ class SNConv_plus_plus(nn.Module):
         if part is None and self.w.shard_range is not None:
             raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h, c = _lin_aligned(x, self.lin)
+        h, c, table = _lin_aligned(x, self.lin, shard)
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:
@@ -318,15 +330,15 @@ class SNConv_plus_plus(nn.Module):
                     raise ValueError("w was sharded for a different node range")
                 shard_f = _shard_for(flipped, part, True, bool(self.is_remove_self_loops))
                 wt = self.w.weight.t()
-                table = shard_f.table(wt if wt.is_contiguous() else wt.contiguous())
-                out_0 = ops.gather_sum(table, self.w.bias, shard_f.graph)
+                w_table = shard_f.table(wt if wt.is_contiguous() else wt.contiguous())
+                out_0 = ops.gather_sum(w_table, self.w.bias, shard_f.graph)
             else:
                 # w.weight replicated ([C, N_total]): its gradient is each rank's partial sum,
                 # all-reduced with the other parameters (dist.allreduce_grads)
                 graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
                                              row_range=(part.row_begin, part.row_end))
                 out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
-        out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr)), c)
+        out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table), c)
         out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias

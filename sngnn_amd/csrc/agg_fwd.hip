@@ -10,6 +10,7 @@ using namespace sngnn;
 // microseconds on this stack); sngnn_profile_last_forward reports it so that the caller can
 // take it off the three kernel figures.
 static bool g_prof_on = false;
+namespace sngnn { int g_prof_reps = 1; }
 static hipEvent_t g_prof_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
 extern "C" int sngnn_profile_enable(int on)
@@ -17,6 +18,7 @@ extern "C" int sngnn_profile_enable(int on)
     if (on && !g_prof_ev[0])
         for (auto &e : g_prof_ev) SN_HIP(hipEventCreate(&e));
     g_prof_on = on != 0;
+    g_prof_reps = on > 1 ? on : 1;
     return SNGNN_OK;
 }
 
@@ -29,6 +31,9 @@ extern "C" int sngnn_profile_last_forward(float *norm_ms, float *main_ms, float 
     SN_HIP(hipEventElapsedTime(main_ms, g_prof_ev[1], g_prof_ev[2]));
     SN_HIP(hipEventElapsedTime(fin_ms, g_prof_ev[2], g_prof_ev[3]));
     SN_HIP(hipEventElapsedTime(empty_ms, g_prof_ev[3], g_prof_ev[4]));
+    *norm_ms /= (float)g_prof_reps;
+    *main_ms /= (float)g_prof_reps;
+    *fin_ms /= (float)g_prof_reps;
     return SNGNN_OK;
 }
 
@@ -135,11 +140,12 @@ extern "C" int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *
 // everything after the unit rows exist
 static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const float *n, const float *nrm,
                               const void *filt, int C, int top_k, float thr, float *out, float *wsel, float *inv_norm,
-                              int32_t *sel_src, float *sel_w, void *scratch, hipEvent_t *ev, hipStream_t st)
+                              int32_t *sel_src, float *sel_w, void *scratch, hipEvent_t *ev, hipStream_t st,
+                              const uint8_t *row_flag = nullptr, int row_want = 0)
 {
     if (top_k > (1 << 20)) top_k = 1 << 20;     // more than any row can use
 
-    if (sel_src && top_k > 0) {
+    if (sel_src && top_k > 0 && row_flag == nullptr) {
         // (a kernel, not hipMemsetAsync: inside a captured HIP graph a memset node was seen to
         // race with the kernel nodes behind it on this stack - see agg_bwd_impl.h)
         const int64_t nw = g->N * (int64_t)top_k;
@@ -150,6 +156,7 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
     a.filt = (const uint4 *)filt;
     a.role_mask = g_role_mask;
+    a.row_flag = row_flag; a.row_want = row_want;
     // row order: calls that stream the small rows (deg <= SMALL_T <= top_k, or no top_k) take the
     // bucket order, calls that rank inside them the exact degree order (graph.hip 5b)
     const bool stream_small = top_k < 0 || top_k >= SMALL_T;
@@ -235,7 +242,8 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     void *filt = use_filter(g, C, top_k, thr) ? ws_filter(workspace, g->Ntot, C) : nullptr;
     hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
-    if (int rc = normalize_dispatch(cfg, h, g->Ntot, C, n, nrm, filt, st)) return rc;
+    for (int rep = 0; rep < (ev ? g_prof_reps : 1); ++rep)
+        if (int rc = normalize_dispatch(cfg, h, g->Ntot, C, n, nrm, filt, st)) return rc;
     return forward_normalized(g, cfg, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
                               ev ? ev + 1 : nullptr, st);
 }
@@ -270,6 +278,28 @@ extern "C" int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n
     }
     return forward_normalized(g, cfg, n, nrm, f, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
                               ev ? ev + 1 : nullptr, st);
+}
+
+extern "C" int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *nrm, const void *filt,
+                                      int C, int top_k, float thr, const uint8_t *row_flag, int row_want,
+                                      float *out, float *wsel, float *inv_norm, void *workspace, void *stream)
+{
+    RowCfg cfg;
+    if (int rc = check_forward_args(g, n, C, top_k, out, nullptr, nullptr, cfg)) return rc;
+    if (g->N == 0) return SNGNN_OK;
+    SN_REQUIRE(nrm != nullptr && row_flag != nullptr && workspace != nullptr, SNGNN_EINVAL, "nrm/row_flag/workspace is NULL");
+    SN_REQUIRE(filt == nullptr || filter_row_bytes(C) > 0, SNGNN_EINVAL,
+               "no filter rows for this C (sngnn_filter_row_bytes(C) == 0)");
+    SN_REQUIRE(((uintptr_t)filt % 16) == 0, SNGNN_EINVAL, "filt must be 16-byte aligned");
+    void *scratch = (char *)workspace + fwd_table_bytes(g->Ntot, C);
+    // (the caller decides whether filter rows exist - sngnn_filter_wanted - and passes them or NULL)
+    return forward_normalized(g, cfg, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, nullptr, nullptr, scratch,
+                              nullptr, (hipStream_t)stream, row_flag, row_want);
+}
+
+extern "C" int sngnn_filter_wanted(const sngnn_graph_t *g, int C, int top_k, float thr)
+{
+    return g != nullptr && use_filter(g, C, top_k, thr) ? 1 : 0;
 }
 
 extern "C" int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float *n, const float *nrm, int C,

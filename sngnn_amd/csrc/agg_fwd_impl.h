@@ -66,6 +66,12 @@ struct FwdArgs {
     int lowbits;                    // bits needed for a row-local edge index
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
     int role_mask;              // measurement aid (sngnn_tuning_set): bit 0 tasks, 1 wave rows, 2 small rows
+    // row filter (sngnn_agg_forward_rows): only the target rows i with row_flag[i] == row_want are
+    // computed and written; nullptr = all rows.  (A rank's interior rows - all sources local - run
+    // while the halo rows of its boundary rows are still in flight, sngnn_amd/dist.py.)
+    const uint8_t *row_flag;
+    int row_want;
+    __device__ __forceinline__ bool skip_row(int i) const { return row_flag != nullptr && row_flag[i] != row_want; }
 };
 
 #ifndef SNGNN_FWD_WAVES
@@ -370,7 +376,9 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
 
     auto load_desc = [&](int st) -> int4 {
         const int slot = a.n_med_end + st * RPW + gid;
-        return (st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
+        int4 d = (st < nsets && slot < a.N) ? a.rdesc[slot] : make_int4(0, 0, 0, -1);
+        if (a.row_flag != nullptr && d.w >= 0 && a.skip_row(d.x)) d = make_int4(0, 0, 0, -1);   // not this pass's row
+        return d;
     };
     // lane l fetches column ids q = l + 64 m of the set: row q / SMALL_T, edge q % SMALL_T
     auto load_cols = [&](const int4 d, int (&c)[CPL]) {
@@ -409,7 +417,8 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
-        small_rows_set<VEC, G, R>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+        if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull)
+            small_rows_set<VEC, G, R>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
         store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
@@ -562,6 +571,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     const int slot = a.n_split + item;
     const int4 d = a.rdesc[slot];
     const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (wave-uniform)
     const int self = i + a.row_off;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
@@ -663,6 +673,7 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
     const int p = a.task_slot[tq], c = a.task_chunk[tq];
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (wave-uniform)
     const int self = i + a.row_off;
     const int e0 = c * CHUNK, e1 = min(deg, e0 + CHUNK);
     const bool emit = a.sel_src != nullptr && a.k >= 0;
@@ -771,6 +782,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
     const int gid = lane / G, lg = lane % G;
     const int p = blockIdx.x;
     const int i = a.rperm[p];
+    if (a.skip_row(i)) return;                              // (workgroup-uniform)
     const int rs = a.rowptr[i];
     const int deg = a.rowptr[i + 1] - rs;
     const bool emit = a.sel_src != nullptr && a.k >= 0;
@@ -906,6 +918,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     const int gid = lane / G, lg = lane % G;
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (workgroup-uniform)
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
@@ -1046,6 +1059,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     const int gid = lane / G, lg = lane % G;
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (wave-uniform)
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
     if (a.k < 0) {
         // (rows of at most 16 tasks come here: their partial rows are loaded together)
@@ -1201,16 +1215,21 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
     return SNGNN_OK;
 }
 
+// profiling (sngnn_profile_enable(reps)): every launch is issued `reps` times back to back
+// between its two events, so the event pair's own cost is spread over reps launches
+extern int g_prof_reps;
+
 template <int VEC, int G, int R>
 int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
+    const int reps = ev ? std::max(g_prof_reps, 1) : 1;
     constexpr int RPW = 64 / G;
     const int n_small = a.N - a.n_med_end;
     const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
     // persistent grid: what the chip holds at the kernel's occupancy, or less
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
-    if (grid > 0) {
+    for (int rep = 0; rep < reps && grid > 0; ++rep) {
         if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
             if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true><<<grid, BLOCK, 0, st>>>(a);
             else k_agg_fwd<VEC, G, R, false><<<grid, BLOCK, 0, st>>>(a);
@@ -1219,7 +1238,8 @@ int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStrea
         }
     }
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
-    if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;
+    for (int rep = 0; rep < reps; ++rep)
+        if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;
     if (ev) {
         SN_HIP(hipEventRecord(ev[2], st));
         SN_HIP(hipEventRecord(ev[3], st));       // empty interval: the cost of an event pair

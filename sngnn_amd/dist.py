@@ -208,6 +208,12 @@ class HaloPlan:
         src_l = torch.where(own, src_g - r0, self.n_local + torch.searchsorted(need, src_g))
         self.edge_index = torch.stack([src_l, dst[mine] - r0]).contiguous()
         self.halo_ids = need
+        # rows with at least one halo source ("boundary"): 1; rows whose sources are all local
+        # ("interior"): 0 - the interior rows are aggregated while the halo is in flight
+        flag = torch.zeros(self.n_local, dtype=torch.uint8, device=dev)
+        flag[(dst[mine] - r0)[~own]] = 1
+        self.row_boundary = flag
+        self.n_boundary = int(flag.sum())
 
     @property
     def table_rows(self) -> int:
@@ -218,35 +224,147 @@ class HaloPlan:
         return self.n_halo * channels * 4
 
 
+class _Pending:
+    """An exchange in flight: ``wait()`` makes the current stream wait for it."""
+
+    def __init__(self, work=None):
+        self._work = work
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+
+def new_table(plan: HaloPlan, channels: int, like: torch.Tensor) -> torch.Tensor:
+    """An uninitialised [own | halo] feature table for one forward (the caching allocator hands
+    it out without any device work; a layer's ``lin`` writes its rows straight into the head)."""
+    return like.new_empty((plan.table_rows, channels))
+
+
+def start_halo_exchange(table: torch.Tensor, plan: HaloPlan) -> _Pending:
+    """Send the own rows the peers asked for and receive this rank's halo rows STRAIGHT INTO
+    ``table[n_local:]``; the own rows must already be in ``table[:n_local]``.  RCCL: one
+    ``all_to_all_single`` issued asynchronously - kernels launched before ``wait()`` overlap it.
+    (gloo: the point-to-point form, complete on return.)"""
+    part = plan.part
+    own = table[:plan.n_local]
+    send = own.index_select(0, plan.send_idx)
+    halo = table[plan.n_local:]
+    if _is_gloo(table, part.group):
+        if plan.n_halo or send.size(0):
+            halo.copy_(_all_to_all_rows(send, plan.send_counts, plan.recv_counts, part))
+        return _Pending()
+    work = dist.all_to_all_single(halo, send, output_split_sizes=plan.recv_counts,
+                                  input_split_sizes=plan.send_counts, group=part.group, async_op=True)
+    return _Pending(work)
+
+
+def return_halo_gradients(grad_table: torch.Tensor, plan: HaloPlan) -> torch.Tensor:
+    """Transpose of the exchange: the gradient rows of the halo go back to their owners and are
+    added to ``grad_table[:n_local]`` IN PLACE, peer by peer in rank order (inside one peer's
+    block the rows are distinct: deterministic).  Returns that head view."""
+    g_own = grad_table[:plan.n_local]
+    back = _all_to_all_rows(grad_table[plan.n_local:].contiguous(), plan.recv_counts, plan.send_counts, plan.part)
+    off = 0
+    for n in plan.send_counts:
+        if n:
+            g_own.index_add_(0, plan.send_idx[off:off + n], back[off:off + n])
+        off += n
+    return g_own
+
+
 class _HaloExchange(torch.autograd.Function):
+    """[n_local, C] -> the [own | halo] table.  ``table`` (a ``_TableRef``) may already hold the
+    own rows (``rows_local`` IS its head: the layer's ``lin`` wrote there) - nothing is copied
+    then; otherwise they are copied in.  No concatenation either way."""
+
     @staticmethod
-    def forward(ctx, rows_local, plan: HaloPlan):
+    def forward(ctx, rows_local, table_ref, plan: HaloPlan):
         ctx.plan = plan
-        rows_local = rows_local.contiguous()
-        send = rows_local.index_select(0, plan.send_idx)
-        halo = _all_to_all_rows(send, plan.send_counts, plan.recv_counts, plan.part)
-        return torch.cat([rows_local, halo], dim=0)
+        table = table_ref.t
+        if rows_local.data_ptr() != table.data_ptr():
+            table[:plan.n_local].copy_(rows_local)
+        start_halo_exchange(table, plan).wait()
+        return table
 
     @staticmethod
     def backward(ctx, grad_table):
-        plan = ctx.plan
-        grad_table = grad_table.contiguous()
-        g_own = grad_table[:plan.n_local].clone()
-        back = _all_to_all_rows(grad_table[plan.n_local:], plan.recv_counts, plan.send_counts, plan.part)
-        # peers' contributions in rank order; inside one peer's block the rows are distinct
-        off = 0
-        for n in plan.send_counts:
-            if n:
-                g_own.index_add_(0, plan.send_idx[off:off + n], back[off:off + n])
-            off += n
-        return g_own, None
+        # (grad_table comes fresh out of the aggregation's backward: updated in place)
+        return return_halo_gradients(grad_table.contiguous(), ctx.plan), None, None
 
 
-def halo_exchange(rows_local: torch.Tensor, plan: HaloPlan) -> torch.Tensor:
-    """Differentiable: [n_local, C] -> [n_local + n_halo, C] (own rows, then the halo)."""
+class _TableRef:
+    """Holder of a table tensor (kept out of autograd's sight as an input)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
+def halo_exchange(rows_local: torch.Tensor, plan: HaloPlan, table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable: [n_local, C] -> [n_local + n_halo, C] (own rows, then the halo).
+    ``table``: the preallocated table whose head ``rows_local`` already is (``new_table``)."""
     if rows_local.size(0) != plan.n_local:
         raise ValueError(f"local shard has {rows_local.size(0)} rows, plan says {plan.n_local}")
-    return _HaloExchange.apply(rows_local, plan)
+    if table is None:
+        table = new_table(plan, rows_local.size(1), rows_local)
+    return _HaloExchange.apply(rows_local.contiguous(), _TableRef(table), plan)
+
+
+class _HaloAggregate(torch.autograd.Function):
+    """Exchange + fused aggregation of one rank, overlapped: the rank's INTERIOR rows (every
+    source local) are normalised and aggregated while the halo rows are on the wire, the
+    BOUNDARY rows after they have arrived - two row-filtered launches of the same kernels on the
+    same graph (``sngnn_agg_forward_rows``), bit-identical to one unfiltered call.  Backward: the
+    aggregation's backward on the whole local table, then the transpose of the exchange."""
+
+    @staticmethod
+    def forward(ctx, rows_local, table_ref, plan: HaloPlan, graph, top_k, thr):
+        from . import ops
+        table = table_ref.t
+        n_loc, c = plan.n_local, table.size(1)
+        if rows_local.data_ptr() != table.data_ptr():
+            table[:n_loc].copy_(rows_local)
+        pending = start_halo_exchange(table, plan)
+        need_grad = ctx.needs_input_grad[0]
+        dev = table.device
+        unit = torch.empty_like(table)
+        nrm = torch.empty(table.size(0), dtype=torch.float32, device=dev)
+        fb = ops.filter_row_bytes(c) if ops.filter_wanted(graph, c, top_k, thr) else 0
+        filt = torch.empty((table.size(0), fb), dtype=torch.uint8, device=dev) if fb else None
+        out = torch.empty((n_loc, c), dtype=torch.float32, device=dev)
+        wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=dev) if need_grad else None
+        inv = torch.empty(n_loc, dtype=torch.float32, device=dev) if need_grad else None
+        ops.normalize_rows_into(table[:n_loc], unit[:n_loc], nrm[:n_loc], None if filt is None else filt[:n_loc])
+        if plan.n_boundary < n_loc:
+            ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 0, out, wsel, inv)
+        pending.wait()
+        if plan.n_halo:
+            ops.normalize_rows_into(table[n_loc:], unit[n_loc:], nrm[n_loc:], None if filt is None else filt[n_loc:])
+        if plan.n_boundary:
+            ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 1, out, wsel, inv)
+        if need_grad:
+            ctx.plan, ctx.graph = plan, graph
+            ctx.save_for_backward(table, wsel)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import ops
+        table, wsel = ctx.saved_tensors
+        grad_table = ops.aggregate_backward(ctx.graph, table, grad_out.contiguous(), wsel)
+        return return_halo_gradients(grad_table, ctx.plan), None, None, None, None, None
+
+
+def halo_aggregate(rows_local: torch.Tensor, plan: HaloPlan, graph, top_k, thr: float,
+                   table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One rank's conv after ``lin``: exchange the halo, aggregate the owned rows - the interior
+    rows while the halo is in flight.  ``table``: see ``halo_exchange``.  [n_local, C] -> [n_local, C]."""
+    if rows_local.size(0) != plan.n_local:
+        raise ValueError(f"local shard has {rows_local.size(0)} rows, plan says {plan.n_local}")
+    if table is None:
+        table = new_table(plan, rows_local.size(1), rows_local)
+    return _HaloAggregate.apply(rows_local.contiguous(), _TableRef(table), plan, graph, top_k, float(thr))
 
 
 # ---------------------------------------------------------------------------

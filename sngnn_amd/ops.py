@@ -93,6 +93,48 @@ def normalize_rows_filter(h: torch.Tensor):
     return n, nrm, filt
 
 
+def filter_wanted(graph: Graph, c: int, top_k: Optional[int], thr: float) -> bool:
+    """``sngnn_filter_wanted``: whether a forward with these arguments uses filter rows."""
+    k = -1 if top_k is None else int(top_k)
+    return bool(_lib.load().sngnn_filter_wanted(graph.handle, int(c), k, float(thr)))
+
+
+def normalize_rows_into(h: torch.Tensor, n: torch.Tensor, nrm: torch.Tensor, filt: Optional[torch.Tensor]) -> None:
+    """``sngnn_normalize_rows_filter`` into caller-owned (slices of) buffers: ``n`` [rows, C] like
+    ``h``, ``nrm`` [rows], ``filt`` uint8 [rows, filter_row_bytes(C)] or None."""
+    rows, c = h.shape
+    if rows == 0:
+        return
+    if not (h.is_contiguous() and n.is_contiguous() and nrm.is_contiguous() and (filt is None or filt.is_contiguous())):
+        raise ValueError("normalize_rows_into needs contiguous row blocks")
+    if n.shape != h.shape or nrm.numel() != rows or (filt is not None and filt.size(0) != rows):
+        raise ValueError("normalize_rows_into: buffer shapes do not match h")
+    with torch.cuda.device(h.device):
+        rc = _lib.load().sngnn_normalize_rows_filter(h.data_ptr(), rows, c, n.data_ptr(), nrm.data_ptr(),
+                                                     _lib.ptr(filt), _stream(h.device))
+    _lib.check(rc, "sngnn_normalize_rows_filter")
+
+
+def aggregate_forward_rows(graph: Graph, n: torch.Tensor, nrm: torch.Tensor, filt: Optional[torch.Tensor],
+                           top_k: Optional[int], thr: float, row_flag: torch.Tensor, want: int,
+                           out: torch.Tensor, wsel: Optional[torch.Tensor] = None,
+                           inv: Optional[torch.Tensor] = None) -> None:
+    """``sngnn_agg_forward_rows``: the aggregation of the target rows whose ``row_flag`` (uint8 [N])
+    equals ``want``, written into the caller's ``out`` / ``wsel`` / ``inv``; other rows untouched."""
+    c = n.size(1)
+    k = -1 if top_k is None else int(top_k)
+    if row_flag.dtype != torch.uint8 or row_flag.numel() != graph.num_nodes or not row_flag.is_contiguous():
+        raise ValueError("row_flag must be a contiguous uint8 tensor with one entry per owned row")
+    if n.size(0) != graph.num_total_nodes or out.shape != (graph.num_nodes, c):
+        raise ValueError("n must hold one row per feature-table row and out one per owned row")
+    ws = graph.workspace(c)
+    with torch.cuda.device(n.device):
+        rc = _lib.load().sngnn_agg_forward_rows(graph.handle, n.data_ptr(), nrm.data_ptr(), _lib.ptr(filt), c, k,
+                                                float(thr), row_flag.data_ptr(), int(want), out.data_ptr(),
+                                                _lib.ptr(wsel), _lib.ptr(inv), ws.data_ptr(), _stream(n.device))
+    _lib.check(rc, "sngnn_agg_forward_rows")
+
+
 def aggregate_forward_normalized(graph: Graph, n: torch.Tensor, nrm: torch.Tensor,
                                  top_k: Optional[int], thr: float, *, want_selection: bool = False,
                                  filt: Optional[torch.Tensor] = None):
@@ -371,6 +413,13 @@ def _workspace(key, nbytes, device):
     return ws
 
 
+class OutBuffer:
+    """Holder of a preallocated result tensor for ``_Linear`` (``.t``)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
 class _Linear(torch.autograd.Function):
     """``self.lin(x)`` (models.py:121,237,324): hand-written streaming MFMA forward for
     narrow layers on big graphs (rocBLAS otherwise), hand-written weight
@@ -378,11 +427,13 @@ class _Linear(torch.autograd.Function):
     handles poorly), grad_x through rocBLAS only when x needs it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad_to=None):
+    def forward(ctx, x, weight, bias, pad_to=None, out=None):
         """``pad_to``: produce [N, pad_to] with zero channels behind the layer's own (16-byte
         rows for the aggregation kernels).  The padded weight / bias live in two persistent
         buffers attached to the weight and are refreshed by two small copies - no
-        concatenation, no allocation and no autograd node per forward."""
+        concatenation, no allocation and no autograd node per forward.
+        ``out``: ``OutBuffer`` around a contiguous [N, C] tensor to write into (the head of a rank's
+        [own | halo] feature table, sngnn_amd/dist.py) - that tensor is returned as the result."""
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         n, f = x.shape
@@ -403,11 +454,20 @@ class _Linear(torch.autograd.Function):
         # 169 343 x 128 -> 40).  A wide layer, a tiny graph or a wide INPUT (the first layer of the
         # real datasets: F = 932 .. 2 325) goes to the BLAS, which tiles the contraction
         # (7 600 x 932 -> 32: 18.7 us against 36.7; 2 277 x 2 325 -> 32: 19 us against 83).
+        if out is not None:
+            out = out.t          # (a holder object, not a tensor argument: autograd must see the result
+            #                       as this node's fresh output, not as an input modified in place)
+            if out.shape != (n, c) or not out.is_contiguous() or out.dtype != torch.float32:
+                raise ValueError("out must be a contiguous float32 [N, C] buffer")
         if c > 64 or n < 4096 or f > 128:
-            return torch.nn.functional.linear(x, weight, bias)
+            if out is None:
+                return torch.nn.functional.linear(x, weight, bias)
+            if bias is None:
+                return torch.mm(x, weight.t(), out=out)
+            return torch.addmm(bias, x, weight.t(), out=out)
         xc, wc = x.contiguous(), weight.contiguous()
         bc = None if bias is None else bias.contiguous()
-        h = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        h = torch.empty((n, c), dtype=torch.float32, device=x.device) if out is None else out
         with torch.cuda.device(x.device):
             rc = _lib.load().sngnn_linear_forward(xc.data_ptr(), wc.data_ptr(), _lib.ptr(bc), n, f, c,
                                                   h.data_ptr(), _stream(x.device))
@@ -446,14 +506,14 @@ class _Linear(torch.autograd.Function):
             _lib.check(rc, "sngnn_linear_wgrad")
             gw = gw[:ctx.c]
             gb = None if gb is None else gb[:ctx.c]
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     """Apply ``lin`` with the hand-written weight gradient (fp32 GPU tensors), or
     plain ``lin(x)`` for anything else."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32:
-        return _Linear.apply(x, lin.weight, lin.bias, None)
+        return _Linear.apply(x, lin.weight, lin.bias, None, None)
     return lin(x)
 
 

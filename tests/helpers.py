@@ -149,7 +149,7 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
         rem = bool(cr.is_remove_self_loops)
         with torch.no_grad():
             h_r = cr.lin(cap_r[li])
-            h_g, _ = CV._lin_aligned(cap_g[li], cg.lin)
+            h_g = CV._lin_aligned(cap_g[li], cg.lin)[0]
         res = O.aggregate_reference(h_r, data_cpu.edge_index, add_loops=True, remove_loops=rem,
                                     top_k=int(k), thr=float(cr.thr))
         g = GLOBAL_CACHE.get(data_gpu.edge_index, h_g.size(0), True, rem)

@@ -91,3 +91,32 @@ def test_filter_changes_nothing(cuda, n, e, c, hubs, k, thr, kind):
     for a, b in ((out_p, res[0][0]), (out_n, res[0][0]), (src_p, res[0][2]), (src_n, res[0][2]),
                  (w_p, res[0][3]), (w_n, res[0][3])):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("c,k,thr", [(40, 16, 0.0), (40, 4, 0.5), (7, 3, 0.0), (48, None, 0.0), (64, 16, 0.9)])
+def test_row_filtered_passes_equal_one_pass(cuda, c, k, thr):
+    """sngnn_agg_forward_rows: two launches with complementary row flags write exactly what one
+    unrestricted forward writes - out, the saved selection and the inverse norms (one rank's
+    interior / boundary passes, sngnn_amd/dist.py:halo_aggregate)."""
+    from sngnn_amd import ops
+    from sngnn_amd.graph import Graph
+    n = 2500
+    ei = random_graph(n, 50000, seed=c, hubs=((0, 2499), (3, 700), (9, 300), (11, 140))).to(cuda)
+    h = _rows(n, c, 5 + c, "normal").to(cuda)
+    g = Graph(ei, n, True, True)
+    out, wsel, inv, _, _ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+    gen = torch.Generator().manual_seed(2)
+    flag = (torch.rand(n, generator=gen) < 0.4).to(torch.uint8).to(cuda)
+    flag[0] = 1                                   # the biggest hub on one side, the next on the other
+    flag[3] = 0
+    un, nrm, filt = ops.normalize_rows_filter(h)
+    if filt is not None and not ops.filter_wanted(g, c, k, thr):
+        filt = None
+    out2 = torch.full_like(out, float("nan"))
+    wsel2 = torch.full_like(wsel, float("nan"))
+    inv2 = torch.full_like(inv, float("nan"))
+    for want in (0, 1):
+        ops.aggregate_forward_rows(g, un, nrm, filt, k, thr, flag, want, out2, wsel2, inv2)
+        if want == 0:                             # the other side's rows are untouched so far
+            assert torch.isnan(out2[flag.bool()]).all() and not torch.isnan(out2[~flag.bool()]).any()
+    assert torch.equal(out2, out) and torch.equal(wsel2, wsel) and torch.equal(inv2, inv)

@@ -58,7 +58,7 @@ def test_plus_plus_layer_at_products_size(cuda):
     graph = GLOBAL_CACHE.get(ei, N, True, True)
     with torch.no_grad():
         from sngnn_amd.conv import _lin_aligned
-        h_pad, _ = _lin_aligned(x, conv.lin)          # the layer's own ``lin`` (same bits: a 1-ulp change
+        h_pad = _lin_aligned(x, conv.lin)[0]          # the layer's own ``lin`` (same bits: a 1-ulp change
         h = h_pad[:, :CLASSES]                        # of h flips near-ties somewhere among 2.4 M rows)
         out_1 = ops.aggregate_forward(graph, h_pad, K, THR)[0][:, :CLASSES]
         out_0 = ops.adj_linear(conv.w.weight, conv.w.bias, graph)
