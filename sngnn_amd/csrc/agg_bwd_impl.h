@@ -77,7 +77,9 @@ __device__ __forceinline__ void t_edge_row(const Row<VEC, G, R> &x, const Row<VE
 {
     // live = 0: a padding repeat of the previous edge (odd count) adds nothing; keeping it
     // unconditional keeps its row load in flight with its partner's instead of behind a branch
-    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));   // same bits as the forward
+    // (rsq + one Newton step, about half an ulp: the backward only needs the value to be accurate;
+    // the forward's selection uses IEEE sqrt / division on whole rows, agg_fwd_impl.h)
+    const float invj = inv_norm_of(group_sum<G>(x.dot_partial(x)));
     const float d = group_sum<G>(gp.dot_partial(x));
     fma_row<VEC, G, R>(acc, d * invj * live, x);
 }
