@@ -234,6 +234,34 @@ class _AdjLinearParams(nn.Module):
         bound = 1 / math.sqrt(self.in_features) if self.in_features > 0 else 0
         nn.init.uniform_(self.bias, -bound, bound)
 
+    # --- checkpoints of a sharded w (built under a partition: this rank holds [C, n_local]) ------
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """A reference-format checkpoint ([C, N] under ``...w.weight``) loads into a sharded
+        module: the rank takes its own columns."""
+        key = prefix + "weight"
+        if self.shard_range is not None and key in state_dict:
+            w = state_dict[key]
+            if w.dim() == 2 and w.size(1) == self.in_features and self.in_features != self.weight.size(1):
+                state_dict = dict(state_dict)
+                state_dict[key] = w[:, self.shard_range[0]:self.shard_range[1]]
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def full_weight(self, part=None) -> torch.Tensor:
+        """The reference-shaped [C, N] weight: the parameter itself when replicated, the
+        all-gather of the ranks' column shards (a collective: every rank calls it) when sharded -
+        what a checkpoint that must load into a single-process model, or into the reference,
+        stores under ``w.weight`` (``sngnn_amd.dist.full_state_dict``)."""
+        if self.shard_range is None:
+            return self.weight.detach()
+        part = part or sn_dist.current_partition()
+        if part is None:
+            raise ValueError("a sharded w needs its partition to be gathered")
+        wt = self.weight.detach().t()
+        rows = sn_dist.all_gather_rows(wt if wt.is_contiguous() else wt.contiguous(), part)
+        return rows.t()
+
     def _apply(self, fn, recurse=True):
         # .to()/.cuda() would re-materialise the weight row-major; restore the layout
         super()._apply(fn, recurse)
@@ -299,7 +327,17 @@ class SNConv_plus_plus(nn.Module):
                 m = 0
             else:
                 keep = edge_index[0] != edge_index[1]
-                m = int(edge_index[0][keep].min()) if bool(keep.any()) else 0
+                m = edge_index[0][keep].min() if bool(keep.any()) else edge_index.new_tensor(2 ** 62)
+                part = sn_dist.current_partition()
+                if part is not None and torch.distributed.is_initialized():
+                    # ranks may hold different subsets of the edges: the shift is a property of the
+                    # WHOLE list, so every rank must arrive at the same value (and raise together)
+                    m = m.clone()
+                    if sn_dist._is_gloo(m, part.group):
+                        m = m.cpu()
+                    torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MIN, group=part.group)
+                m = int(m)
+                m = 0 if m >= 2 ** 62 else m
             hit = (key, m)
             self._src_min_cache = hit
         return hit[1]

@@ -199,9 +199,9 @@ class HaloPlan:
         self.recv_counts = [int(v) for v in need_counts.tolist()]           # rows I receive per peer
         self.send_counts = [int(v) for v in _exchange_counts(need_counts, part).tolist()]
         # tell every owner which of its rows I need (ids relative to the owner's range)
-        req = (need - b[owner]).to(torch.int64).view(-1, 1).to(torch.float64)   # exact below 2^53
+        req = (need - b[owner]).to(torch.int64).view(-1, 1)
         got = _all_to_all_rows(req, self.recv_counts, self.send_counts, part)
-        self.send_idx = got.view(-1).to(torch.int64).to(dev)                   # my local rows, by peer
+        self.send_idx = got.view(-1).to(dev)                                   # my local rows, by peer
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
             raise RuntimeError("halo plan: a peer asked for a row outside this rank's range")
         # local edge list: targets -> [0, n_local), sources -> own id or n_local + halo position
@@ -483,3 +483,16 @@ def sync_batch_norm(bn: torch.nn.BatchNorm1d, x: torch.Tensor, part: Partition) 
         bn.num_batches_tracked += 1
     return _SyncBatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                 bn.momentum, part)
+
+
+def full_state_dict(module: torch.nn.Module, part: Optional[Partition] = None) -> dict:
+    """``module.state_dict()`` in the REFERENCE's layout: every sharded ``w.weight`` ([C, n_local]
+    on this rank) replaced by the gathered [C, N] table, so the checkpoint loads into a
+    single-process model (or the reference) - and, through ``_AdjLinearParams``'s load hook, back
+    into a model sharded over any partition.  A collective when something is sharded: every rank
+    calls it; write the result from one."""
+    sd = dict(module.state_dict())
+    for name, sub in module.named_modules():
+        if hasattr(sub, "full_weight") and getattr(sub, "shard_range", None) is not None:
+            sd[(name + "." if name else "") + "weight"] = sub.full_weight(part).contiguous()
+    return sd

@@ -62,8 +62,8 @@ class Graph:
     def workspace(self, channels: int) -> torch.Tensor:
         """Scratch for forward/backward at ``channels``: one buffer per (width, stream), so
         calls on the same graph from different streams never share scratch (the entry
-        points are re-entrant per stream).  Allocated on first use, i.e. outside any capture
-        that later replays the call (``GraphedEpoch`` runs an eager pass first)."""
+        points are re-entrant per stream).  Allocated on first use: ``GraphedEpoch`` runs an
+        eager pass on the very stream it then captures on, so the capture finds its buffers."""
         key = (channels, torch.cuda.current_stream(self.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
@@ -98,6 +98,7 @@ class GraphCache:
     def __init__(self, max_entries: int = 4):
         self._entries: Dict[Tuple, Tuple[Graph, torch.Tensor]] = {}
         self._max = max_entries
+        self._recording = None          # list of graphs handed out while record() is active
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, add_loops: bool,
             remove_loops: bool, row_range=None) -> Graph:
@@ -112,7 +113,24 @@ class GraphCache:
             # for a different tensor while the key is cached
             hit = (Graph(edge_index, num_nodes, add_loops, remove_loops, row_range), edge_index)
             self._entries[key] = hit
+        if self._recording is not None and not any(g is hit[0] for g in self._recording):
+            self._recording.append(hit[0])
         return hit[0]
+
+    def record(self):
+        """Context manager: collects the Graph objects ``get`` hands out inside it (the graphs a
+        captured epoch launches on - what its owner must keep alive)."""
+        cache = self
+
+        class _Rec:
+            def __enter__(self):
+                cache._recording = self.graphs = []
+                return self.graphs
+
+            def __exit__(self, *exc):
+                cache._recording = None
+                return False
+        return _Rec()
 
     def snapshot(self):
         """The Graph objects currently cached.  Whoever captured raw pointers of them (a HIP

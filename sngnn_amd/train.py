@@ -119,24 +119,27 @@ class GraphedEpoch:
                     and all(dense(p) and p.is_cuda for p in g["params"])):
                 g["fused"] = True
         self._materialise_adam_state()
-        with torch.no_grad():            # library handles / workspaces exist before the capture
-            model.eval()
-            model(data)
+        from .graph import GLOBAL_CACHE
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
+            # library handles and the per-(width, STREAM) workspaces exist before the capture: the
+            # priming forward, the warm-up and the capture all run on this one stream
+            with torch.no_grad():
+                model.eval()
+                model(data)
             for _ in range(warmup):          # allocator / lazy-init warm-up outside the capture
                 self._epoch()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._epoch()
         # The captured launches hold raw device pointers into the structure arrays and the
-        # workspaces of the graphs the model ran on.  The cache that owns them evicts (FIFO):
-        # keep them alive for as long as this capture can be replayed.
-        from .graph import GLOBAL_CACHE
-        self._held_graphs = GLOBAL_CACHE.snapshot()
+        # workspaces of the graphs the model runs on.  The cache that owns them evicts (FIFO):
+        # keep exactly those alive for as long as this capture can be replayed.
+        with GLOBAL_CACHE.record() as used:
+            with torch.cuda.graph(self.graph, stream=side):
+                self._epoch()
+        self._held_graphs = list(used)
 
     def _materialise_adam_state(self):
         """Adam creates its state lazily inside the first ``step()``; inside a capture

@@ -25,9 +25,17 @@ from tests.dist_case import BOUNDS, build_case, build_model  # noqa: E402
 def main():
     kind, out_path, exchange, sharded = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] == "1"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    # SNGNN_DIST_BACKEND=nccl: one rank per GPU over RCCL (needs >= world GPUs); default: the ranks
+    # share GPU 0 and talk over gloo
+    backend = os.environ.get("SNGNN_DIST_BACKEND", "gloo")
+    dev_id = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     x, ei, y, mask, _ = build_case(world)
     part = sd.Partition(rank, world, bounds=BOUNDS[world], exchange=exchange)
     if sharded:

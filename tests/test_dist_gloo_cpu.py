@@ -188,3 +188,52 @@ def test_set_partition_switch():
     assert sd.current_partition() is p and p.row_begin == 10 and p.n_total == 40
     sd.set_partition(None)
     assert sd.current_partition() is None
+
+
+def _ckpt_worker(rank, world, port, bounds, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sngnn_amd
+    from sngnn_amd import dist as sd
+    n = bounds[-1]
+    args = (6, 8, 3, n, 2, 2, 0.0, 0.5, 1, 0.0)
+    torch.manual_seed(5)
+    single = sngnn_amd.SNGNN_Plus_Plus(*args)                 # the reference-shaped model
+    part = sd.Partition(rank, world, bounds=bounds)
+    sd.set_partition(part)
+    torch.manual_seed(5)
+    sharded = sngnn_amd.SNGNN_Plus_Plus(*args)                # w holds this rank's columns only
+    ok = sharded.lins[0].w.weight.shape == (8, part.n_local)
+    full = sd.full_state_dict(sharded, part)                  # collective: gathers the column shards
+    ref = single.state_dict()
+    ok = ok and list(full) == list(ref) and all(torch.equal(full[k], ref[k]) for k in ref)
+    # ... and the reference-format checkpoint loads back into a model sharded differently
+    other = sd.Partition(rank, world, bounds=(0, 9, n))
+    sd.set_partition(other)
+    torch.manual_seed(99)
+    again = sngnn_amd.SNGNN_Plus_Plus(*args)
+    again.load_state_dict(full)
+    ok = ok and all(torch.equal(again.lins[l].w.weight, ref[f"lins.{l}.w.weight"][:, other.row_begin:other.row_end])
+                    for l in (0, 1))
+    sd.set_partition(None)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_w_checkpoint_round_trip():
+    """per-rank shards of ``w.weight`` share one state_dict key - ``full_state_dict``
+    gathers them into the reference's [C, N] layout, and such a checkpoint loads into a model
+    sharded over any partition (or into a single-process model)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, (0, 23, 40), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

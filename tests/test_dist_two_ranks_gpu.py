@@ -23,12 +23,11 @@ CASES = [("SNGNN_Plus", "halo", 0), ("SNGNN_Plus", "allgather", 0), ("SNGNN_Plus
          ("SNGNN", "halo", 0), ("AGNN", "halo", 0)]
 
 
-@pytest.mark.parametrize("kind,exchange,sharded", CASES)
-def test_two_ranks_equal_one_process(cuda, kind, exchange, sharded, tmp_path):
+def _run_and_compare(cuda, kind, exchange, sharded, tmp_path, backend):
     from sngnn_amd.synth import Data
     world = 2
     out_path = str(tmp_path / "ranks.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNGNN_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(ROOT, "tests", "dist_worker_gpu.py"), kind, out_path, exchange, str(sharded)]
@@ -50,3 +49,21 @@ def test_two_ranks_equal_one_process(cuda, kind, exchange, sharded, tmp_path):
         assert np.abs(g - w).max() <= 2e-5 * max(np.abs(w).max(), 1e-6), k
     for k, b in model.named_buffers():          # batch-norm running statistics
         assert np.allclose(z["buf." + k], b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("kind,exchange,sharded", CASES)
+def test_two_ranks_equal_one_process(cuda, kind, exchange, sharded, tmp_path):
+    _run_and_compare(cuda, kind, exchange, sharded, tmp_path, "gloo")
+
+
+@pytest.mark.parametrize("kind,exchange,sharded", [("SNGNN_Plus", "halo", 0), ("SNGNN_Plus", "allgather", 0),
+                                                   ("SNGNN_Plus_Plus", "halo", 1), ("SNGNN_Plus_bn", "halo", 0)])
+def test_two_ranks_over_rccl(cuda, kind, exchange, sharded, tmp_path):
+    """The same comparison with one rank per GPU over RCCL (backend "nccl"): the asynchronous
+    ``all_to_all_single`` into the [own | halo] table overlapped with the interior rows'
+    aggregation, its transpose in backward, ``all_gather_into_tensor`` / ``reduce_scatter_tensor``,
+    the gradient all-reduce and sync batch norm - with world_size 2.  Needs two visible GPUs:
+    skipped on the one-GPU test box, runs wherever the suite sees a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (one rank per GPU over RCCL)")
+    _run_and_compare(cuda, kind, exchange, sharded, tmp_path, "nccl")
