@@ -354,6 +354,18 @@ int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *
  */
 int sngnn_linear_forward(const float *x, const float *weight, const float *bias,
                          int64_t N, int F, int C, float *h, void *stream);
+/*
+ * Replaces: self.lin followed by F.normalize (models.py:237-238, :121-122, :324-325 - adjacent
+ * lines of every conv forward): h as above AND, from the same launch's epilogue, the unit rows
+ * n = h / max(||h||, 1e-12), the clamped norms and (filt != NULL, C > 32) the fp16 filter rows -
+ * bit for bit what sngnn_normalize_rows_filter computes from h (same summation tree, IEEE
+ * square root and division), so sngnn_agg_forward_prepared can follow without a normalisation
+ * pass.  C % 4 == 0, C <= 64, F in {16, 32, 64, 128} (sngnn_linear_normalized_supported).
+ */
+int sngnn_linear_normalized_supported(int64_t N, int F, int C);
+int sngnn_linear_forward_normalized(const float *x, const float *weight, const float *bias,
+                                    int64_t N, int F, int C, float *h, float *n, float *nrm,
+                                    void *filt, void *stream);
 int64_t sngnn_linear_wgrad_workspace_bytes(int64_t N, int C, int F);
 int sngnn_linear_wgrad(const float *grad_out, const float *x, int64_t N, int C, int F,
                        float *grad_weight, float *grad_bias, void *workspace, void *stream);

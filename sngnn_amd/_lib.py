@@ -66,6 +66,8 @@ SIGNATURES = {
     "sngnn_head_nll": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "sngnn_head_nll2": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "sngnn_linear_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sngnn_linear_normalized_supported": (_i32, [_i64, _i32, _i32]),
+    "sngnn_linear_forward_normalized": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_linear_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "sngnn_linear_wgrad": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_cosine_dense": (_i32, [_vp, _i64, _i64, _vp, _vp]),

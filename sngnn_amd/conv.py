@@ -71,7 +71,7 @@ def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remov
     return shard.graph, shard
 
 
-def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None):
+def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None):
     """``h = lin(x)`` with the channel count rounded up to a multiple of 4 by zero
     weights (returns h, the true width and the rank's feature table or None).  Rows of 4k
     floats are 16-byte aligned, so the kernels read them with 16-byte lane loads (2.5x faster
@@ -83,12 +83,21 @@ def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None):
     cp = (c + 3) // 4 * 4
     pad = None if (cp == c or c < 16 or not x.is_cuda) else cp
     if shard is None or shard.plan is None or not x.is_cuda or x.dtype != torch.float32:
-        if pad is None:
-            return ops.linear(x, lin), c, None
-        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None), c, None
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32):
+            return lin(x), c, None
+        # ``unit`` (single GPU): F.normalize of h from the same launch, for the aggregation that follows
+        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None, unit if shard is None else None), c, None
     table = sn_dist.new_table(shard.plan, pad or c, x)
     head = table[:shard.plan.n_local]
-    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head)), c, table
+    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head), None), c, table
+
+
+def _unit_for(lin: nn.Linear, graph, top_k, thr) -> "ops.UnitRows":
+    """The holder ``lin``'s normalising epilogue fills (ops.UnitRows); it asks for the fp16 filter
+    rows only when the forward that follows will read them."""
+    c = lin.out_features
+    cp = c if (c % 4 == 0 or c < 16) else (c + 3) // 4 * 4
+    return ops.UnitRows(ops.filter_wanted(graph, cp, int(top_k), float(thr)))
 
 
 def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
@@ -98,12 +107,12 @@ def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
     return out if out.size(1) == c else out[:, :c]
 
 
-def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float, table=None) -> torch.Tensor:
+def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float, table=None, unit=None) -> torch.Tensor:
     """Fused aggregation of the local rows; under a node-range partition the feature rows the
     rank's in-edges reference are exchanged first (RCCL) - in the halo form overlapped with the
     aggregation of the rows that need none of them (sngnn_amd/dist.py:halo_aggregate)."""
     if shard is None:
-        return ops.aggregate(h, graph, top_k, thr)
+        return ops.aggregate(h, graph, top_k, thr, unit)
     if shard.plan is not None:
         return sn_dist.halo_aggregate(h, shard.plan, graph, top_k, thr, table)
     return ops.aggregate(shard.table(h), graph, top_k, thr)
@@ -131,8 +140,9 @@ class SNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, False)
-        h, c, table = _lin_aligned(x, self.lin, shard)
-        out = _true_width(_aggregate(h, graph, shard, None, 0.0, table), c)
+        unit = ops.UnitRows(False)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit)
+        out = _true_width(_aggregate(h, graph, shard, None, 0.0, table, unit), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -189,8 +199,9 @@ class SNConv_plus(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h, c, table = _lin_aligned(x, self.lin, shard)
-        out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table), c)
+        unit = _unit_for(self.lin, graph, self.top_k, self.thr)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit)
+        out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)
         if self.bias is not None:
             out = out + self.bias
         return out
@@ -350,7 +361,8 @@ class SNConv_plus_plus(nn.Module):
         if part is None and self.w.shard_range is not None:
             raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        h, c, table = _lin_aligned(x, self.lin, shard)
+        unit = _unit_for(self.lin, graph, self.top_k, self.thr)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit)
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:
@@ -376,7 +388,7 @@ class SNConv_plus_plus(nn.Module):
                 graph_out = GLOBAL_CACHE.get(flipped, part.n_total, True, bool(self.is_remove_self_loops),
                                              row_range=(part.row_begin, part.row_end))
                 out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
-        out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table), c)
+        out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)
         out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias

@@ -137,6 +137,136 @@ __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, 
     }
 }
 
+// Lane-GROUP-per-row variant for C % 4 == 0, C <= 64 (round 3): G = 8 or 16 lanes share a row,
+// 16 bytes per lane, so a wave-wide load reads 64 / G whole rows as ONE contiguous segment
+// (the lane-per-row form above reads 64 rows 4 C bytes apart per instruction: 64 different
+// lines for 16 useful bytes each, and the lines must survive in the CU's 32 KB L1 until the
+// row's other nine loads come by - 15 us for 27 MB of logits, 1.8 TB/s).  The row's maximum,
+// its first arg-max, the sum of the exponentials and the label's logit are 4-step DPP
+// reductions inside the group (no LDS, no shuffles).  Two rows per group in flight.
+// Same per-row arithmetic up to the order of the exp sum (a fixed tree here).
+template <int CTRL> __device__ __forceinline__ float dpp_maxf(float v)
+{
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_mini(int v)
+{
+    return min(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ float dpp_addf(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int G> __device__ __forceinline__ float gmaxf(float v)
+{
+    v = dpp_maxf<0xB1>(v); v = dpp_maxf<0x4E>(v); v = dpp_maxf<0x141>(v);
+    if constexpr (G == 16) v = dpp_maxf<0x140>(v);
+    return v;
+}
+template <int G> __device__ __forceinline__ int gmini(int v)
+{
+    v = dpp_mini<0xB1>(v); v = dpp_mini<0x4E>(v); v = dpp_mini<0x141>(v);
+    if constexpr (G == 16) v = dpp_mini<0x140>(v);
+    return v;
+}
+template <int G> __device__ __forceinline__ float gsumf(float v)
+{
+    v = dpp_addf<0xB1>(v); v = dpp_addf<0x4E>(v); v = dpp_addf<0x141>(v);
+    if constexpr (G == 16) v = dpp_addf<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ float fast_exp_neg(float t) { return __builtin_amdgcn_exp2f(t * 1.44269504088896341f); }
+
+template <int G, bool TWO>
+__global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z, const int64_t *__restrict__ y,
+                                                     const unsigned char *__restrict__ sel, int64_t N, int C,
+                                                     float scale, float *__restrict__ grad,
+                                                     float *__restrict__ part)
+{
+    constexpr int RPW = 64 / G, U = 2;
+    __shared__ float s_loss[4], s_corr[4], s_lossb[4], s_corrb[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const bool in = 4 * lg < C;
+    const int c0 = in ? 4 * lg : 0;
+    float loss = 0.f, corr = 0.f, lossb = 0.f, corrb = 0.f;
+    const int64_t nw = (int64_t)gridDim.x * 4, w0 = (int64_t)blockIdx.x * 4 + wave;
+    for (int64_t base = w0 * (RPW * U); base < N; base += nw * (RPW * U)) {
+        float4 t[U];
+        int yi[U];
+        unsigned char sv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                         // all loads first
+            const int64_t i = base + u * RPW + gid;
+            const int64_t ic = i < N ? i : N - 1;
+            sv[u] = i < N ? sel[ic] : (unsigned char)0;
+            t[u] = *reinterpret_cast<const float4 *>(z + ic * C + c0);
+            yi[u] = (int)y[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + u * RPW + gid;
+            if (i >= N) continue;                             // (group-uniform)
+            float *gi = grad ? grad + i * C + c0 : nullptr;
+            if (sv[u] == 0) {
+                if (gi && in) *reinterpret_cast<float4 *>(gi) = make_float4(0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            const float v0 = in ? t[u].x : -INFINITY, v1 = in ? t[u].y : -INFINITY;
+            const float v2 = in ? t[u].z : -INFINITY, v3 = in ? t[u].w : -INFINITY;
+            const float mx = gmaxf<G>(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+            // first channel that attains the maximum (torch.max on the CPU keeps the first)
+            int a = 1 << 30;
+            if (v3 == mx) a = c0 + 3;
+            if (v2 == mx) a = c0 + 2;
+            if (v1 == mx) a = c0 + 1;
+            if (v0 == mx) a = c0;
+            const int arg = gmini<G>(a);
+            // exp(t) for t <= 0 as 2^(t log2 e): v_exp_f32 (1 ulp) on a product rounded once - a
+            // relative error of at most |t| 2^-24 + 2^-23 per term, i.e. below 3e-6 even for the
+            // terms 40 below the maximum (which weigh e^-40); the library expf spends ~15
+            // instructions per value on the last bit and made this kernel VALU-bound
+            const float e0 = in ? fast_exp_neg(v0 - mx) : 0.f, e1 = in ? fast_exp_neg(v1 - mx) : 0.f;
+            const float e2 = in ? fast_exp_neg(v2 - mx) : 0.f, e3 = in ? fast_exp_neg(v3 - mx) : 0.f;
+            const float se = gsumf<G>((e0 + e1) + (e2 + e3));
+            const int yy = yi[u];
+            const int k = yy - c0;                            // the label's logit sits in exactly one lane
+            const float mine = (in && k >= 0 && k < 4) ? (k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3) : 0.f;
+            const float zy = gsumf<G>(mine);
+            const float row_loss = -(zy - mx - logf(se)), row_corr = (arg == yy) ? 1.f : 0.f;
+            if (lg == 0) {
+                if constexpr (TWO) {
+                    if (sv[u] & 1) { loss += row_loss; corr += row_corr; }
+                    if (sv[u] & 2) { lossb += row_loss; corrb += row_corr; }
+                } else {
+                    loss += row_loss;
+                    corr += row_corr;
+                }
+            }
+            if (gi && in) {
+                const float inv = scale / se;
+                *reinterpret_cast<float4 *>(gi) = make_float4(e0 * inv - (k == 0 ? scale : 0.f), e1 * inv - (k == 1 ? scale : 0.f),
+                                                              e2 * inv - (k == 2 ? scale : 0.f), e3 * inv - (k == 3 ? scale : 0.f));
+            }
+        }
+    }
+    loss = wsum(loss);
+    corr = wsum(corr);
+    if constexpr (TWO) { lossb = wsum(lossb); corrb = wsum(corrb); }
+    if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; s_lossb[wave] = lossb; s_corrb[wave] = corrb; }
+    __syncthreads();
+    if (threadIdx.x == 0 && TWO) {
+        part[4 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        part[4 * blockIdx.x + 1] = (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+        part[4 * blockIdx.x + 2] = (s_lossb[0] + s_lossb[1]) + (s_lossb[2] + s_lossb[3]);
+        part[4 * blockIdx.x + 3] = (s_corrb[0] + s_corrb[1]) + (s_corrb[2] + s_corrb[3]);
+    } else if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        part[2 * blockIdx.x + 1] = (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+    }
+}
+
 // One wave per row.  sel[i] != 0 marks the rows of the mask.  Per-block partial (loss
 // sum, correct count) go to part[]; grad (optional, dense [N, C]) = (softmax - onehot)
 // * scale on masked rows, 0 elsewhere.  C <= 64: the row lives in one register per lane.
@@ -371,11 +501,15 @@ extern "C" int sngnn_head_nll2(const float *logits, const int64_t *y, const unsi
     SN_REQUIRE(N >= 0 && C >= 1 && C <= 64, SNGNN_EINVAL, "sngnn_head_nll2 needs 1 <= C <= 64");
     SN_REQUIRE(logits && y && row_sets && out4 && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (int)std::min<int64_t>((N + 255) / 256, HEAD_MAX_BLOCKS);
+    int nb = (int)std::min<int64_t>((N + 255) / 256, HEAD_MAX_BLOCKS);
     const float sa = 1.0f / (float)(n_a > 0 ? n_a : 1), sb = 1.0f / (float)(n_b > 0 ? n_b : 1);
     const bool vec4 = C % 4 == 0 && (uintptr_t)logits % 16 == 0;
-    if (nb > 0 && vec4)
-        k_head_rows<true, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
+    // (the group kernels take 32 / 64 rows per workgroup and sweep: fill the chip)
+    if (vec4) nb = (int)std::min<int64_t>((N + 31) / 32, HEAD_MAX_BLOCKS);
+    if (nb > 0 && vec4 && C <= 32)
+        k_head_groups<8, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
+    else if (nb > 0 && vec4)
+        k_head_groups<16, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
     else if (nb > 0)
         k_head_rows<false, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
     k_head_reduce<<<2, 256, 0, st>>>((const float *)workspace, nb, sa, sb, 4, out4);
@@ -392,11 +526,14 @@ extern "C" int sngnn_head_nll(const float *logits, const int64_t *y, const unsig
     hipStream_t st = (hipStream_t)stream;
     const bool rows = C <= 64;      // lane-per-row kernel
     const int64_t per_block = rows ? 256 : HEAD_ROWS_PER_BLOCK;
-    const int nb = (int)std::min<int64_t>((N + per_block - 1) / per_block, HEAD_MAX_BLOCKS);
+    int nb = (int)std::min<int64_t>((N + per_block - 1) / per_block, HEAD_MAX_BLOCKS);
     const float scale = 1.0f / (float)(n_masked > 0 ? n_masked : 1);     // nll_loss(reduction='mean')
     const bool vec4 = C % 4 == 0 && (uintptr_t)logits % 16 == 0 && (grad_logits == nullptr || (uintptr_t)grad_logits % 16 == 0);
-    if (nb > 0 && rows && vec4)
-        k_head_rows<true><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
+    if (rows && vec4) nb = (int)std::min<int64_t>((N + 31) / 32, HEAD_MAX_BLOCKS);
+    if (nb > 0 && rows && vec4 && C <= 32)
+        k_head_groups<8, false><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
+    else if (nb > 0 && rows && vec4)
+        k_head_groups<16, false><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
     else if (nb > 0 && rows)
         k_head_rows<false><<<nb, 256, 0, st>>>(logits, y, row_mask, N, C, scale, grad_logits, (float *)workspace);
     else if (nb > 0)

@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "agg_fwd_filter.h"
 #include "common.h"
+#include "device_utils.h"
 
 namespace sngnn {
 
@@ -115,14 +117,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 // inputs: W^T alone is 128 registers - is allowed the whole register file, the others keep the
 // two-wave budget they were tuned with: at 256 registers the wide one spilled and took 65 us
 // instead of 36 us; rocBLAS: 83 us)
-template <int NT, int FQ>
+// NORM: the epilogue also writes F.normalize of the finished rows (models.py:237-238 are adjacent
+// lines) - unit rows, clamped norms and, when asked for, the fp16 filter rows - with the very
+// instruction sequence of k_normalize_rows (agg_fwd_impl.h): a finished 16-row tile goes through a
+// wave-private LDS tile into the aggregation's row layout (VEC 4, G = 8 or 16 lanes per row),
+// there the same fma chain, the same DPP tree, the same IEEE square root and division.  Needs
+// C % 4 == 0.  h itself then leaves from that layout too (16-byte stores).
+template <int NT, int FQ, bool NORM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NT == 4 && FQ == 8) ? 1 : 2, (NT == 4 && FQ == 8) ? 1 : 2)))
 void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
-                   int N, int C, float *__restrict__ h, int ntiles)
+                   int N, int C, float *__restrict__ h, int ntiles, float *__restrict__ un,
+                   float *__restrict__ unrm, void *__restrict__ filt)
 {
     constexpr int F = 16 * FQ, KS = 4 * FQ, LD = F + 4;
     constexpr int RPI = 16 / FQ;                     // rows covered by one wave-wide 16-byte load
+    constexpr int HLD = 16 * NT + 4;                 // row stride of the finished tile in LDS
     __shared__ __align__(16) float lds[4][16 * LD];
+    __shared__ __align__(16) float hts[NORM ? 4 : 1][NORM ? 16 * HLD : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     float *tile = lds[wave];
@@ -188,13 +199,63 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             hoff[t][r] = (16 * t + r16 < C) ? (unsigned)((4 * kq + r) * C + 16 * t + r16) * 4u : BUF_OOB;
+    // NORM: buffer resources of the three extra outputs; lane roles in the aggregation's row layout
+    constexpr int GN = NT <= 2 ? 8 : 16;             // lanes per row: C <= 32 -> 8, C <= 64 -> 16 (row_cfg)
+    constexpr int RPWN = 64 / GN;
+    const int gidn = lane / GN, lgn = lane % GN;
+    __amdgpu_buffer_rsrc_t ur = hr, nr = hr, fr = hr;
+    if constexpr (NORM) {
+        ur = make_rsrc(un, (unsigned)N * (unsigned)C * 4u);
+        nr = make_rsrc(unrm, (unsigned)N * 4u);
+        fr = make_rsrc(filt, filt != nullptr ? (unsigned)N * 128u : 0u);
+    }
     auto store_tile = [&](int tl_, const f32x4 (&v)[NT]) {
-        const unsigned to = (unsigned)tl_ * 16u * (unsigned)C * 4u;
+        if constexpr (!NORM) {
+            const unsigned to = (unsigned)tl_ * 16u * (unsigned)C * 4u;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), hr, hoff[t][r] + to, 0, 0);
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), hr, hoff[t][r] + to, 0, 0);
+        } else {
+            using RowT = Row<4, GN, 1>;
+            using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
+            float *ht = hts[wave];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ht[(4 * kq + r) * HLD + 16 * t + r16] = v[t][r];
+            wave_barrier_lds();
+            const bool in = 4 * lgn < C;
+#pragma unroll
+            for (int sidx = 0; sidx < 16 / RPWN; ++sidx) {
+                const int rt = sidx * RPWN + gidn;
+                const unsigned grow = (unsigned)tl_ * 16u + (unsigned)rt;
+                RowT xrow;
+                const float4 tv = *reinterpret_cast<const float4 *>(ht + rt * HLD + (in ? 4 * lgn : 0));
+                xrow.x[0][0] = in ? tv.x : 0.f; xrow.x[0][1] = in ? tv.y : 0.f;
+                xrow.x[0][2] = in ? tv.z : 0.f; xrow.x[0][3] = in ? tv.w : 0.f;
+                const unsigned roff = in ? (grow * (unsigned)C + 4u * lgn) * 4u : BUF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    u32x4n{__float_as_uint(xrow.x[0][0]), __float_as_uint(xrow.x[0][1]),
+                           __float_as_uint(xrow.x[0][2]), __float_as_uint(xrow.x[0][3])}, hr, roff, 0, 0);
+                // F.normalize, exactly as k_normalize_rows does it
+                const float q = group_sum<GN>(xrow.dot_partial(xrow));
+                const float d = fmaxf(ieee_sqrt(q), EPS_NORM);
+                xrow.div_rn(d);
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    u32x4n{__float_as_uint(xrow.x[0][0]), __float_as_uint(xrow.x[0][1]),
+                           __float_as_uint(xrow.x[0][2]), __float_as_uint(xrow.x[0][3])}, ur, roff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), nr, lgn == 0 ? grow * 4u : BUF_OOB, 0, 0);
+                if constexpr (GN == 16) {
+                    using u32x2n = __attribute__((ext_vector_type(2))) unsigned;
+                    __builtin_amdgcn_raw_buffer_store_b64(
+                        u32x2n{pack_half2(xrow.x[0][0] * FILT_SCALE, xrow.x[0][1] * FILT_SCALE),
+                               pack_half2(xrow.x[0][2] * FILT_SCALE, xrow.x[0][3] * FILT_SCALE)},
+                        fr, grow * 128u + 8u * lgn, 0, 0);
+                }
+            }
+        }
     };
     // The finished values of tile i (bias added) stay in their own registers and are stored
     // in iteration i + 1, before that iteration's loads are issued.  A store reads its data
@@ -466,17 +527,30 @@ int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, f
 
 template <int FQ>
 static int launch_linear_rows(const float *x, const float *w, const float *b, int N, int C, float *h,
-                              hipStream_t st)
+                              float *un, float *unrm, void *filt, hipStream_t st)
 {
     const int ntiles = (int)((N + 15) / 16);
     // one workgroup per CU (one wave per SIMD): measured faster than two (29 vs 36 us at
     // arxiv size) - the kernel is bound by its MFMA stream, more waves only add W traffic
-    const int grid = std::min(256, (ntiles + 3) / 4);
-    switch ((C + 15) / 16) {
-    case 1: k_linear_rows<1, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
-    case 2: k_linear_rows<2, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
-    case 3: k_linear_rows<3, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
-    default: k_linear_rows<4, FQ><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles); break;
+#ifndef SNGNN_LIN_NORM_WGS
+#define SNGNN_LIN_NORM_WGS 1
+#endif
+    int grid = std::min(256, (ntiles + 3) / 4);
+    if (un != nullptr) {
+        grid = std::min(256 * SNGNN_LIN_NORM_WGS, (ntiles + 3) / 4);
+        switch ((C + 15) / 16) {
+        case 1: k_linear_rows<1, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
+        case 2: k_linear_rows<2, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
+        case 3: k_linear_rows<3, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
+        default: k_linear_rows<4, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
+        }
+    } else {
+        switch ((C + 15) / 16) {
+        case 1: k_linear_rows<1, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
+        case 2: k_linear_rows<2, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
+        case 3: k_linear_rows<3, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
+        default: k_linear_rows<4, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
+        }
     }
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
@@ -485,6 +559,36 @@ static int launch_linear_rows(const float *x, const float *w, const float *b, in
 }  // namespace sngnn
 
 using namespace sngnn;
+
+// whether sngnn_linear_forward_normalized handles a shape (else: sngnn_linear_forward + a
+// normalisation pass)
+extern "C" int sngnn_linear_normalized_supported(int64_t N, int F, int C)
+{
+    const int64_t lim = ((int64_t)1 << 31) - ((int64_t)64 << 20);
+    return (C % 4 == 0 && C >= 4 && C <= 64 && (F == 16 || F == 32 || F == 64 || F == 128) && N >= 1 &&
+            N * F * 4 < lim && N * (int64_t)128 < lim)
+               ? 1 : 0;
+}
+
+extern "C" int sngnn_linear_forward_normalized(const float *x, const float *weight, const float *bias, int64_t N,
+                                               int F, int C, float *h, float *n, float *nrm, void *filt,
+                                               void *stream)
+{
+    SN_REQUIRE(sngnn_linear_normalized_supported(N, F, C), SNGNN_EINVAL,
+               "shape not handled (sngnn_linear_normalized_supported)");
+    SN_REQUIRE(x && weight && h && n && nrm, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)weight % 16 == 0 && (uintptr_t)h % 16 == 0 &&
+                   (uintptr_t)n % 16 == 0 && (uintptr_t)filt % 16 == 0,
+               SNGNN_EINVAL, "x / weight / h / n / filt must be 16-byte aligned");
+    SN_REQUIRE(filt == nullptr || filter_row_bytes(C) == 128, SNGNN_EINVAL, "no 128-byte filter rows for this C");
+    hipStream_t st = (hipStream_t)stream;
+    switch (F) {
+    case 16: return launch_linear_rows<1>(x, weight, bias, (int)N, C, h, n, nrm, filt, st);
+    case 32: return launch_linear_rows<2>(x, weight, bias, (int)N, C, h, n, nrm, filt, st);
+    case 64: return launch_linear_rows<4>(x, weight, bias, (int)N, C, h, n, nrm, filt, st);
+    default: return launch_linear_rows<8>(x, weight, bias, (int)N, C, h, n, nrm, filt, st);
+    }
+}
 
 extern "C" int sngnn_linear_forward(const float *x, const float *weight, const float *bias, int64_t N,
                                     int F, int C, float *h, void *stream)
@@ -499,10 +603,10 @@ extern "C" int sngnn_linear_forward(const float *x, const float *weight, const f
     const int64_t lim = ((int64_t)1 << 31) - ((int64_t)64 << 20);
     if (al16 && N * F * 4 < lim && N * (int64_t)C * 4 < lim) {
         switch (F) {
-        case 16: return launch_linear_rows<1>(x, weight, bias, (int)N, C, h, st);
-        case 32: return launch_linear_rows<2>(x, weight, bias, (int)N, C, h, st);
-        case 64: return launch_linear_rows<4>(x, weight, bias, (int)N, C, h, st);
-        case 128: return launch_linear_rows<8>(x, weight, bias, (int)N, C, h, st);
+        case 16: return launch_linear_rows<1>(x, weight, bias, (int)N, C, h, nullptr, nullptr, nullptr, st);
+        case 32: return launch_linear_rows<2>(x, weight, bias, (int)N, C, h, nullptr, nullptr, nullptr, st);
+        case 64: return launch_linear_rows<4>(x, weight, bias, (int)N, C, h, nullptr, nullptr, nullptr, st);
+        case 128: return launch_linear_rows<8>(x, weight, bias, (int)N, C, h, nullptr, nullptr, nullptr, st);
         default: break;
         }
     }

@@ -182,10 +182,14 @@ class _Aggregate(torch.autograd.Function):
     and not saved, so the models' in-place ReLU on it is safe (models.py:81,206,298)."""
 
     @staticmethod
-    def forward(ctx, h, graph, top_k, thr):
+    def forward(ctx, h, graph, top_k, thr, unit=None):
         need_grad = ctx.needs_input_grad[0]
-        out, wsel, _, _, _ = aggregate_forward(graph, h, top_k, thr,
-                                               save_for_backward=need_grad)
+        if unit is not None and unit.n is not None:
+            # the producer of h (``lin``'s epilogue) already wrote F.normalize(h): no pass over h
+            out, wsel = _forward_prepared(graph, unit, top_k, thr, need_grad)
+        else:
+            out, wsel, _, _, _ = aggregate_forward(graph, h, top_k, thr,
+                                                   save_for_backward=need_grad)
         if need_grad:
             ctx.graph = graph
             ctx.save_for_backward(h, wsel)
@@ -195,13 +199,45 @@ class _Aggregate(torch.autograd.Function):
     def backward(ctx, grad_out):
         h, wsel = ctx.saved_tensors
         grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel)
-        return grad_h, None, None, None
+        return grad_h, None, None, None, None
 
 
-def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float) -> torch.Tensor:
+class UnitRows:
+    """What ``lin``'s normalising epilogue leaves behind for the aggregation that follows:
+    ``n`` [N, C] unit rows, ``nrm`` [N] clamped norms, ``filt`` fp16 filter rows or None
+    (``sngnn_linear_forward_normalized``).  ``want_filter``: whether the consumer will use them
+    (``ops.filter_wanted``).  ``n`` stays None when the layer's shape took another route."""
+
+    def __init__(self, want_filter: bool = False):
+        self.want_filter = bool(want_filter)
+        self.n = self.nrm = self.filt = None
+
+
+def _forward_prepared(graph: Graph, unit: "UnitRows", top_k, thr, need_grad):
+    lib = _lib.load()
+    n = unit.n
+    c = n.size(1)
+    k = -1 if top_k is None else int(top_k)
+    out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=n.device)
+    wsel = inv = None
+    if need_grad:
+        wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=n.device)
+        inv = torch.empty(graph.num_nodes, dtype=torch.float32, device=n.device)
+    ws = graph.workspace(c)
+    with torch.cuda.device(n.device):
+        rc = lib.sngnn_agg_forward_prepared(graph.handle, n.data_ptr(), unit.nrm.data_ptr(), _lib.ptr(unit.filt), c, k,
+                                            float(thr), out.data_ptr(), _lib.ptr(wsel), _lib.ptr(inv), None, None,
+                                            ws.data_ptr(), _stream(n.device))
+    _lib.check(rc, "sngnn_agg_forward_prepared")
+    return out, wsel
+
+
+def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float,
+              unit: Optional["UnitRows"] = None) -> torch.Tensor:
     """Differentiable fused aggregation: [N_total, C] -> [N, C] (N_total == N unless
-    ``graph`` is a node-range partition)."""
-    return _Aggregate.apply(h, graph, top_k, thr)
+    ``graph`` is a node-range partition).  ``unit``: F.normalize(h) as left by ``lin``'s
+    epilogue (``UnitRows``) - the normalisation pass is skipped then."""
+    return _Aggregate.apply(h, graph, top_k, thr, unit)
 
 
 def attention_forward(graph: Graph, h: torch.Tensor, save_for_backward: bool = True):
@@ -427,13 +463,15 @@ class _Linear(torch.autograd.Function):
     handles poorly), grad_x through rocBLAS only when x needs it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad_to=None, out=None):
+    def forward(ctx, x, weight, bias, pad_to=None, out=None, unit=None):
         """``pad_to``: produce [N, pad_to] with zero channels behind the layer's own (16-byte
         rows for the aggregation kernels).  The padded weight / bias live in two persistent
         buffers attached to the weight and are refreshed by two small copies - no
         concatenation, no allocation and no autograd node per forward.
         ``out``: ``OutBuffer`` around a contiguous [N, C] tensor to write into (the head of a rank's
-        [own | halo] feature table, sngnn_amd/dist.py) - that tensor is returned as the result."""
+        [own | halo] feature table, sngnn_amd/dist.py) - that tensor is returned as the result.
+        ``unit``: a ``UnitRows`` to fill with F.normalize of the result from the same launch
+        (models.py:237-238 are adjacent lines); left empty when the shape takes the BLAS."""
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         n, f = x.shape
@@ -468,9 +506,22 @@ class _Linear(torch.autograd.Function):
         xc, wc = x.contiguous(), weight.contiguous()
         bc = None if bias is None else bias.contiguous()
         h = torch.empty((n, c), dtype=torch.float32, device=x.device) if out is None else out
+        lib = _lib.load()
+        if unit is not None and lib.sngnn_linear_normalized_supported(n, f, c) and xc.data_ptr() % 16 == 0 \
+                and wc.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0:
+            unit.n = torch.empty((n, c), dtype=torch.float32, device=x.device)
+            unit.nrm = torch.empty(n, dtype=torch.float32, device=x.device)
+            fb = int(lib.sngnn_filter_row_bytes(c)) if unit.want_filter else 0
+            unit.filt = torch.empty((n, fb), dtype=torch.uint8, device=x.device) if fb == 128 else None
+            with torch.cuda.device(x.device):
+                rc = lib.sngnn_linear_forward_normalized(xc.data_ptr(), wc.data_ptr(), _lib.ptr(bc), n, f, c,
+                                                         h.data_ptr(), unit.n.data_ptr(), unit.nrm.data_ptr(),
+                                                         _lib.ptr(unit.filt), _stream(x.device))
+            _lib.check(rc, "sngnn_linear_forward_normalized")
+            return h
         with torch.cuda.device(x.device):
-            rc = _lib.load().sngnn_linear_forward(xc.data_ptr(), wc.data_ptr(), _lib.ptr(bc), n, f, c,
-                                                  h.data_ptr(), _stream(x.device))
+            rc = lib.sngnn_linear_forward(xc.data_ptr(), wc.data_ptr(), _lib.ptr(bc), n, f, c,
+                                          h.data_ptr(), _stream(x.device))
         _lib.check(rc, "sngnn_linear_forward")
         return h
 
@@ -506,14 +557,14 @@ class _Linear(torch.autograd.Function):
             _lib.check(rc, "sngnn_linear_wgrad")
             gw = gw[:ctx.c]
             gb = None if gb is None else gb[:ctx.c]
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     """Apply ``lin`` with the hand-written weight gradient (fp32 GPU tensors), or
     plain ``lin(x)`` for anything else."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32:
-        return _Linear.apply(x, lin.weight, lin.bias, None, None)
+        return _Linear.apply(x, lin.weight, lin.bias, None, None, None)
     return lin(x)
 
 

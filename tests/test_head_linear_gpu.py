@@ -102,3 +102,73 @@ def test_blend_matches_the_reference_expression(cuda, n, c):
     # anything the fused path does not take falls back to the expression
     assert torch.equal(ops.blend(o0.detach()[:, : max(c - 1, 1)], o1.detach()[:, : max(c - 1, 1)], beta.detach()),
                        (beta * o0[:, : max(c - 1, 1)] + (1 - beta) * o1[:, : max(c - 1, 1)]).detach())
+
+
+@pytest.mark.parametrize("n,f,c", [(5000, 128, 40), (4097, 128, 32), (6000, 32, 40), (4500, 64, 64), (8191, 16, 8),
+                                   (5003, 128, 48), (4200, 64, 36), (4100, 128, 4)])
+def test_lin_normalising_epilogue_is_bitwise_the_normalisation_pass(cuda, n, f, c):
+    """sngnn_linear_forward_normalized (models.py:237-238 in one launch): h equals
+    sngnn_linear_forward's bit for bit, and the unit rows / norms / filter rows equal what
+    sngnn_normalize_rows_filter computes from that h - bit for bit, incl. duplicate rows, a zero
+    row and a row with one non-zero channel."""
+    from sngnn_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.sngnn_linear_normalized_supported(n, f, c)
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, f, generator=g)
+    x[5] = x[6]
+    x[9] = 0.0
+    w = torch.randn(c, f, generator=g) / f ** 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    b0 = torch.zeros(c)
+    for bias in (b, b0):
+        xd, wd, bd = x.to(cuda), w.to(cuda), bias.to(cuda)
+        st = torch.cuda.current_stream().cuda_stream
+        h_ref = torch.empty(n, c, device=cuda)
+        _lib.check(lib.sngnn_linear_forward(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, f, c, h_ref.data_ptr(), st), "lin")
+        h = torch.empty(n, c, device=cuda)
+        un = torch.full((n, c), float("nan"), device=cuda)
+        nrm = torch.full((n,), float("nan"), device=cuda)
+        fb = ops.filter_row_bytes(c)
+        filt = torch.full((n, fb), 0xAB, dtype=torch.uint8, device=cuda) if fb == 128 else None
+        _lib.check(lib.sngnn_linear_forward_normalized(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, f, c, h.data_ptr(),
+                                                       un.data_ptr(), nrm.data_ptr(), _lib.ptr(filt), st), "lin+norm")
+        assert torch.equal(h, h_ref)
+        un2, nrm2, filt2 = ops.normalize_rows_filter(h_ref)
+        assert torch.equal(un, un2) and torch.equal(nrm, nrm2)
+        if filt is not None:
+            assert torch.equal(filt, filt2)
+    # with a zero bias row 9 of h is zero: unit row 0, norm clamped at eps
+    assert (un[9] == 0).all() and float(nrm[9]) == pytest.approx(1e-12)
+
+
+def test_model_path_uses_the_epilogue_and_matches_the_pass(cuda):
+    """SNConv_plus on a graph big enough for the hand-written lin: the forward that takes the
+    unit rows from lin's epilogue equals the one that runs the normalisation pass, bit for bit,
+    and so do the gradients."""
+    import sngnn_amd
+    from sngnn_amd import ops
+    from tests.helpers import random_graph
+    n, f, c = 5000, 64, 40
+    ei = random_graph(n, 60000, seed=3, hubs=((0, 4000), (5, 900))).to(cuda)
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(1)).to(cuda)
+    gout = torch.randn(n, c, generator=torch.Generator().manual_seed(2)).to(cuda)
+    torch.manual_seed(0)
+    conv = sngnn_amd.SNConv_plus(f, c, n, top_k=8, thr=0.1).to(cuda)
+    seen = {}
+    orig = ops._forward_prepared
+    ops._forward_prepared = lambda *a, **k: (seen.__setitem__("prepared", True), orig(*a, **k))[1]
+    try:
+        out = conv(x, ei)
+        (out * gout).sum().backward()
+    finally:
+        ops._forward_prepared = orig
+    assert seen.get("prepared"), "the conv did not take the unit rows from lin's epilogue"
+    g1 = [p.grad.clone() for p in conv.parameters()]
+    conv.zero_grad()
+    h = ops.linear(x, conv.lin)
+    out2 = ops.aggregate(h, sngnn_amd.graph.GLOBAL_CACHE.get(ei, n, True, True), 8, 0.1)
+    (out2 * gout).sum().backward()
+    assert torch.equal(out, out2)
+    for a, p in zip(g1, conv.parameters()):
+        assert torch.equal(a, p.grad)

@@ -31,8 +31,19 @@ for F, C in ((128, 40), (128, 32), (32, 40), (64, 64), (16, 7)):
     lin = torch.nn.Linear(F, C).to(dev)
     g = torch.randn(N, C, device=dev)
     with torch.no_grad():
+        out0 = ops.linear(x, lin)
         t_f = timed(lambda: ops.linear(x, lin))
         t_b = timed(lambda: torch.nn.functional.linear(x, lin.weight, lin.bias))
+        if C % 4 == 0:       # the same launch with the F.normalize epilogue (unit rows + norms [+ filter rows])
+            def lin_norm(filt):
+                u = ops.UnitRows(filt)
+                ops._Linear.apply(x, lin.weight, lin.bias, None, None, u)
+                return u
+            t_n = timed(lambda: lin_norm(False))
+            t_nf = timed(lambda: lin_norm(True)) if C > 32 else float("nan")
+            t_pass = timed(lambda: ops.normalize_rows(out0))
+        else:
+            t_n = t_nf = t_pass = float("nan")
     out = ops.linear(x, lin)
 
     def wg():
@@ -41,7 +52,8 @@ for F, C in ((128, 40), (128, 32), (32, 40), (64, 64), (16, 7)):
     t_w = timed(wg, reps=50)
     mb_f = (N * F + N * C) * 4 / 1e6
     print(f"F={F:4d} C={C:3d}  lin fwd {t_f:6.1f} us (rocBLAS {t_b:6.1f}; {mb_f:.0f} MB -> {mb_f / 8e6 * 1e6:5.1f} us at 8 TB/s)"
-          f"   wgrad {t_w:6.1f} us", flush=True)
+          f"   wgrad {t_w:6.1f} us   | lin + normalise epilogue {t_n:6.1f} us (+ filter rows {t_nf:6.1f}); "
+          f"separate normalise pass {t_pass:5.1f} us", flush=True)
 
 C = 40
 z = torch.randn(N, C, device=dev)
