@@ -20,8 +20,13 @@ restatement in core torch of
     sites, each in its own function below.
 It is pinned by hand-derived known-answer tests (SURVEY.md Appendix B,
 tests/golden/kat_appendix_b.json), by a literal serial-loop C restatement of
-the same algorithms (oracle/sngnn_oracle.c) and by cross-checks between the
-vectorised and literal-loop forms - not by outputs of the reference itself.
+the same algorithms (oracle/sngnn_oracle.c), by cross-checks between the
+vectorised and literal-loop forms, and - tests/golden/pin_reference.py, build
+container only - by runs of the reference's OWN files: models/models.py under stub
+modules whose third-party functions are this file's restatements (the in-tree half
+of the conv path, bit for bit), and SimGFAToolbox/dense.py + sparse.py with the real
+scipy / scikit-learn (the toolbox section at the end of this file; fixtures
+tests/golden/toolbox_*.npz).  The third-party kernels themselves stay unpinned.
 
 Everything here runs on CPU tensors, fp32 values and int64 indices exactly as
 the reference's CPU path does.
