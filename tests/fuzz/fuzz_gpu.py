@@ -12,11 +12,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sngnn_oracle as O  # noqa: E402
-from sngnn_amd import ops  # noqa: E402
+from sngnn_amd import _lib, ops  # noqa: E402
 from sngnn_amd.graph import Graph, LOOPS_REPLACE  # noqa: E402
 from tests.helpers import check_selection, random_graph  # noqa: E402
 
 dev = torch.device("cuda:0")
+FILTER_MODE = int(os.environ.get("SNGNN_FUZZ_FILTER", "1"))      # 0 never / 1 auto / 2 always (csrc/agg_fwd_filter.h)
+_lib.load().sngnn_filter_enable(FILTER_MODE)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t_end = time.time() + budget
@@ -71,6 +73,25 @@ while time.time() < t_end:
                 gp = Graph(ei.to(dev), n, True, rem, row_range=(r0, r1))
                 outs.append(ops.aggregate_forward(gp, hg.detach(), k, thr)[0])
             assert torch.equal(torch.cat(outs), out.detach()), "partition != whole"
+        # --- the fp16 filter changes nothing (forced on vs off), and two row-filtered passes
+        #     with complementary flags equal one unrestricted forward (round 3)
+        if k is not None and ops.filter_row_bytes(C):
+            res = []
+            for mode in (2, 0):
+                _lib.load().sngnn_filter_enable(mode)
+                res.append(ops.aggregate_forward(g, hg.detach(), k, thr, save_for_backward=True)[:2])
+            _lib.load().sngnn_filter_enable(FILTER_MODE)
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "filter on != off"
+        if n >= 2:
+            o1, w1, i1, _, _ = ops.aggregate_forward(g, hg.detach(), k, thr, save_for_backward=True)
+            flag = torch.from_numpy(rng.integers(0, 2, size=n).astype(np.uint8)).to(dev)
+            un, nrm, filt = ops.normalize_rows_filter(hg.detach())
+            if filt is not None and not ops.filter_wanted(g, C, k, thr):
+                filt = None
+            o2, w2, i2 = torch.full_like(o1, float("nan")), torch.full_like(w1, float("nan")), torch.full_like(i1, float("nan"))
+            for want in (0, 1):
+                ops.aggregate_forward_rows(g, un, nrm, filt, k, thr, flag, want, o2, w2, i2)
+            assert torch.equal(o1, o2) and torch.equal(w1, w2) and torch.equal(i1, i2), "row-filtered passes != one pass"
         # --- attention mode
         hr2 = h.clone().requires_grad_(True)
         ra = O.attention_reference(hr2, ei)

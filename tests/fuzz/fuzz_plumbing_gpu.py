@@ -43,6 +43,23 @@ while time.time() < t_end:
         tol_w = 2e-6 * (gd.abs().t() @ xd.abs()) + 1e-7
         assert ((lin.weight.grad.double() - gd.t() @ xd).abs() <= tol_w).all(), "wgrad"
         assert ((lin.bias.grad.double() - gd.sum(0)).abs() <= 2e-6 * gd.abs().sum(0) + 1e-7).all(), "bias grad"
+        # lin with the F.normalize epilogue (round 3): h, unit rows, norms, filter rows bit for
+        # bit what the separate calls give
+        from sngnn_amd import _lib
+        lib = _lib.load()
+        if lib.sngnn_linear_normalized_supported(n, f, c):
+            st = torch.cuda.current_stream().cuda_stream
+            w_, b_ = lin.weight.detach().contiguous(), lin.bias.detach().contiguous()
+            h0 = torch.empty(n, c, device=dev)
+            _lib.check(lib.sngnn_linear_forward(x.data_ptr(), w_.data_ptr(), b_.data_ptr(), n, f, c, h0.data_ptr(), st), "lin")
+            h1, un, nrm = torch.empty(n, c, device=dev), torch.empty(n, c, device=dev), torch.empty(n, device=dev)
+            fb = ops.filter_row_bytes(c)
+            filt = torch.empty((n, fb), dtype=torch.uint8, device=dev) if fb == 128 else None
+            _lib.check(lib.sngnn_linear_forward_normalized(x.data_ptr(), w_.data_ptr(), b_.data_ptr(), n, f, c, h1.data_ptr(),
+                                                           un.data_ptr(), nrm.data_ptr(), _lib.ptr(filt), st), "lin+norm")
+            un2, nrm2, filt2 = ops.normalize_rows_filter(h0)
+            assert torch.equal(h0, h1) and torch.equal(un, un2) and torch.equal(nrm, nrm2), "normalising epilogue"
+            assert filt is None or torch.equal(filt, filt2), "filter rows of the epilogue"
         # head
         z = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
         y = torch.randint(0, c, (n,), generator=gen).to(dev)
