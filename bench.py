@@ -477,8 +477,14 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
         bw.append(ev[0].elapsed_time(ev[1]) / 10)
     bwd_ms = float(np.mean(bw[2:]))
     b_bwd = backward_bytes(e_prime, n_sel, n, c)
+    traffic = None
+    try:       # counter bytes per backward call of the committed PMC passes (arxiv, k 16 only)
+        if (e_prime, n, c, top_k) == (1163820, 169343, 40, 16):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("arxiv_k16_bwd")
+    except Exception:
+        traffic = None
     return {"bound": "hbm", "kernels": "k_bwd_clear + k_bwd_t + k_bwd_t_fin + k_bwd_s (one backward call)",
-            "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd,
+            "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd, "traffic": traffic,
             "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "timer": "torch events on the launch stream around batches of 10 backward calls"}
