@@ -199,7 +199,11 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
                            const uint8_t *row_flag, int row_want, float *out, float *wsel,
                            float *inv_norm, void *workspace, void *stream);
 /* measurement aid: knob 0 = row classes the main forward kernel runs (bit 0 split-row tasks,
- * 1 wave rows, 2 small rows; default 7 - anything else leaves the output incomplete) */
+ * 1 wave rows, 2 small rows; default 7 - anything else leaves the output incomplete);
+ * knob 2 = how sngnn_agg_forward scores: 0 (default) = on the fly from h when nothing is selected
+ * (top_k < 0) and through the normalisation pass + unit-row table otherwise; 1 = table always;
+ * 2 = on the fly always (fast cosine, exact normalise-then-dot wherever a decision is in doubt:
+ * the same selections, bit for bit) */
 int sngnn_tuning_set(int which, int value);
 /* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
 int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,

@@ -61,10 +61,17 @@ static int g_filter_mode = 1;
 // way); sngnn_tuning_set(0, mask) runs only some row classes of the main kernel (bit 0 split-row
 // tasks, 1 wave rows, 2 small rows; results are then incomplete - timing only)
 static int g_role_mask = 7;
+// how sngnn_agg_forward scores: 0 = auto (on the fly from h when nothing is selected - top_k < 0,
+// SNConv: 68 -> 58 us per forward at arxiv size, no normalisation pass, no table; the unit-row
+// table otherwise: for ranking rows one cheap pass over table rows beats a fast pass plus the
+// exact re-scoring of the candidates, 72.2 against 73.5 us at top_k 16 / thr 0), 1 = table
+// always, 2 = on the fly always (same selections, bit for bit)
+static int g_table_mode = 0;
 extern "C" int sngnn_tuning_set(int which, int value)
 {
-    SN_REQUIRE(which == 0, SNGNN_EINVAL, "unknown tuning knob");
-    g_role_mask = value & 7;
+    SN_REQUIRE(which == 0 || which == 2, SNGNN_EINVAL, "unknown tuning knob");
+    if (which == 0) g_role_mask = value & 7;
+    else g_table_mode = value;
     return SNGNN_OK;
 }
 
@@ -154,7 +161,12 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
 
     FwdArgs a;
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
-    a.filt = (const uint4 *)filt;
+    a.filt = nrm ? (const uint4 *)filt : nullptr;
+    // OTF (nrm == NULL, n = raw rows): bound on |fast cosine - reference-order cosine|.  Either
+    // value is within (2 C + 8) u of the real cosine (u = 2^-24: C products and sums of the dot,
+    // C / 2 + 3 for each norm, the scalings), so they differ by less than (4 C + 16) u; twice
+    // the margin on the constant term.
+    a.delta = (float)(4 * C + 32) * 5.9604644775390625e-8f;
     a.role_mask = g_role_mask;
     a.row_flag = row_flag; a.row_want = row_want;
     // row order: calls that stream the small rows (deg <= SMALL_T <= top_k, or no top_k) take the
@@ -235,6 +247,17 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(workspace != nullptr, SNGNN_EINVAL, "workspace is NULL");
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t *ev0 = g_prof_on ? g_prof_ev : nullptr;
+    void *scratch0 = (char *)workspace + fwd_table_bytes(g->Ntot, C);
+    if (g_table_mode == 2 || (g_table_mode == 0 && top_k < 0)) {
+        // on the fly: no normalisation pass, no table - the kernels gather h itself (FwdArgs)
+        if (ev0) {
+            SN_HIP(hipEventRecord(ev0[0], st));
+        }
+        return forward_normalized(g, cfg, h, nullptr, nullptr, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w,
+                                  scratch0, ev0 ? ev0 + 1 : nullptr, st);
+    }
+    // table mode (sngnn_tuning_set(2, 1)): the normalisation pass first.
     // workspace: unit rows [Ntot, C] | norms [Ntot] | fp16 filter rows | scratch of the split rows
     float *n = (float *)workspace;
     float *nrm = (float *)((char *)workspace + (g->Ntot * (int64_t)C * 4 + 255) / 256 * 256);
@@ -287,7 +310,9 @@ extern "C" int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, co
     RowCfg cfg;
     if (int rc = check_forward_args(g, n, C, top_k, out, nullptr, nullptr, cfg)) return rc;
     if (g->N == 0) return SNGNN_OK;
-    SN_REQUIRE(nrm != nullptr && row_flag != nullptr && workspace != nullptr, SNGNN_EINVAL, "nrm/row_flag/workspace is NULL");
+    // (nrm == NULL: n holds the RAW rows h and the call scores on the fly, like sngnn_agg_forward)
+    SN_REQUIRE(row_flag != nullptr && workspace != nullptr, SNGNN_EINVAL, "row_flag/workspace is NULL");
+    SN_REQUIRE(nrm != nullptr || filt == nullptr, SNGNN_EINVAL, "filter rows go with unit rows + norms");
     SN_REQUIRE(filt == nullptr || filter_row_bytes(C) > 0, SNGNN_EINVAL,
                "no filter rows for this C (sngnn_filter_row_bytes(C) == 0)");
     SN_REQUIRE(((uintptr_t)filt % 16) == 0, SNGNN_EINVAL, "filt must be 16-byte aligned");

@@ -107,12 +107,14 @@ __device__ __forceinline__ void filter_scores(const uint4 *__restrict__ filt, co
 
 // Which of the wave's n <= 128 approximately scored edges (two per lane: lane, lane + 64) must
 // be scored exactly.
-__device__ __forceinline__ void approx_candidates(const float *sc, int n, int k, float thr, bool &c0, bool &c1)
+// eps: the bound on |approximate - exact| of the scores in sc[]
+__device__ __forceinline__ void approx_candidates(const float *sc, int n, int k, float thr, float eps, bool &c0,
+                                                  bool &c1)
 {
     const int lane = lane_id();
     const int i0 = lane, i1 = lane + 64;
     const float s0 = i0 < n ? sc[i0] + 0.0f : 0.f, s1 = i1 < n ? sc[i1] + 0.0f : 0.f;
-    const float lo = thr - FILT_EPS;
+    const float lo = thr - eps;
     const bool v0 = i0 < n && s0 >= lo, v1 = i1 < n && s1 >= lo;
     const int cnt = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
     if (cnt <= k) { c0 = v0; c1 = v1; return; }
@@ -125,7 +127,7 @@ __device__ __forceinline__ void approx_candidates(const float *sc, int n, int k,
         if (c >= k) T = cand;
     }
     const float tk = __uint_as_float((T & 0x80000000u) ? (T & 0x7FFFFFFFu) : ~T);
-    const float cut = tk - 2.0f * FILT_EPS;
+    const float cut = tk - 2.0f * eps;
     c0 = v0 && s0 >= cut;
     c1 = v1 && s1 >= cut;
 }

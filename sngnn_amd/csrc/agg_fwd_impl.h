@@ -42,8 +42,17 @@
 namespace sngnn {
 
 struct FwdArgs {
-    const float *n;       // [Ntot, C] unit rows (k_normalize_rows)
-    const float *nrm;     // [Ntot]    max(|h|_2, eps)
+    // TABLE mode: n = unit rows [Ntot, C] (k_normalize_rows), nrm = max(|h|_2, eps) [Ntot].
+    // OTF mode (on the fly; nrm == nullptr): n = the RAW rows h themselves.  Every edge gets the
+    // fast cosine <h_i, h_j> inv_i inv_j (device_utils.h: edge_score), which differs from the
+    // reference-order value s = <h_i / d_i, h_j / d_j> by at most `delta`; wherever a decision
+    // cannot be taken from the fast value - within delta of thr, within 2 delta of the top_k-th or
+    // of another edge whose rank is asked for - the edge is scored again exactly (IEEE
+    // normalisation of the two rows in registers, the table path's dot), so selections, ties
+    // included, are those of the table path, bit for bit, without the normalisation pass.
+    const float *n;
+    const float *nrm;
+    float delta;          // OTF: bound on |fast - exact| (launcher: (4 C + 32) 2^-24)
     const uint4 *filt;    // [Ntot, filter_row_halfs(C)] fp16 filter rows (agg_fwd_filter.h) or nullptr
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
@@ -203,6 +212,33 @@ __device__ __forceinline__ float unit_dot(const Row<VEC, G, R> &a, const Row<VEC
     return group_sum<G>(a.dot_partial(x)) + 0.0f;
 }
 
+// F.normalize of a row held in registers - the instruction sequence of k_normalize_rows (same
+// fma chain, DPP tree, IEEE square root and division: the same bits); returns the clamped norm
+template <int VEC, int G, int R>
+__device__ __forceinline__ float normalize_in_place(Row<VEC, G, R> &x)
+{
+    const float q = group_sum<G>(x.dot_partial(x));
+    const float d = fmaxf(ieee_sqrt(q), EPS_NORM);
+    x.div_rn(d);
+    return d;
+}
+
+// the reference-order cosine of a UNIT target row and a RAW source row (OTF mode's exact score:
+// what the table path computes from its two table rows)
+template <int VEC, int G, int R>
+__device__ __forceinline__ float exact_score_raw(const Row<VEC, G, R> &nu, Row<VEC, G, R> x)
+{
+    normalize_in_place<VEC, G, R>(x);
+    return unit_dot<VEC, G, R>(nu, x);
+}
+
+// the G bits of a wave ballot that belong to lane group gid
+template <int G> __device__ __forceinline__ unsigned long long fwd_group_bits(unsigned long long m, int gid)
+{
+    if constexpr (G == 64) return m;
+    else return (m >> (gid * G)) & ((1ull << G) - 1ull);
+}
+
 // ---------------------------------------------------------------------------
 // Wave-level top-k of up to 128 selection keys, two per lane (0 = no key).
 // Keys are unique, so "the k largest" is well defined: bitwise search for the
@@ -270,7 +306,7 @@ __device__ __forceinline__ WaveSel wave_select(const float *sc, int n, int base,
 // ---------------------------------------------------------------------------
 // One set of 64/G small rows (one per lane group) whose column ids are already in
 // LDS (s_col[gid][t]).  d = this group's row descriptor (deg 0 for a padding slot).
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool OTF>
 __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, bool valid,
                                                int *lds_wave, const int *s_col_set)
 {
@@ -292,6 +328,11 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
     RowT ni;
     ni.load(a.n + (size_t)self * a.C, a.C, lg);
     const int dmax = wave_max_i(deg);
+    float inv_i = 0.f, q_i = 0.f;
+    if constexpr (OTF) {
+        q_i = group_sum<G>(ni.dot_partial(ni));
+        inv_i = inv_norm_of(q_i);
+    }
 
     RowT acc;
     acc.zero();
@@ -302,11 +343,27 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
         for (int u = 0; u < U; ++u) {
             const int j = (t0 + u) < deg ? s_col[t0 + u] : self;
             x[u].load(a.n + (size_t)j * a.C, a.C, lg);
-            nj[u] = rank ? 0.f : a.nrm[j];        // a streaming row weighs the row it has just scored
+            if constexpr (OTF) nj[u] = 1.f;
+            else nj[u] = rank ? 0.f : a.nrm[j];   // a streaming row weighs the row it has just scored
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = unit_dot<VEC, G, R>(ni, x[u]);
+            float s;
+            if constexpr (OTF) {
+                s = edge_score<VEC, G, R>(ni, inv_i, x[u]);
+                if (a.k >= 0 && !rank) {
+                    // the threshold decides this edge: exact where the fast value cannot tell
+                    const bool amb = (t0 + u < deg) && fabsf(s - a.thr) <= a.delta;
+                    if (__ballot(amb) != 0ull) {                 // (wave-uniform; rare)
+                        RowT nu = ni;
+                        normalize_in_place<VEC, G, R>(nu);
+                        const float se = exact_score_raw<VEC, G, R>(nu, x[u]);
+                        if (amb) s = se;
+                    }
+                }
+            } else {
+                s = unit_dot<VEC, G, R>(ni, x[u]);
+            }
             if (t0 + u < deg) {
                 if (need_sc && lg == 0) s_sc[t0 + u] = s;
                 if (!rank) {
@@ -317,7 +374,45 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
             }
         }
     }
-    if (a.inv_norm && valid && lg == 0) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    if (a.inv_norm && valid && lg == 0) {
+        if constexpr (OTF) a.inv_norm[i] = ieee_div(1.0f, fmaxf(ieee_sqrt(q_i), EPS_NORM));
+        else a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    }
+
+    if constexpr (OTF) {
+        if (need_sc) {
+            // ranks are asked for: wherever two fast scores of a row (or one and thr) are too close
+            // to order, the whole row (<= 16 edges, cache-hot) is scored again exactly
+            wave_lds_sync();
+            bool amb = false;
+            for (int e = lg; e < deg; e += G) {
+                const float se = s_sc[e];
+                // edges surely above / possibly above this one: its side of the top_k cut is in
+                // doubt iff the cut falls between the two counts (ranks emitted: any near pair)
+                int above = 0, maybe = 0;
+                for (int b = 0; b < deg; ++b) {
+                    const float sb = s_sc[b];
+                    above += sb > se + 2.0f * a.delta;
+                    maybe += (b != e) && sb >= se - 2.0f * a.delta;
+                }
+                amb |= emit ? (maybe > above) : (above < a.k && maybe >= a.k);
+                amb |= above < a.k && fabsf(se - a.thr) <= a.delta;
+            }
+            const bool row_amb = fwd_group_bits<G>(__ballot(amb), gid) != 0ull;
+            if (__ballot(row_amb) != 0ull) {                         // (wave-uniform)
+                RowT nu = ni;
+                normalize_in_place<VEC, G, R>(nu);
+                const int dm = wave_max_i(row_amb ? deg : 0);
+                for (int t = 0; t < dm; ++t) {
+                    const bool live = row_amb && t < deg;
+                    RowT xr;
+                    xr.load(a.n + (size_t)(live ? s_col[t] : self) * a.C, a.C, lg);
+                    const float se = exact_score_raw<VEC, G, R>(nu, xr);
+                    if (live && lg == 0) s_sc[t] = se;
+                }
+            }
+        }
+    }
 
     if (need_sc) {
         wave_lds_sync();
@@ -347,7 +442,8 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
                     const int j = s_col[t];
                     RowT xr;
                     xr.load(a.n + (size_t)j * a.C, a.C, lg);
-                    acc.axpy(w * a.nrm[j], xr);
+                    if constexpr (OTF) acc.axpy(w, xr);
+                    else acc.axpy(w * a.nrm[j], xr);
                 }
             }
         }
@@ -365,7 +461,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 // current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool OTF>
 __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
@@ -418,7 +514,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
         if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull)
-            small_rows_set<VEC, G, R>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+            small_rows_set<VEC, G, R, OTF>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
         store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
@@ -438,17 +534,25 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
 //           sc[t - sc_off]  (never form an out-of-range LDS pointer: LDS pointer
 //           arithmetic is 32-bit and does not survive the cast to a flat address)
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R>
+//   OTF: ni is the RAW target row, inv_i its fast inverse norm.  Scores are the fast cosine,
+//           except: a streaming edge within delta of thr is scored exactly; with exact_all EVERY
+//           edge is (the paths that rank from scores in HBM scratch: top_k > CAND_MAX_K, hubs
+//           beyond the candidate finalize, ranks of a streaming split row).
+template <int VEC, int G, int R, bool OTF>
 __device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, int e0, int e1,
-                                            const Row<VEC, G, R> &ni, bool stream,
+                                            const Row<VEC, G, R> &ni, float inv_i, bool stream,
                                             float *sc, int sc_off, Row<VEC, G, R> &acc,
-                                            int *ids_lds = nullptr)
+                                            int *ids_lds = nullptr, bool exact_all = false)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
     constexpr int U = Unroll<R>::U;
     const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
+    RowT nu;                                   // OTF + exact_all: the unit target row
+    if constexpr (OTF) {
+        if (exact_all) { nu = ni; normalize_in_place<VEC, G, R>(nu); }
+    }
     // column ids one iteration ahead: the col -> row dependency of iteration n+1
     // overlaps the row loads of iteration n
     int jn[U];
@@ -471,7 +575,8 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             x[u].load(a.n + (size_t)j[u] * a.C, a.C, lg);
-            nj[u] = stream ? a.nrm[j[u]] : 0.f;
+            if constexpr (OTF) nj[u] = 1.f;
+            else nj[u] = stream ? a.nrm[j[u]] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -480,7 +585,25 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = unit_dot<VEC, G, R>(ni, x[u]);
+            float s;
+            if constexpr (OTF) {
+                if (exact_all) {
+                    s = exact_score_raw<VEC, G, R>(nu, x[u]);
+                } else {
+                    s = edge_score<VEC, G, R>(ni, inv_i, x[u]);
+                    if (stream && a.k >= 0) {
+                        const bool amb = act[u] && fabsf(s - a.thr) <= a.delta;
+                        if (__ballot(amb) != 0ull) {             // (wave-uniform; rare)
+                            RowT nt = ni;
+                            normalize_in_place<VEC, G, R>(nt);
+                            const float se = exact_score_raw<VEC, G, R>(nt, x[u]);
+                            if (amb) s = se;
+                        }
+                    }
+                }
+            } else {
+                s = unit_dot<VEC, G, R>(ni, x[u]);
+            }
             if (act[u]) {
                 if (sc && lg == 0) sc[t[u] - sc_off] = s;
                 if (ids_lds && lg == 0) ids_lds[t[u] - sc_off] = j[u];      // for the re-gather of the kept rows
@@ -497,7 +620,8 @@ __device__ __forceinline__ void score_edges(const FwdArgs &a, int self, int rs, 
 // Exact scores of the listed edges (list[q] = chunk-local edge index, ids[idx] = its source):
 // sc[idx] = <n_i, n_j>.  U rows per lane group in flight; a slot past the end repeats the
 // last listed edge and stores nothing.
-template <int VEC, int G, int R>
+// (OTF: ni is the UNIT target row, the listed rows are raw and are normalised in registers)
+template <int VEC, int G, int R, bool OTF>
 __device__ __forceinline__ void score_list(const FwdArgs &a, const Row<VEC, G, R> &ni, const int *list, int ncand,
                                            const int *ids, float *sc)
 {
@@ -520,35 +644,88 @@ __device__ __forceinline__ void score_list(const FwdArgs &a, const Row<VEC, G, R
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float s = unit_dot<VEC, G, R>(ni, x[u]);
+            float s;
+            if constexpr (OTF) s = exact_score_raw<VEC, G, R>(ni, x[u]);
+            else s = unit_dot<VEC, G, R>(ni, x[u]);
             if (q0 + u * NG + gid < ncand && lg == 0) sc[idx[u]] = s;
         }
     }
 }
 
-// The filtered form of "score the edges [e0, e1) and select" for a ranking row (deg > top_k):
-// approximate scores of all n = e1 - e0 <= 128 edges from the fp16 filter rows, exact scores
-// of the candidates only (agg_fwd_filter.h), exact selection among them.  On return sc[t]
-// holds the exact score of every candidate (in particular of every kept edge), ids[t] the
-// source of every edge, and the returned keys / flags are what wave_select would have given
-// on exact scores of all edges.  list[] is scratch.
-template <int VEC, int G, int R>
-__device__ __forceinline__ WaveSel filtered_select(const FwdArgs &a, const Row<VEC, G, R> &ni, int self, int rs,
-                                                   int e0, int e1, float *sc, int *list, int *ids, int lowbits)
+// "Score the edges [e0, e1) of a ranking row and select" in two precisions: approximate scores
+// of all n = e1 - e0 <= 128 edges, exact scores of the CANDIDATES only - the edges within
+// 2 eps of the top_k-th approximate score and not below thr - eps, where eps bounds
+// |approximate - exact| (agg_fwd_filter.h has the argument) - and the exact selection among them.
+//   FILT: approximate = fp16 filter rows (eps = FILT_EPS), exact = table rows;
+//   OTF:  approximate = the fast cosine of the raw rows (eps = a.delta), exact = rows normalised
+//         in registers; ni = raw target row, inv_i its fast inverse norm.
+// On return sc[t] holds the exact score of every candidate (in particular of every kept edge),
+// ids[t] the source of every edge, and the returned keys / flags are what wave_select would have
+// given on exact scores of all edges.  list[] is scratch.
+//   OTF, optimistic = true: the selection is first made on the fast scores alone and kept when it
+//         is beyond doubt - no edge within delta of thr, and the weakest kept edge more than
+//         2 delta above the strongest valid edge left out (then the exact scores would select
+//         the same set; the kept edges' weights are the fast values, within delta of the exact
+//         ones).  Only a row that fails this test - ties and near ties at the cut - takes the
+//         candidate path.  (Not for split-row tasks: their keys are merged with other tasks'
+//         keys by the finalize, which needs them exact; not when ranks are emitted.)
+template <int VEC, int G, int R, bool OTF>
+__device__ __forceinline__ WaveSel banded_select(const FwdArgs &a, const Row<VEC, G, R> &ni, float inv_i, int self,
+                                                 int rs, int e0, int e1, float *sc, int *list, int *ids, int lowbits,
+                                                 bool optimistic = false)
 {
-    constexpr int GF = G * R / 2;                    // 16-byte lanes per filter row (VEC == 4)
+    using RowT = Row<VEC, G, R>;
     const int lane = lane_id();
     const int n = e1 - e0;
-    filter_scores<GF>(a.filt, a.col, self, rs, e0, e1, sc, ids);
+    float eps;
+    if constexpr (OTF) {
+        RowT unused;
+        unused.zero();
+        score_edges<VEC, G, R, true>(a, self, rs, e0, e1, ni, inv_i, false, sc, e0, unused, ids);
+        eps = a.delta;
+    } else {
+        constexpr int GF = G * R / 2;                // 16-byte lanes per filter row (VEC == 4)
+        filter_scores<GF>(a.filt, a.col, self, rs, e0, e1, sc, ids);
+        eps = FILT_EPS;
+    }
     wave_lds_sync();
+    if constexpr (OTF) {
+        if (optimistic) {
+            const int i0 = lane, i1 = lane + 64;
+            const float f0 = i0 < n ? sc[i0] + 0.0f : 0.f, f1 = i1 < n ? sc[i1] + 0.0f : 0.f;
+            WaveSel r;
+            r.key0 = (i0 < n && f0 >= a.thr) ? sel_key(f0, e0 + i0) : 0ull;
+            r.key1 = (i1 < n && f1 >= a.thr) ? sel_key(f1, e0 + i1) : 0ull;
+            wave_topk_keys(r.key0, r.key1, a.k, lowbits, r.kept0, r.kept1);
+            bool doubt = (i0 < n && fabsf(f0 - a.thr) <= eps) || (i1 < n && fabsf(f1 - a.thr) <= eps);
+            // weakest kept against strongest valid edge left out
+            float kmin = fminf(r.kept0 ? f0 : INFINITY, r.kept1 ? f1 : INFINITY);
+            float umax = fmaxf((r.key0 != 0ull && !r.kept0) ? f0 : -INFINITY, (r.key1 != 0ull && !r.kept1) ? f1 : -INFINITY);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                kmin = fminf(kmin, __shfl_xor(kmin, m, 64));
+                umax = fmaxf(umax, __shfl_xor(umax, m, 64));
+            }
+            doubt = doubt || (kmin - umax <= 2.0f * eps);      // (umax = -inf: nothing was left out)
+            if (__ballot(doubt) == 0ull) return r;
+        }
+    }
     bool c0, c1;
-    approx_candidates(sc, n, a.k, a.thr, c0, c1);
+    approx_candidates(sc, n, a.k, a.thr, eps, c0, c1);
     const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
     const int n0 = __popcll(m0), ncand = n0 + __popcll(m1);
     if (c0) list[prefix_popc(m0)] = lane;
     if (c1) list[n0 + prefix_popc(m1)] = lane + 64;
     wave_lds_sync();
-    if (ncand > 0) score_list<VEC, G, R>(a, ni, list, ncand, ids, sc);
+    if (ncand > 0) {
+        if constexpr (OTF) {
+            RowT nu = ni;
+            normalize_in_place<VEC, G, R>(nu);
+            score_list<VEC, G, R, true>(a, nu, list, ncand, ids, sc);
+        } else {
+            score_list<VEC, G, R, false>(a, ni, list, ncand, ids, sc);
+        }
+    }
     wave_lds_sync();
     WaveSel r;
     const float s0 = c0 ? sc[lane] : 0.f, s1 = c1 ? sc[lane + 64] : 0.f;
@@ -561,7 +738,7 @@ __device__ __forceinline__ WaveSel filtered_select(const FwdArgs &a, const Row<V
 // ---------------------------------------------------------------------------
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool FILT>
+template <int VEC, int G, int R, bool FILT, bool OTF>
 __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -583,19 +760,27 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 
     RowT ni;
     ni.load(a.n + (size_t)self * a.C, a.C, lg);
+    float inv_i = 0.f, q_i = 0.f;
+    if constexpr (OTF) {
+        q_i = group_sum<G>(ni.dot_partial(ni));
+        inv_i = inv_norm_of(q_i);
+    }
 
     RowT acc;
     acc.zero();
-    const bool filtered = FILT && rank;
-    if (!filtered)
-        score_edges<VEC, G, R>(a, self, rs, 0, deg, ni, !rank, need_sc ? s_sc : nullptr, 0, acc,
-                               rank ? s_ids : nullptr);
+    // two-precision selection: the filter for ranking rows; OTF whenever scores are kept (ranks
+    // asked for on a streaming row included: their order needs exact scores too)
+    const bool banded = OTF ? need_sc : (FILT && rank);
+    if (!banded)
+        score_edges<VEC, G, R, OTF>(a, self, rs, 0, deg, ni, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc,
+                                    rank ? s_ids : nullptr);
 
     if (need_sc) {
         WaveSel ws;
-        if constexpr (FILT) {
-            if (filtered) {
-                ws = filtered_select<VEC, G, R>(a, ni, self, rs, 0, deg, s_sc, s_list, s_ids, 7);
+        if constexpr (FILT || OTF) {
+            if (banded) {
+                ws = banded_select<VEC, G, R, OTF>(a, ni, inv_i, self, rs, 0, deg, s_sc, s_list, s_ids, 7,
+                                                   /*optimistic=*/OTF && !emit);
             } else {
                 wave_lds_sync();
                 ws = wave_select(s_sc, deg, 0, a.k, a.thr, 7);
@@ -611,7 +796,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
         if (ws.kept0) s_list[prefix_popc(m0)] = i0;
         if (ws.kept1) s_list[n0 + prefix_popc(m1)] = i1;
         const int nsel = n0 + __popcll(m1);
-        if (rank && a.wsel) {
+        if ((rank || banded) && a.wsel) {
             if (i0 < deg) a.wsel[rs + i0] = ws.kept0 ? s_sc[i0] : SNGNN_UNSELECTED;
             if (i1 < deg) a.wsel[rs + i1] = ws.kept1 ? s_sc[i1] : SNGNN_UNSELECTED;
         }
@@ -628,7 +813,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
                 }
             }
         }
-        if (rank && nsel > 0) {
+        if ((rank || banded) && nsel > 0) {
             // the kept rows again, U per lane group in flight, unconditionally (a slot past the
             // end repeats the last kept edge with weight 0): their column ids wait in LDS, so
             // this is ONE memory round trip instead of a col -> row chain per kept edge
@@ -643,7 +828,8 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
                     const int j = s_ids[idx];
                     w[u] = q < nsel ? s_sc[idx] : 0.f;
                     x[u].load(a.n + (size_t)j * a.C, a.C, lg);
-                    nj[u] = a.nrm[j];
+                    if constexpr (OTF) nj[u] = 1.f;
+                    else nj[u] = a.nrm[j];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc.axpy(w[u] * nj[u], x[u]);
@@ -657,14 +843,17 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     }
     // (stored at the END of the row: a store up front would pin the scoring pass's first
     // column-id loads behind it - the pointers are not restrict)
-    if (lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    if (lane == 0 && a.inv_norm) {
+        if constexpr (OTF) a.inv_norm[i] = ieee_div(1.0f, fmaxf(ieee_sqrt(q_i), EPS_NORM));
+        else a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    }
     wave_lds_sync();            // the wave's LDS scratch is reused by its next item
 }
 
 // ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool FILT>
+template <int VEC, int G, int R, bool FILT, bool OTF>
 __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -682,20 +871,29 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 
     RowT ni;
     ni.load(a.n + (size_t)self * a.C, a.C, lg);
-    if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    float inv_i = 0.f;
+    if constexpr (OTF) {
+        const float q_i = group_sum<G>(ni.dot_partial(ni));
+        inv_i = inv_norm_of(q_i);
+        if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, fmaxf(ieee_sqrt(q_i), EPS_NORM));
+    } else {
+        if (c == 0 && lane == 0 && a.inv_norm) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+    }
 
     RowT acc;
     acc.zero();
     float *s_sc = reinterpret_cast<float *>(lds_wave);          // [CHUNK], chunk-local
     float *sc_glb = (!cand && (rank || emit)) ? a.scores + a.split_soff[p] : nullptr;   // HBM scratch
-    if (FILT && cand) { /* scored below, through the filter */ }
-    else if (cand) score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, s_sc, e0, acc);     // LDS
-    else score_edges<VEC, G, R>(a, self, rs, e0, e1, ni, !rank, sc_glb, 0, acc);             // HBM / none
+    if ((FILT || OTF) && cand) { /* scored below, in two precisions */ }
+    else if (cand) score_edges<VEC, G, R, OTF>(a, self, rs, e0, e1, ni, inv_i, !rank, s_sc, e0, acc);   // LDS
+    // HBM scratch (ranked later from those scores: OTF writes exact ones) / none (pure streaming)
+    else score_edges<VEC, G, R, OTF>(a, self, rs, e0, e1, ni, inv_i, !rank, sc_glb, 0, acc, nullptr,
+                                     /*exact_all=*/sc_glb != nullptr);
     if (cand) {
         WaveSel ws;
-        if constexpr (FILT) {
-            ws = filtered_select<VEC, G, R>(a, ni, self, rs, e0, e1, s_sc, lds_wave + CHUNK, lds_wave + 2 * CHUNK,
-                                            a.lowbits);
+        if constexpr (FILT || OTF) {
+            ws = banded_select<VEC, G, R, OTF>(a, ni, inv_i, self, rs, e0, e1, s_sc, lds_wave + CHUNK,
+                                               lds_wave + 2 * CHUNK, a.lowbits);
         } else {
             wave_lds_sync();
             ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
@@ -724,9 +922,10 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // Persistent waves: wave w of the grid takes work items w, w + n_waves, ... of the
 // list [split-row tasks | wave rows | small-row sets], each class in order of
 // descending degree, so every wave gets a similar mix and the grid drains evenly.
-template <int VEC, int G, int R, bool FILT>
+template <int VEC, int G, int R, bool FILT, bool OTF>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
+    static_assert(!(FILT && OTF), "the filter belongs to the table mode");
     __shared__ __align__(16) int lds[WAVES][WaveLds<G>::WORDS];
     const int wave = threadIdx.x >> 6;
     int *lw = lds[wave];
@@ -734,14 +933,14 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
     for (; it < a.n_tasks; it += nw)
-        if (a.role_mask & 1) role_task<VEC, G, R, FILT>(a, a.task_order[it], lw);
+        if (a.role_mask & 1) role_task<VEC, G, R, FILT, OTF>(a, a.task_order[it], lw);
     it -= a.n_tasks;
     for (; it < n_wave_rows; it += nw)
-        if (a.role_mask & 2) role_wave<VEC, G, R, FILT>(a, it, lw);
+        if (a.role_mask & 2) role_wave<VEC, G, R, FILT, OTF>(a, it, lw);
     it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    if (a.role_mask & 4) role_small<VEC, G, R>(a, it, nw, nsets, lw);
+    if (a.role_mask & 4) role_small<VEC, G, R, OTF>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -877,7 +1076,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
                 const int j = a.col[rs + idx];
                 RowT x;
                 x.load(a.n + (size_t)j * a.C, a.C, lg);
-                acc.axpy(sc[idx] * a.nrm[j], x);
+                acc.axpy(sc[idx] * (a.nrm ? a.nrm[j] : 1.0f), x);        // (OTF: the rows are h itself)
             }
         }
         acc.reduce_across_groups();
@@ -1014,7 +1213,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
             const int j = wsrc[q];
             RowT x;
             x.load(a.n + (size_t)j * a.C, a.C, lg);
-            acc.axpy(key_score(win[q]) * a.nrm[j], x);
+            acc.axpy(key_score(win[q]) * (a.nrm ? a.nrm[j] : 1.0f), x);
         }
     }
     for (int q = tid; q < nsel; q += FINC_BLOCK) {
@@ -1100,7 +1299,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
             const int w = min(w0 + u * NG + gid, nsel - 1);
             const int j = s_src_w[w];
             x[u].load(a.n + (size_t)j * a.C, a.C, lg);
-            nj[u] = a.nrm[j];
+            nj[u] = a.nrm ? a.nrm[j] : 1.0f;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -1230,11 +1429,13 @@ int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStrea
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     for (int rep = 0; rep < reps && grid > 0; ++rep) {
-        if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
-            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true><<<grid, BLOCK, 0, st>>>(a);
-            else k_agg_fwd<VEC, G, R, false><<<grid, BLOCK, 0, st>>>(a);
+        if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
+            k_agg_fwd<VEC, G, R, false, true><<<grid, BLOCK, 0, st>>>(a);
+        } else if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
+            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false><<<grid, BLOCK, 0, st>>>(a);
+            else k_agg_fwd<VEC, G, R, false, false><<<grid, BLOCK, 0, st>>>(a);
         } else {
-            k_agg_fwd<VEC, G, R, false><<<grid, BLOCK, 0, st>>>(a);
+            k_agg_fwd<VEC, G, R, false, false><<<grid, BLOCK, 0, st>>>(a);
         }
     }
     if (ev) SN_HIP(hipEventRecord(ev[1], st));

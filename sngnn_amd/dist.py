@@ -328,18 +328,22 @@ class _HaloAggregate(torch.autograd.Function):
         pending = start_halo_exchange(table, plan)
         need_grad = ctx.needs_input_grad[0]
         dev = table.device
-        unit = torch.empty_like(table)
-        nrm = torch.empty(table.size(0), dtype=torch.float32, device=dev)
-        fb = ops.filter_row_bytes(c) if ops.filter_wanted(graph, c, top_k, thr) else 0
-        filt = torch.empty((table.size(0), fb), dtype=torch.uint8, device=dev) if fb else None
         out = torch.empty((n_loc, c), dtype=torch.float32, device=dev)
         wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=dev) if need_grad else None
         inv = torch.empty(n_loc, dtype=torch.float32, device=dev) if need_grad else None
-        ops.normalize_rows_into(table[:n_loc], unit[:n_loc], nrm[:n_loc], None if filt is None else filt[:n_loc])
+        on_the_fly = top_k is None          # nothing is selected: scored straight from h (as sngnn_agg_forward does)
+        if on_the_fly:
+            unit, nrm, filt = table, None, None
+        else:
+            unit = torch.empty_like(table)
+            nrm = torch.empty(table.size(0), dtype=torch.float32, device=dev)
+            fb = ops.filter_row_bytes(c) if ops.filter_wanted(graph, c, top_k, thr) else 0
+            filt = torch.empty((table.size(0), fb), dtype=torch.uint8, device=dev) if fb else None
+            ops.normalize_rows_into(table[:n_loc], unit[:n_loc], nrm[:n_loc], None if filt is None else filt[:n_loc])
         if plan.n_boundary < n_loc:
             ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 0, out, wsel, inv)
         pending.wait()
-        if plan.n_halo:
+        if plan.n_halo and not on_the_fly:
             ops.normalize_rows_into(table[n_loc:], unit[n_loc:], nrm[n_loc:], None if filt is None else filt[n_loc:])
         if plan.n_boundary:
             ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 1, out, wsel, inv)

@@ -120,7 +120,9 @@ def aggregate_forward_rows(graph: Graph, n: torch.Tensor, nrm: torch.Tensor, fil
                            out: torch.Tensor, wsel: Optional[torch.Tensor] = None,
                            inv: Optional[torch.Tensor] = None) -> None:
     """``sngnn_agg_forward_rows``: the aggregation of the target rows whose ``row_flag`` (uint8 [N])
-    equals ``want``, written into the caller's ``out`` / ``wsel`` / ``inv``; other rows untouched."""
+    equals ``want``, written into the caller's ``out`` / ``wsel`` / ``inv``; other rows untouched.
+    ``nrm=None``: ``n`` holds the RAW rows h and the call scores on the fly (what
+    ``sngnn_agg_forward`` does by itself when nothing is selected, top_k None)."""
     c = n.size(1)
     k = -1 if top_k is None else int(top_k)
     if row_flag.dtype != torch.uint8 or row_flag.numel() != graph.num_nodes or not row_flag.is_contiguous():
@@ -129,7 +131,7 @@ def aggregate_forward_rows(graph: Graph, n: torch.Tensor, nrm: torch.Tensor, fil
         raise ValueError("n must hold one row per feature-table row and out one per owned row")
     ws = graph.workspace(c)
     with torch.cuda.device(n.device):
-        rc = _lib.load().sngnn_agg_forward_rows(graph.handle, n.data_ptr(), nrm.data_ptr(), _lib.ptr(filt), c, k,
+        rc = _lib.load().sngnn_agg_forward_rows(graph.handle, n.data_ptr(), _lib.ptr(nrm), _lib.ptr(filt), c, k,
                                                 float(thr), row_flag.data_ptr(), int(want), out.data_ptr(),
                                                 _lib.ptr(wsel), _lib.ptr(inv), ws.data_ptr(), _stream(n.device))
     _lib.check(rc, "sngnn_agg_forward_rows")

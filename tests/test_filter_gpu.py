@@ -112,6 +112,8 @@ def test_row_filtered_passes_equal_one_pass(cuda, c, k, thr):
     un, nrm, filt = ops.normalize_rows_filter(h)
     if filt is not None and not ops.filter_wanted(g, c, k, thr):
         filt = None
+    if k is None:                                 # nothing selected: sngnn_agg_forward scores on the fly from h
+        un, nrm, filt = h, None, None
     out2 = torch.full_like(out, float("nan"))
     wsel2 = torch.full_like(wsel, float("nan"))
     inv2 = torch.full_like(inv, float("nan"))
@@ -120,3 +122,49 @@ def test_row_filtered_passes_equal_one_pass(cuda, c, k, thr):
         if want == 0:                             # the other side's rows are untouched so far
             assert torch.isnan(out2[flag.bool()]).all() and not torch.isnan(out2[~flag.bool()]).any()
     assert torch.equal(out2, out) and torch.equal(wsel2, wsel) and torch.equal(inv2, inv)
+
+
+OTF_CASES = [
+    # n, e, C, hubs, top_k, thr, kind
+    (3000, 60000, 40, ((0, 2999), (3, 900), (9, 300)), 16, 0.0, "normal"),
+    (3000, 60000, 40, ((0, 2999), (3, 900)), 1, 0.99, "normal"),
+    (2000, 50000, 40, ((1, 1500),), 10, 0.0, "parallel"),       # every cosine within 1e-3 of 1: doubt everywhere
+    (2000, 50000, 8, ((1, 1500),), 4, 0.0, "sparse"),           # many duplicate / zero rows: exact ties
+    (1500, 40000, 48, ((2, 1400), (7, 200)), 40, -1.0, "normal"),   # top_k > 32: scores through HBM scratch
+    (1200, 30000, 7, ((2, 1100),), 3, 0.5, "tiny"),
+    (1000, 30000, 1, ((4, 999),), 5, -0.5, "normal"),           # C == 1: every cosine is exactly +-1
+    (1000, 30000, 40, ((4, 999),), None, 0.0, "normal"),        # SNConv: on the fly is the default
+    (900, 20000, 64, ((4, 800),), 300, 0.2, "sparse"),          # streaming split rows
+]
+
+
+@pytest.mark.parametrize("n,e,c,hubs,k,thr,kind", OTF_CASES)
+def test_scoring_on_the_fly_selects_what_the_table_selects(cuda, n, e, c, hubs, k, thr, kind):
+    """sngnn_tuning_set(2, mode): scoring straight from h (fast cosine; exact normalise-then-dot
+    wherever a decision is within the error bound) against the normalisation pass + unit-row
+    table: saved selections (wsel: which edges, exact-tie order included) identical, outputs
+    equal to rounding (the kept edges' weights are fast values)."""
+    from sngnn_amd import _lib, ops
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    ei = random_graph(n, e, seed=n + c, hubs=hubs).to(cuda)
+    h = _rows(n, c, 11 * c + (k or 0), kind).to(cuda)
+    h[11] = h[12] * 2.0                        # power-of-two multiple: same unit row
+    g = Graph(ei, n, True, k is not None)
+    res = {}
+    try:
+        for mode in (1, 2):                    # table always / on the fly always
+            lib.sngnn_tuning_set(2, mode)
+            out, wsel, inv, _, _ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+            sel = ops.aggregate_forward(g, h, k, thr, want_selection=True)[3] if k else None
+            res[mode] = (out, wsel, inv, sel)
+    finally:
+        lib.sngnn_tuning_set(2, 0)
+    kept1, kept2 = res[1][1] > -3.0, res[2][1] > -3.0
+    assert torch.equal(kept1, kept2)
+    assert torch.equal(res[1][2], res[2][2])                         # inverse norms: same IEEE formula
+    if k:
+        assert torch.equal(res[1][3], res[2][3])                     # selected sources in rank order
+    w1, w2 = res[1][1][kept1], res[2][1][kept2]
+    assert (w1 - w2).abs().max() <= 2e-5 if w1.numel() else True     # weights: fast vs exact
+    assert (res[1][0] - res[2][0]).abs().max() <= 2e-5 * max(1.0, float(res[1][0].abs().max()))
