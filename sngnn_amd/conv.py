@@ -140,9 +140,9 @@ class SNConv(nn.Module):
 
     def forward(self, x, edge_index):
         graph, shard = _graph_for(x, edge_index, True, False)
-        unit = ops.UnitRows(False)
-        h, c, table = _lin_aligned(x, self.lin, shard, unit)
-        out = _true_width(_aggregate(h, graph, shard, None, 0.0, table, unit), c)
+        # (no selection: the aggregation scores straight from h - no unit rows wanted from lin)
+        h, c, table = _lin_aligned(x, self.lin, shard)
+        out = _true_width(_aggregate(h, graph, shard, None, 0.0, table), c)
         if self.bias is not None:
             out = out + self.bias
         return out
