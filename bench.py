@@ -23,11 +23,11 @@ aggregation + blend - at C = 48 (47 classes padded to 16-byte rows).
 
 The line's keys (beyond the driver's contract):
   roofline        dominant kernel k_agg_fwd: SURVEY.md 8d's algorithmic bytes of one launch over its
-                  average launch duration, HIP events on the launch stream around BATCHES of 20
-                  back-to-back launches recorded inside the library (sngnn_profile_enable(20)), nothing
-                  subtracted; the single-launch event interval and the committed rocprofv3 average of
-                  the same command are printed beside it (kernel_ms_single_launch_events,
-                  kernel_ms_rocprofv3).  traffic = counter bytes per launch of the committed PMC
+                  average launch duration = the larger of (a) HIP events on the launch stream around
+                  BATCHES of 20 back-to-back launches recorded inside the library
+                  (sngnn_profile_enable(20)), nothing subtracted, and (b) the committed rocprofv3
+                  average of the same command; both and the single-launch event interval are in the
+                  line (kernel_ms_batched_events, kernel_ms_rocprofv3, kernel_ms_single_launch_events).  traffic = counter bytes per launch of the committed PMC
                   passes (profiles/traffic.json), not re-measured in this run.
   roofline_step   the same bytes over ms_per_step - the whole forward (normalise + main + finalize
                   launches and the gaps between them), the gate BASELINE.md defines.
@@ -311,7 +311,6 @@ def main():
         norm_ms, main_ms, fin_ms, _ = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 6, 20)
         _, main_single_ms, _, empty_ms = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 30, 1)
         b_alg = algorithmic_bytes(e_prime, n, c)
-        achieved = b_alg / (main_ms * 1e-3) / 1e9
         traffic = rocprof_us = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -323,6 +322,13 @@ def main():
                 traffic_src = prof.get("source")
             except Exception:
                 traffic = rocprof_us = None
+        # the figure `frac` is priced on: the live batched-event average, but never less than the
+        # committed rocprofv3 average of the same command (dispatch to completion of one kernel:
+        # back-to-back launches of one kernel can overlap a ramp with a drain and read lower)
+        main_batched_ms = main_ms
+        if rocprof_us is not None and world == 1 and not plus_plus and args.scale == 1.0:
+            main_ms = max(main_ms, rocprof_us * 1e-3)
+        achieved = b_alg / (main_ms * 1e-3) / 1e9
         layer = ("one SNGNN_Plus_Plus layer forward (adjacency branch + aggregation + blend)" if plus_plus
                  else "SNGNN_Plus aggregation forward")
         if world == 1:
@@ -351,8 +357,10 @@ def main():
                          "traffic_source": traffic_src,
                          "kernel": "k_agg_fwd", "kernel_ms": main_ms,
                          "normalize_kernel_ms": norm_ms, "finalize_kernel_ms": fin_ms,
-                         "timer": "HIP events on the launch stream, recorded inside the library around batches "
-                                  "of 20 back-to-back launches of each kernel; interval / 20, nothing subtracted",
+                         "kernel_ms_batched_events": main_batched_ms,
+                         "timer": "kernel_ms = max(HIP events on the launch stream around batches of 20 back-to-back "
+                                  "launches recorded inside the library: interval / 20, nothing subtracted; the committed "
+                                  "rocprofv3 --kernel-trace average of this command)",
                          "algorithmic_bytes": b_alg,
                          "kernel_ms_single_launch_events": main_single_ms,
                          "frac_single_launch_events": b_alg / (main_single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
