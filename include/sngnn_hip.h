@@ -203,7 +203,9 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * knob 2 = how sngnn_agg_forward scores: 0 (default) = on the fly from h when nothing is selected
  * (top_k < 0) and through the normalisation pass + unit-row table otherwise; 1 = table always;
  * 2 = on the fly always (fast cosine, exact normalise-then-dot wherever a decision is in doubt:
- * the same selections, bit for bit) */
+ * the same selections, bit for bit);
+ * knob 3 = sngnn_agg_backward: 0 (default) = node-centric (a node small both as target and as
+ * source does both passes in one work item), 1 = the two passes for every node (same bits) */
 int sngnn_tuning_set(int which, int value);
 /* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
 int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,

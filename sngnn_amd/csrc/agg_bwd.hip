@@ -3,6 +3,11 @@
 
 using namespace sngnn;
 
+// sngnn_tuning_set(3, v): 0 = node-centric backward (default), 1 = the two passes for every node
+// (the same bits; measurement / test aid)
+static int g_bwd_mode = 0;
+int sngnn::set_bwd_mode(int v) { g_bwd_mode = v ? 1 : 0; return SNGNN_OK; }
+
 extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                                   const float *grad_out, const float *wsel, float *grad_h,
                                   void *workspace, void *stream)
@@ -29,6 +34,7 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     a.wd = nullptr;
     a.kmask = (unsigned *)ws;
     a.kmask_words = (g->Ep + 31) / 32;
+    a.Ep = g->Ep;
     a.inv_deg = g->inv_deg;
     const size_t ds_len = (2 * (size_t)g->Ep + 3) / 4 * 4;  // keep rows 16-byte aligned
     a.dnT = ws + ds_len;
@@ -39,7 +45,11 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk; a.split_task0 = g->split_task0;
     a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
-    a.nbA = a.nbB = 0;
+    a.nbA = a.nbB = a.nbC = 0;
+    a.mode = g_bwd_mode;
+    a.fdesc = g->fdesc; a.trest = g->trest;
+    a.n_fused = g->n_fused; a.n_trest = g->n_trest;
+    a.s_small_end = a.mode == 0 ? g->srcs_gt(SMALL_T - 1) : (int)g->Ntot;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {
     case 1: return launch_agg_bwd_v1(cfg, a, st);

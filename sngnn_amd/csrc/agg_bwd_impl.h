@@ -29,6 +29,10 @@
 #pragma once
 #include "device_utils.h"
 
+#ifndef SNGNN_BWDF_STEP
+#define SNGNN_BWDF_STEP 1          // kept in-edges and kept out-edges per step of a fused node (2: 74.9 us against 73.3)
+#endif
+
 namespace sngnn {
 
 struct BwdArgs {
@@ -38,8 +42,9 @@ struct BwdArgs {
     const int4 *rdesc, *sdesc;    // per degree-sorted slot: {node, first entry, degree, 0}: one load, not a chain of three
     const int32_t *cscptr, *csc_eid, *csc_dst, *csc_pos, *sperm;
     float2 *wd;                   // [E'] per-edge record in CSC order (attention mode: attn_impl.h)
-    unsigned *kmask;              // [kmask_words = ceil(E'/32)] kept bits in CSC order: set by pass T, read by pass S
-    int64_t kmask_words;
+    unsigned *kmask;              // [kmask_words = ceil(E'/32)] kept bits: two-pass mode in CSC order (set by pass T, read
+                                  // by pass S); node-centric mode in CSR order (k_pack_kept), read by both parts
+    int64_t kmask_words, Ep;
     const float *inv_deg;         // [N] 1 / max(in-degree, 1)
     float *dnT, *grad_h;
     int n_split, n_med_end, n_tasks;
@@ -49,6 +54,12 @@ struct BwdArgs {
     const int32_t *stask_slot, *stask_chunk, *ssplit_task0;
     float *partS;
     int nbA, nbB;
+    int s_small_end;              // pass S walks the small sources sdesc[n_smed_end, s_small_end)
+    // node-centric path: nodes small both as target and as source do both passes in one work item
+    const int4 *fdesc;            // [n_fused] {node, first in-edge, first CSC entry, in-degree | out-degree << 8}
+    const int4 *trest;            // [n_trest] small targets that are not fused (out-degree > SMALL_T): rdesc layout
+    int n_fused, n_trest, nbC;
+    int mode;                     // 0 = node-centric (default), 1 = the two passes for every node
 };
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
@@ -84,6 +95,9 @@ __device__ __forceinline__ void t_edge_row(const Row<VEC, G, R> &x, const Row<VE
     fma_row<VEC, G, R>(acc, d * invj * live, x);
 }
 
+// node-centric mode: kept bit of CSR edge e (the mask is 145 KB at arxiv size: cache resident)
+__device__ __forceinline__ bool kept_csr(const BwdArgs &a, int e) { return (a.kmask[e >> 5] >> (e & 31)) & 1u; }
+
 __device__ __forceinline__ void set_kept_bit(const BwdArgs &a, int cp)
 {
     atomicOr(a.kmask + (cp >> 5), 1u << (cp & 31));        // result unused: no return trip
@@ -91,21 +105,29 @@ __device__ __forceinline__ void set_kept_bit(const BwdArgs &a, int cp)
 
 // kept edges among [e0, e1) of a CSR row, compacted (ascending): their source ids into
 // jlist[]; their bits in the CSC-order mask are set here.  Lanes cover the range 64 at a time.
+// (MARK = false, node-centric mode: the kept bits are read from k_pack_kept's mask, nothing to set)
+template <bool MARK>
 __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e1, int *jlist)
 {
     const int lane = lane_id();
     int n = 0;
     for (int base = e0; base < e1; base += 64) {
         const int t = base + lane;
-        const float w = t < e1 ? a.wsel[rs + t] : SNGNN_UNSELECTED;
-        const int cp = t < e1 ? a.csc_pos[rs + t] : 0;
+        bool kept;
+        int cp = 0;
+        if constexpr (MARK) {
+            const float w = t < e1 ? a.wsel[rs + t] : SNGNN_UNSELECTED;
+            cp = t < e1 ? a.csc_pos[rs + t] : 0;
+            kept = is_kept(w);
+        } else {
+            kept = t < e1 && kept_csr(a, rs + t);
+        }
         // (with the weight, not behind `if (kept)`: a load inside the branch is a round trip of its own)
         const int j = t < e1 ? a.col[rs + t] : 0;
-        const bool kept = is_kept(w);
         const unsigned long long m = __ballot(kept);
         if (kept) {
             jlist[n + prefix_popc(m)] = j;
-            set_kept_bit(a, cp);
+            if constexpr (MARK) set_kept_bit(a, cp);
         }
         n += __popcll(m);
     }
@@ -115,16 +137,16 @@ __device__ __forceinline__ int kept_list(const BwdArgs &a, int rs, int e0, int e
 // small targets (deg <= SMALL_T), one group per row.  The group's lanes first fetch the
 // kept flags and source ids of all its edges in parallel (one round trip), then the
 // kept source rows are gathered two at a time.
-template <int VEC, int G, int R>
-__device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds_wave)
+template <int VEC, int G, int R, bool MARK>
+__device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds_wave, const int4 *desc, int n_desc)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int RPW = 64 / G;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int gid = lane / G, lg = lane % G;
-    const int slot = a.n_med_end + (blk * WAVES + wave) * RPW + gid;
-    if (slot >= a.N) return;                     // group-uniform
-    const int4 d = a.rdesc[slot];
+    const int slot = (blk * WAVES + wave) * RPW + gid;
+    if (slot >= n_desc) return;                  // group-uniform
+    const int4 d = desc[slot];
     const int i = d.x, rs = d.y, deg = d.z;
     // The kept edges are compacted first (ballot within the group), so the gather loop below
     // has no `if (kept)` around its loads: a load inside a divergent branch is waited for
@@ -135,14 +157,20 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     int nk = 0;
     for (int t0 = 0; t0 < deg; t0 += G) {
         const int t = t0 + lg;
-        const float w = t < deg ? a.wsel[rs + t] : SNGNN_UNSELECTED;
-        const int cp = t < deg ? a.csc_pos[rs + t] : 0;
+        bool kept;
+        int cp = 0;
+        if constexpr (MARK) {
+            const float w = t < deg ? a.wsel[rs + t] : SNGNN_UNSELECTED;
+            cp = t < deg ? a.csc_pos[rs + t] : 0;
+            kept = is_kept(w);
+        } else {
+            kept = t < deg && kept_csr(a, rs + t);
+        }
         const int j = t < deg ? a.col[rs + t] : 0;       // with the weight: not a round trip of its own
-        const bool kept = is_kept(w);
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
             s_j[nk + __popcll(gm & ((1ull << lg) - 1ull))] = j;
-            set_kept_bit(a, cp);
+            if constexpr (MARK) set_kept_bit(a, cp);
         }
         nk += __popcll(gm);
     }
@@ -163,7 +191,7 @@ __device__ __forceinline__ void t_role_small(const BwdArgs &a, int blk, int *lds
     acc.store(a.dnT + (size_t)i * a.C, a.C, lg);
 }
 
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool MARK>
 __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
 {
     using RowT = Row<VEC, G, R>;
@@ -192,7 +220,7 @@ __device__ __forceinline__ void t_role_wave(const BwdArgs &a, int blk, int *lds_
     gp.scale(invdeg);
     acc.zero();
     int *jlist = lds_wave;
-    const int nsel = kept_list(a, rs, e0, e1, jlist);
+    const int nsel = kept_list<MARK>(a, rs, e0, e1, jlist);
     wave_lds_sync();
     // two kept rows per lane group in flight, unconditionally (a slot past the end repeats the
     // last kept edge with live = 0): no col -> row chain, no load behind a branch.  Matters on
@@ -218,9 +246,9 @@ __global__ __launch_bounds__(BLOCK) void k_bwd_t(const BwdArgs a)
     __shared__ __align__(16) int lds[WAVES][WAVE_T];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
-    if (b < a.nbA) t_role_wave<VEC, G, R>(a, b, lw, true);
-    else if (b < a.nbA + a.nbB) t_role_wave<VEC, G, R>(a, b - a.nbA, lw, false);
-    else t_role_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
+    if (b < a.nbA) t_role_wave<VEC, G, R, true>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) t_role_wave<VEC, G, R, true>(a, b - a.nbA, lw, false);
+    else t_role_small<VEC, G, R, true>(a, b - a.nbA - a.nbB, lw, a.rdesc + a.n_med_end, a.N - a.n_med_end);
 }
 
 // split targets: dnT_i = sum of the tasks' partial rows.  Thread (c, q) adds every 4th
@@ -331,7 +359,8 @@ __device__ __forceinline__ void s_edge_rows(const Row<VEC, G, R> &x, const Row<V
 // of the kept edges are gathered two edges at a time.
 //   REC = true:  per-edge scalars from the records a.wd (attention mode)
 //   REC = false: kept bits from a.kmask, scalars recomputed from the rows
-template <int VEC, int G, int R, bool REC>
+//   CSRM (with REC = false): the mask is in CSR order (node-centric mode): bit of csc_eid[q]
+template <int VEC, int G, int R, bool REC, bool CSRM>
 __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -339,7 +368,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int gid = lane / G, lg = lane % G;
     const int slot = a.n_smed_end + (blk * WAVES + wave) * RPW + gid;
-    if (slot >= a.Ntot) return;
+    if (slot >= a.s_small_end) return;
     const int4 d = a.sdesc[slot];
     const int v = d.x, qs = d.y, od = d.z;
     FinishRows<VEC, G, R> fin;
@@ -357,6 +386,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
             const int q = qs + t;
             it = a.csc_dst[q];
             if constexpr (REC) rec = a.wd[q];
+            else if constexpr (CSRM) kept = kept_csr(a, a.csc_eid[q]);
             else kept = (a.kmask[q >> 5] >> (q & 31)) & 1u;
         }
         if constexpr (REC) kept = is_kept(rec.x);
@@ -397,7 +427,136 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
     s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
-template <int VEC, int G, int R, bool REC>
+// ------------------------- node-centric work item ---------------------------
+// A node that is small both as a target (in-degree <= SMALL_T) and as a source (out-degree <=
+// SMALL_T) - 95 % of the nodes at arxiv size - does its pass-T part and its pass-S part in one
+// work item of one lane group: its dnT row never leaves the registers (no store in pass T, no
+// load in pass S), its descriptor, own rows and lists are fetched once, and the kept in-edge
+// rows (h_j) and kept out-edge row pairs (h_i, G_i) are gathered in ONE loop - at ~1.2 kept
+// in-edges and ~1.9 kept out-edges per node the two passes were three dependent round trips
+// each, mostly for one gather step.  The sums run in the two passes' order (kept edges
+// ascending, T then S), so the result equals theirs bit for bit.
+// The kept bits come from k_pack_kept's mask in CSR order (below): in-edges by position, out-edges
+// through csc_eid.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void f_role_node(const BwdArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int RPW = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = (blk * WAVES + wave) * RPW + gid;
+    if (slot >= a.n_fused) return;               // group-uniform
+    const int4 d = a.fdesc[slot];
+    const int v = d.x, rs = d.y, qs = d.z, deg = d.w & 255, od = d.w >> 8;
+    const int vl = v - a.row_off;
+    int *s_j = lds_wave + gid * 2 * SMALL_T;     // kept in-edges: source id
+    int *s_i = s_j + SMALL_T;                    // kept out-edges: target row
+    FinishRows<VEC, G, R> fin;                   // .t becomes dnT_v, .hv = h_v (raw)
+    RowT gp;
+    gp.load(a.gout + (size_t)vl * a.C, a.C, lg);
+    fin.hv.load(a.h + (size_t)v * a.C, a.C, lg);
+    fin.own = true;
+    int nk = 0, nko = 0;
+    for (int t0 = 0; t0 < max(deg, od); t0 += G) {           // (one trip for G >= 16)
+        const int t = t0 + lg;
+        const bool kept_i = t < deg && kept_csr(a, rs + t);
+        const int j = t < deg ? a.col[rs + t] : 0;
+        bool kept_o = false;
+        int it = 0;
+        if (t < od) {
+            it = a.csc_dst[qs + t];
+            kept_o = kept_csr(a, a.csc_eid[qs + t]);         // index -> bit: the one chained load of the item
+        }
+        const unsigned long long gi = group_bits<G>(__ballot(kept_i), gid);
+        const unsigned long long go = group_bits<G>(__ballot(kept_o), gid);
+        const unsigned long long below = (1ull << lg) - 1ull;
+        if (kept_i) s_j[nk + __popcll(gi & below)] = j;
+        if (kept_o) s_i[nko + __popcll(go & below)] = it;
+        nk += __popcll(gi);
+        nko += __popcll(go);
+    }
+    gp.scale(1.0f / (float)max(deg, 1));
+    const float invv = inv_norm_of(group_sum<G>(fin.hv.dot_partial(fin.hv)));
+    RowT msg, dns;
+    fin.t.zero();
+    msg.zero();
+    dns.zero();
+    wave_lds_sync();
+    // one step = FU kept in-edges and FU kept out-edges: 3 FU rows in flight, unconditionally
+    // (a slot past a list's end repeats the node's own row with zero weight)
+    constexpr int FU = SNGNN_BWDF_STEP;
+    const int steps = (max(nk, nko) + FU - 1) / FU;
+    for (int s = 0; s < steps; ++s) {
+        RowT xj[FU], x[FU], gi[FU];
+        float dd[FU];
+        bool ti[FU], to[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int q = FU * s + u;
+            ti[u] = q < nk;
+            to[u] = q < nko;
+            const int j = ti[u] ? s_j[q] : v;
+            const int i = to[u] ? s_i[q] : vl;
+            xj[u].load(a.h + (size_t)j * a.C, a.C, lg);
+            x[u].load(a.h + (size_t)(i + a.row_off) * a.C, a.C, lg);
+            gi[u].load(a.gout + (size_t)i * a.C, a.C, lg);
+            dd[u] = a.inv_deg[i];                                        // travels with the rows
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) t_edge_row<VEC, G, R>(xj[u], gp, fin.t, ti[u] ? 1.0f : 0.0f);
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            s_edge_recompute<VEC, G, R>(x[u], gi[u], fin.hv, invv, dd[u], to[u] ? 1.0f : 0.0f, msg, dns);
+    }
+    s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
+}
+
+// kept bits of the forward's per-edge weights, in CSR (edge) order: one pass over wsel, whole
+// words by ballot - no clear, no atomics.  Every part of the node-centric backward reads kept-ness
+// from this mask (E'/8 bytes: cache resident) instead of 4 bytes per edge.  (First version: the
+// mask in CSC order, one random 4-byte read of wsel per out-edge: 10 us - line traffic.)
+static __global__ __launch_bounds__(256) void k_pack_kept(const float *__restrict__ wsel, int64_t Ep,
+                                                          unsigned long long *__restrict__ kmask64)
+{
+    const int lane = lane_id();
+    const int64_t base = (blockIdx.x * (int64_t)WAVES + (threadIdx.x >> 6)) * 256;
+    if (base >= Ep) return;
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = base + u * 64 + lane;
+        w[u] = e < Ep ? wsel[e] : SNGNN_UNSELECTED;
+    }
+    unsigned long long m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = __ballot(is_kept(w[u]));
+    if (lane < 4 && base + lane * 64 < Ep) kmask64[(base >> 6) + lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+}
+
+// pass T of the targets that are not fused (split-row tasks, wave rows, small targets with a
+// long out-list) and the fused nodes, in one launch
+#ifndef SNGNN_BWDF_OCC
+#define SNGNN_BWDF_OCC 0
+#endif
+#if SNGNN_BWDF_OCC
+#define SNGNN_BWDF_ATTR __attribute__((amdgpu_waves_per_eu(SNGNN_BWDF_OCC, SNGNN_BWDF_OCC)))
+#else
+#define SNGNN_BWDF_ATTR
+#endif
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) SNGNN_BWDF_ATTR void k_bwd_f(const BwdArgs a)
+{
+    __shared__ __align__(16) int lds[WAVES][256];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    if (b < a.nbA) t_role_wave<VEC, G, R, false>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) t_role_wave<VEC, G, R, false>(a, b - a.nbA, lw, false);
+    else if (b < a.nbA + a.nbB + a.nbC) t_role_small<VEC, G, R, false>(a, b - a.nbA - a.nbB, lw, a.trest, a.n_trest);
+    else f_role_node<VEC, G, R>(a, b - a.nbA - a.nbB - a.nbC, lw);
+}
+
+template <int VEC, int G, int R, bool REC, bool CSRM>
 __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_wave, bool task)
 {
     using RowT = Row<VEC, G, R>;
@@ -435,6 +594,8 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
         if constexpr (REC) {
             if (t < e1) rec = a.wd[q];
             kept = is_kept(rec.x);
+        } else if constexpr (CSRM) {
+            kept = t < e1 && kept_csr(a, a.csc_eid[q]);
         } else {
             kept = t < e1 && ((a.kmask[q >> 5] >> (q & 31)) & 1u);
         }
@@ -488,15 +649,15 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
     }
 }
 
-template <int VEC, int G, int R, bool REC>
+template <int VEC, int G, int R, bool REC, bool CSRM = false>
 __global__ __launch_bounds__(BLOCK) void k_bwd_s(const BwdArgs a)
 {
     __shared__ __align__(16) int lds[WAVES][512];
     const int b = blockIdx.x;
     int *lw = lds[threadIdx.x >> 6];
-    if (b < a.nbA) s_role_wave<VEC, G, R, REC>(a, b, lw, true);
-    else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R, REC>(a, b - a.nbA, lw, false);
-    else s_role_small<VEC, G, R, REC>(a, b - a.nbA - a.nbB, lw);
+    if (b < a.nbA) s_role_wave<VEC, G, R, REC, CSRM>(a, b, lw, true);
+    else if (b < a.nbA + a.nbB) s_role_wave<VEC, G, R, REC, CSRM>(a, b - a.nbA, lw, false);
+    else s_role_small<VEC, G, R, REC, CSRM>(a, b - a.nbA - a.nbB, lw);
 }
 
 // split sources: one wave per source sums the tasks' partial rows, then finishes
@@ -533,6 +694,25 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
 {
     constexpr int RPW = 64 / G;
     BwdArgs a = a0;
+    if (a.mode == 0) {
+        // node-centric: kept bits packed from the forward's weights, then the targets' pass with
+        // the fused nodes, then pass S for the sources that are left
+        if (a.kmask_words > 0)
+            k_pack_kept<<<ceil_div(a.Ep, 256 * WAVES), 256, 0, st>>>(a.wsel, a.Ep, (unsigned long long *)a.kmask);
+        a.nbA = ceil_div(a.n_tasks, WAVES);
+        a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
+        a.nbC = ceil_div(a.n_trest, (int64_t)WAVES * RPW);
+        const int nbD = ceil_div(a.n_fused, (int64_t)WAVES * RPW);
+        if (a.nbA + a.nbB + a.nbC + nbD > 0) k_bwd_f<VEC, G, R><<<a.nbA + a.nbB + a.nbC + nbD, BLOCK, 0, st>>>(a);
+        if (a.n_split > 0) k_bwd_t_fin<<<a.n_split, 256, 0, st>>>(a);
+        a.nbA = ceil_div(a.n_stasks, WAVES);
+        a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
+        const int nbS = ceil_div(a.s_small_end - a.n_smed_end, (int64_t)WAVES * RPW);
+        if (a.nbA + a.nbB + nbS > 0) k_bwd_s<VEC, G, R, false, true><<<a.nbA + a.nbB + nbS, BLOCK, 0, st>>>(a);
+        if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
+        SN_HIP(hipGetLastError());
+        return SNGNN_OK;
+    }
     // kept bits in CSC order: cleared, set by pass T, read by pass S.  (A kernel, not
     // hipMemsetAsync: replayed from a captured HIP graph, the memset node did not stay ordered
     // in front of pass T on this stack - ROCm 7.0 runtime under PyTorch 2.10 - and cleared bits
@@ -548,7 +728,7 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
     // pass S (sources)
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);
-    nbC = ceil_div(a.Ntot - a.n_smed_end, (int64_t)WAVES * RPW);
+    nbC = ceil_div(a.s_small_end - a.n_smed_end, (int64_t)WAVES * RPW);
     if (a.nbA + a.nbB + nbC > 0) k_bwd_s<VEC, G, R, false><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
     if (a.n_ssplit > 0) k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
     SN_HIP(hipGetLastError());

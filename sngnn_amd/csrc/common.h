@@ -38,6 +38,8 @@ int wgrad_mfma_partials(int64_t N, int C, int F);
 int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, float *part, float *part_b,
                       hipStream_t st);
 
+int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knob 3)
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Lane layout of one node row for C channels:
@@ -109,6 +111,11 @@ struct sngnn_graph {
     int4 *rdesc_b = nullptr;
     int4 *sdesc = nullptr;     // [Ntot] per slot of sperm: {source, first CSC entry, out-degree, 0}
     float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
+    // backward, node-centric path: the small sources of sdesc / sperm are ordered [not fused |
+    // fused], natural order inside each; fused = owned, in-degree and out-degree <= SMALL_T
+    int4 *fdesc = nullptr;     // [n_fused] {node, first in-edge, first CSC entry, in-degree | out-degree << 8}
+    int4 *trest = nullptr;     // [n_trest] {row, first edge, in-degree, 0}: small targets with out-degree > SMALL_T
+    int n_fused = 0, n_trest = 0;
     // split rows (in-degree > WAVE_T) = the first n_split slots of rperm
     int32_t *task_slot = nullptr, *task_chunk = nullptr;   // [n_tasks]
     int32_t *task_order = nullptr;    // [n_tasks] dealing order of the forward's tasks (XCD-affine by source slice)

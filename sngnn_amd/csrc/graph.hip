@@ -129,10 +129,41 @@ __global__ void k_task_slice(const int4 *__restrict__ rdesc, const int32_t *__re
 // equal degrees inside a wave (k_bwd_s 42.2 -> 36.9 us at arxiv size).  The TARGET rows stay
 // sorted by degree: the forward issues loads up to the longest row of a set, and mixed
 // degrees cost it more (main kernel 54.9 -> 60.1 us) than the line-aligned rows save.
-__global__ void k_class_key(int32_t *__restrict__ deg, int64_t N)
+// Among the small sources the stable sort makes two runs: first those the backward's pass S
+// walks (key SMALL_T), then the FUSED nodes (key SMALL_T - 1): owned nodes small both as source
+// and as target, whose two backward passes run as one work item (agg_bwd_impl.h: f_role_node).
+__global__ void k_class_key(int32_t *__restrict__ deg, int64_t Ntot, const int32_t *__restrict__ rowptr,
+                            int64_t row0, int64_t N)
+{
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= Ntot) return;
+    const int od = deg[v];
+    if (od > SMALL_T) return;
+    const int64_t vl = v - row0;
+    const bool fused = vl >= 0 && vl < N && rowptr[vl + 1] - rowptr[vl] <= SMALL_T;
+    deg[v] = fused ? SMALL_T - 1 : SMALL_T;
+}
+
+// 1 for an owned small target that is not fused (its out-list is long), else 0
+__global__ void k_trest_key(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ cscptr, int64_t row0,
+                            int64_t N, int32_t *__restrict__ key)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) deg[i] = max(deg[i], SMALL_T);
+    if (i >= N) return;
+    const int64_t v = i + row0;
+    key[i] = (rowptr[i + 1] - rowptr[i] <= SMALL_T && cscptr[v + 1] - cscptr[v] > SMALL_T) ? 1 : 0;
+}
+
+// descriptors of the fused nodes from their source descriptors {node, first CSC entry, out-degree}
+__global__ void k_fused_desc(const int4 *__restrict__ sdesc, int64_t n, const int32_t *__restrict__ rowptr,
+                             int64_t row0, int4 *__restrict__ fdesc)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int4 s = sdesc[p];
+    const int64_t vl = s.x - row0;
+    const int rs = rowptr[vl];
+    fdesc[p] = make_int4(s.x, rs, s.y, (rowptr[vl + 1] - rs) | (s.z << 8));
 }
 
 // col with the rows in SLOT order: the in-edges of slot p follow those of slot p - 1, so a
@@ -380,7 +411,7 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     g->sdeg.assign((size_t)Ntot, 0);
     if (Ntot > 0) {
         k_degree<<<grid1(Ntot), 256, 0, st>>>(g->cscptr, Ntot, deg.as<int32_t>());
-        k_class_key<<<grid1(Ntot), 256, 0, st>>>(deg.as<int32_t>(), Ntot);
+        k_class_key<<<grid1(Ntot), 256, 0, st>>>(deg.as<int32_t>(), Ntot, g->rowptr, row0, N);
         if ((rc = sort_pairs(deg.as<int32_t>(), deg_sorted.as<int32_t>(), d_iota, g->sperm, Ntot, 31, true, st)))
             return rc;
         SN_HIP(hipMemcpy(g->sdeg.data(), deg_sorted.p, (size_t)Ntot * 4, hipMemcpyDeviceToHost));
@@ -388,6 +419,28 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     g->max_out_deg = Ntot ? g->sdeg[0] : 0;
     if ((rc = dev_alloc(&g->sdesc, Ntot))) return rc;
     if (Ntot > 0) k_row_desc<<<grid1(Ntot), 256, 0, st>>>(g->sperm, g->cscptr, Ntot, g->sdesc);
+    // 6b. the backward's node-centric lists: fused nodes (the tail of sdesc) and the small
+    //     targets left to pass T
+    {
+        const int n_srest_end = g->srcs_gt(SMALL_T - 1);
+        g->n_fused = (int)Ntot - n_srest_end;
+        if ((rc = dev_alloc(&g->fdesc, g->n_fused))) return rc;
+        if (g->n_fused > 0)
+            k_fused_desc<<<grid1(g->n_fused), 256, 0, st>>>(g->sdesc + n_srest_end, g->n_fused, g->rowptr, row0, g->fdesc);
+        g->n_trest = 0;
+        if (N > 0) {
+            DevBuf perm_t;
+            if (perm_t.alloc((size_t)N * 4)) { set_error("out of device memory (graph build)"); return SNGNN_ENOMEM; }
+            k_trest_key<<<grid1(N), 256, 0, st>>>(g->rowptr, g->cscptr, row0, N, d_keys);
+            if ((rc = sort_pairs(d_keys, deg_sorted.as<int32_t>(), d_iota, perm_t.as<int32_t>(), N, 1, true, st))) return rc;
+            std::vector<int32_t> key_sorted((size_t)N);
+            SN_HIP(hipMemcpy(key_sorted.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+            while (g->n_trest < N && key_sorted[g->n_trest]) ++g->n_trest;
+            if ((rc = dev_alloc(&g->trest, g->n_trest))) return rc;
+            if (g->n_trest > 0) k_row_desc<<<grid1(g->n_trest), 256, 0, st>>>(perm_t.as<int32_t>(), g->rowptr, g->n_trest, g->trest);
+            SN_HIP(hipStreamSynchronize(st));      // perm_t goes out of scope
+        } else if ((rc = dev_alloc(&g->trest, 0))) return rc;
+    }
 
     // 7. split-row / split-source task lists
     g->n_split = g->rows_gt(WAVE_T);
@@ -479,7 +532,7 @@ int sngnn_graph_create(const int64_t *edge_index_dev, int64_t E, int64_t N, int 
 void sngnn_graph_destroy(sngnn_graph_t *g)
 {
     if (!g) return;
-    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->col_s, g->rperm_b, g->rdesc_b, g->col_s_b, g->rperm,
+    void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->col_s, g->rperm_b, g->rdesc_b, g->col_s_b, g->rperm, g->fdesc, g->trest,
                     g->sperm, g->rdesc, g->sdesc, g->inv_deg, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->task_order,
                     g->stask_slot, g->stask_chunk, g->ssplit_task0};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -196,3 +196,42 @@ def test_partitioned_adjacency_branch_reproduces_the_whole_graph(cuda, parts, re
     assert_close(torch.cat(outs), out_full.detach(), what="out_0", rtol=1e-5, atol=1e-5)
     assert_grad_close(dW, w_full.grad, "dW")
     assert_grad_close(db, b_full.grad, "db")
+
+
+def _grad_in_mode(lib, mode, g, h, gout, k, thr):
+    from sngnn_amd import ops
+    lib.sngnn_tuning_set(3, mode)
+    hp = h.clone().requires_grad_(True)
+    (ops.aggregate(hp, g, k, thr) * gout).sum().backward()
+    return hp.grad
+
+
+@pytest.mark.parametrize("n,e,C,hubs,rem,k,thr", CASES + [
+    (3000, 20000, 40, ((0, 2999), (5, 400)), True, 16, 0.0),       # mostly nodes small on both sides
+    (3000, 9000, 32, (), True, 2, 0.3),                            # G = 8: two trips over the lists
+    (2000, 30000, 1, ((1, 1500),), True, 4, 0.0),
+    (50, 0, 12, (), False, 3, 0.0),                                # loops only
+])
+def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k, thr):
+    """sngnn_tuning_set(3, mode): a node small both as target and as source does its pass-T and
+    pass-S parts in one work item (dnT in registers, kept bits from k_kept_csc); the sums keep the
+    two passes' order, so grad_h is the same bit for bit - whole graphs and node-range partitions."""
+    from sngnn_amd import _lib
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    ei = random_graph(n, e, seed=3 * n + e + C, hubs=hubs) if e else torch.zeros(2, 0, dtype=torch.long)
+    ei = torch.cat([ei, torch.stack([torch.full((n // 2,), 3), torch.arange(n // 2) * 2 + 1])], 1)
+    ei = torch.unique(ei, dim=1).to(cuda)
+    gen = torch.Generator().manual_seed(C + n)
+    h = torch.randn(n, C, generator=gen).to(cuda)
+    h[7] = 0.0
+    gout = torch.randn(n, C, generator=gen).to(cuda)
+    try:
+        g = Graph(ei, n, True, rem)
+        assert torch.equal(_grad_in_mode(lib, 0, g, h, gout, k, thr), _grad_in_mode(lib, 1, g, h, gout, k, thr))
+        lo, hi = n // 4, n // 4 + n // 3
+        gp = Graph(ei, n, True, rem, row_range=(lo, hi))
+        assert torch.equal(_grad_in_mode(lib, 0, gp, h, gout[lo:hi], k, thr),
+                           _grad_in_mode(lib, 1, gp, h, gout[lo:hi], k, thr))
+    finally:
+        lib.sngnn_tuning_set(3, 0)

@@ -1,0 +1,48 @@
+"""Backward of the aggregation at config 4 (arxiv size, C 40, top_k 16, thr 0): device time of one
+backward call, node-centric (sngnn_tuning_set(3, 0), default) against the two passes (3, 1)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sngnn_amd import _lib, ops, synth  # noqa: E402
+from sngnn_amd.graph import Graph  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    c = int(os.environ.get("C", 40))
+    k = int(os.environ.get("TOP_K", 16))
+    thr = float(os.environ.get("THR", 0.0))
+    d = synth.make_dataset(os.environ.get("GRAPH", "arxiv"))
+    n = d.x.shape[0]
+    g = Graph(d.edge_index.to(dev), n, True, True)
+    gen = torch.Generator().manual_seed(0)
+    h = torch.randn(n, c, generator=gen).to(dev)
+    gout = torch.randn(n, c, generator=gen).to(dev)
+    _, wsel, *_ = ops.aggregate_forward(g, h, k if k > 0 else None, thr, save_for_backward=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    res = {}
+    for mode in (1, 0, 1, 0):
+        lib.sngnn_tuning_set(3, mode)
+        ts = []
+        for _ in range(8):
+            ev[0].record()
+            for _ in range(10):
+                gh = ops.aggregate_backward(g, h, gout, wsel)
+            ev[1].record()
+            ev[1].synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]) * 100)
+        res.setdefault(mode, []).append(float(np.mean(ts[2:])))
+        res[("g", mode)] = gh
+    lib.sngnn_tuning_set(3, 0)
+    print("two passes   us/call:", res[1])
+    print("node-centric us/call:", res[0])
+    print("equal bits:", bool(torch.equal(res[("g", 0)], res[("g", 1)])))
+
+
+if __name__ == "__main__":
+    main()
