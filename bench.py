@@ -479,7 +479,7 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
     for _ in range(8):
         ev[0].record()
         for _ in range(10):
-            ops.aggregate_backward(graph, h, gout, wsel)
+            ops.aggregate_backward(graph, h, gout, wsel, top_k)
         ev[1].record()
         ev[1].synchronize()
         bw.append(ev[0].elapsed_time(ev[1]) / 10)
@@ -491,7 +491,7 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
             traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("arxiv_k16_bwd")
     except Exception:
         traffic = None
-    return {"bound": "hbm", "kernels": "k_bwd_clear + k_bwd_t + k_bwd_t_fin + k_bwd_s (one backward call)",
+    return {"bound": "hbm", "kernels": "k_pack_kept + k_bwd_w (one backward call, as the autograd function makes it: with the forward's top_k)",
             "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd, "traffic": traffic,
             "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

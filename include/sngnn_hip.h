@@ -205,7 +205,8 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * 2 = on the fly always (fast cosine, exact normalise-then-dot wherever a decision is in doubt:
  * the same selections, bit for bit);
  * knob 3 = sngnn_agg_backward: 0 (default) = node-centric (a node small both as target and as
- * source does both passes in one work item), 1 = the two passes for every node (same bits) */
+ * source does both passes in one work item; with a top_k hint every node), 1 = the two passes for
+ * every node (same bits without the hint; equal to rounding on split rows with it) */
 int sngnn_tuning_set(int which, int value);
 /* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
 int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,
@@ -231,6 +232,14 @@ int sngnn_agg_forward_normalized(const sngnn_graph_t *g, const float *n, const f
 int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                        const float *grad_out, const float *wsel, float *grad_h,
                        void *workspace, void *stream);
+/* The same with the forward's top_k passed along (<= 0: unknown, == sngnn_agg_backward).  A
+ * top_k in [1, 128] promises at most that many kept in-edges per row, which lets one wave take a
+ * whole target row of any in-degree (kept edges found by scanning the packed kept bits): one
+ * launch for all nodes, no split-row partial sums.  The result does not depend on the promise
+ * being true (an over-full row is processed in pieces), only the speed does. */
+int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, int C,
+                            const float *grad_out, const float *wsel, int top_k, float *grad_h,
+                            void *workspace, void *stream);
 
 /*
  * Cosine-attention mode of the same gather skeleton.

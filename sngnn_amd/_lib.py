@@ -49,6 +49,7 @@ SIGNATURES = {
     "sngnn_agg_forward_normalized": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_agg_backward_topk": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_blend_workspace_bytes": (_i64, []),

@@ -5,12 +5,20 @@ using namespace sngnn;
 
 // sngnn_tuning_set(3, v): 0 = node-centric backward (default), 1 = the two passes for every node
 // (the same bits; measurement / test aid)
-static int g_bwd_mode = 0;
+static int g_bwd_mode = 0, g_bwd_roles = 3;
 int sngnn::set_bwd_mode(int v) { g_bwd_mode = v ? 1 : 0; return SNGNN_OK; }
+int sngnn::set_bwd_roles(int v) { g_bwd_roles = v & 3; return SNGNN_OK; }
 
 extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                                   const float *grad_out, const float *wsel, float *grad_h,
                                   void *workspace, void *stream)
+{
+    return sngnn_agg_backward_topk(g, h, C, grad_out, wsel, -1, grad_h, workspace, stream);
+}
+
+extern "C" int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, int C,
+                                       const float *grad_out, const float *wsel, int top_k,
+                                       float *grad_h, void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
     if (g->Ntot == 0) return SNGNN_OK;
@@ -47,6 +55,8 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
     a.nbA = a.nbB = a.nbC = 0;
     a.mode = g_bwd_mode;
+    a.top_k = top_k;
+    a.role_mask = g_bwd_roles;
     a.fdesc = g->fdesc; a.trest = g->trest;
     a.n_fused = g->n_fused; a.n_trest = g->n_trest;
     a.s_small_end = a.mode == 0 ? g->srcs_gt(SMALL_T - 1) : (int)g->Ntot;

@@ -60,6 +60,9 @@ struct BwdArgs {
     const int4 *trest;            // [n_trest] small targets that are not fused (out-degree > SMALL_T): rdesc layout
     int n_fused, n_trest, nbC;
     int mode;                     // 0 = node-centric (default), 1 = the two passes for every node
+    int role_mask;                // measurement aid (sngnn_tuning_set knob 4): bit 0 wave-per-node items, bit 1 fused items
+    int top_k;                    // the forward's top_k when the caller gave it (at most that many kept in-edges
+                                  // per row), else <= 0
 };
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
@@ -512,6 +515,134 @@ __device__ __forceinline__ void f_role_node(const BwdArgs &a, int blk, int *lds_
     s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
 }
 
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ int wave_prefix_incl(int v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// ---------------------- wave-per-node work item (selective calls) ------------------------
+// When the forward kept at most top_k <= WAVE_T in-edges per row (the caller says so:
+// sngnn_agg_backward_topk), a target of ANY in-degree is one wave's work: the kept in-edges are
+// found by scanning the row's bits in the packed mask (2048 edges per wave-wide load - 7 loads
+// for a 13 000-edge hub, where the task form reads 52 KB of flags and writes ~100 partial
+// rows for 16 kept edges), so there are no split-row tasks, no partial rows and no k_bwd_t_fin;
+// and the wave goes on with the node's pass-S part (out-degree <= WAVE_T) with dnT in registers,
+// so pass S has nothing left but split sources and, under a partition, the halo's sources.
+// Robust against a wrong hint: a list that would overflow is flushed (gathered and
+// accumulated) first - slower, still correct and deterministic.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_wave)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int gid = lane / G, lg = lane % G;
+    const int slot = blk * WAVES + wave;
+    if (slot >= a.n_med_end + a.n_trest) return;
+    const int4 d = slot < a.n_med_end ? a.rdesc[slot] : a.trest[slot - a.n_med_end];
+    const int vl = d.x, rs = d.y, deg = d.z;
+    const int v = vl + a.row_off;
+    const int qs = a.cscptr[v], od = a.cscptr[v + 1] - qs;
+    FinishRows<VEC, G, R> fin;                   // .t becomes dnT_v
+    RowT gp;
+    gp.load(a.gout + (size_t)vl * a.C, a.C, lg);
+    fin.hv.load(a.h + (size_t)v * a.C, a.C, lg);
+    fin.own = true;
+    gp.scale(1.0f / (float)max(deg, 1));
+    fin.t.zero();
+    int *elist = lds_wave;                       // [WAVE_T] kept in-edges: CSR index, then source id
+    int *s_i = lds_wave + WAVE_T;                // [WAVE_T] kept out-edges: target row
+    int n = 0;
+    // gather the n listed source rows into fin.t (per-group partial sums), two per group in flight
+    auto flush = [&]() {
+        wave_lds_sync();
+        for (int t = lane; t < n; t += 64) elist[t] = a.col[elist[t]];
+        wave_lds_sync();
+        for (int q0 = 0; q0 < n; q0 += 2 * NG) {
+            const int qa = min(q0 + gid, n - 1), qb = min(q0 + NG + gid, n - 1);
+            RowT xa, xb;
+            xa.load(a.h + (size_t)elist[qa] * a.C, a.C, lg);
+            xb.load(a.h + (size_t)elist[qb] * a.C, a.C, lg);
+            t_edge_row<VEC, G, R>(xa, gp, fin.t, q0 + gid < n ? 1.0f : 0.0f);
+            t_edge_row<VEC, G, R>(xb, gp, fin.t, q0 + NG + gid < n ? 1.0f : 0.0f);
+        }
+        wave_lds_sync();
+        n = 0;
+    };
+    // append the set bits of every lane's word (ascending edge order) to the list
+    auto append = [&](unsigned word, int wi, int total) {
+        if (n + total > WAVE_T) flush();                              // wave-uniform
+        const int cnt = __popc(word);
+        int o = n + wave_prefix_incl(cnt) - cnt;
+        while (word) {
+            const int b = __builtin_ctz(word);
+            word &= word - 1u;
+            elist[o++] = wi * 32 + b;
+        }
+        n += total;
+    };
+    const int e_end = rs + deg;
+    for (int w0 = rs >> 5; w0 * 32 < e_end; w0 += 64) {
+        const int wi = w0 + lane;
+        unsigned word = (int64_t)wi * 32 < e_end ? a.kmask[wi] : 0u;
+        if (wi * 32 < rs) word &= ~0u << (rs & 31);                   // bits of the previous row
+        if (wi * 32 + 32 > e_end) word &= wi * 32 >= e_end ? 0u : ~0u >> ((32 - (e_end & 31)) & 31);
+        const int total = wave_sum_i(__popc(word));
+        if (total <= WAVE_T) append(word, wi, total);
+        else                                                          // (a hint that was not true)
+            for (int sb = 0; sb < 16; ++sb) {
+                const unsigned ws = (lane >> 2) == sb ? word : 0u;    // 4 words = 128 edges at a time
+                append(ws, wi, wave_sum_i(__popc(ws)));
+            }
+    }
+    // kept out-edges (pass-S part, out-degree <= WAVE_T): listed while the in-edge rows travel
+    int nso = 0;
+    const bool s_here = od <= WAVE_T;
+    if (s_here)
+        for (int base = 0; base < od; base += 64) {
+            const int t = base + lane;
+            const int it = t < od ? a.csc_dst[qs + t] : 0;
+            const bool kept = t < od && kept_csr(a, a.csc_eid[qs + t]);
+            const unsigned long long m = __ballot(kept);
+            if (kept) s_i[nso + prefix_popc(m)] = it;
+            nso += __popcll(m);
+        }
+    if (n > 0) flush();
+    fin.t.reduce_across_groups();
+    if (!s_here) {                               // a split source: pass S (tasks) reads dnT from memory
+        if (gid == 0) fin.t.store(a.dnT + (size_t)vl * a.C, a.C, lg);
+        return;
+    }
+    const float invv = inv_norm_of(group_sum<G>(fin.hv.dot_partial(fin.hv)));
+    RowT msg, dns;
+    msg.zero();
+    dns.zero();
+    wave_lds_sync();
+    for (int q0 = 0; q0 < nso; q0 += 2 * NG) {
+        const int qa = min(q0 + gid, nso - 1), qb = min(q0 + NG + gid, nso - 1);
+        const bool la = q0 + gid < nso, lb = q0 + NG + gid < nso;
+        const int ia = s_i[qa], ib = s_i[qb];
+        RowT xa, ga, xb, gb;
+        xa.load(a.h + (size_t)(ia + a.row_off) * a.C, a.C, lg);
+        ga.load(a.gout + (size_t)ia * a.C, a.C, lg);
+        xb.load(a.h + (size_t)(ib + a.row_off) * a.C, a.C, lg);
+        gb.load(a.gout + (size_t)ib * a.C, a.C, lg);
+        const float da = a.inv_deg[ia], db = a.inv_deg[ib];
+        s_edge_recompute<VEC, G, R>(xa, ga, fin.hv, invv, da, la ? 1.0f : 0.0f, msg, dns);
+        s_edge_recompute<VEC, G, R>(xb, gb, fin.hv, invv, db, lb ? 1.0f : 0.0f, msg, dns);
+    }
+    msg.reduce_across_groups();
+    dns.reduce_across_groups();
+    if (gid == 0) s_finish<VEC, G, R>(a, v, lg, msg, dns, fin);
+}
+
 // kept bits of the forward's per-edge weights, in CSR (edge) order: one pass over wsel, whole
 // words by ballot - no clear, no atomics.  Every part of the node-centric backward reads kept-ness
 // from this mask (E'/8 bytes: cache resident) instead of 4 bytes per edge.  (First version: the
@@ -534,16 +665,31 @@ static __global__ __launch_bounds__(256) void k_pack_kept(const float *__restric
     if (lane < 4 && base + lane * 64 < Ep) kmask64[(base >> 6) + lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
 }
 
+// Both node-centric kernels are bound by how many gathers the CU keeps in flight: with the
+// register budget of 8 waves per SIMD (64 VGPRs; the compiler took 84 / 65 for the 16-byte
+// one-step layouts, i.e. 5 / 7 waves) the whole backward went 68.5 -> 60.0 us.  Layouts with
+// more than one step per row keep the compiler's own budget (their rows do not fit).
+#define SNGNN_BWDF_ATTR __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 1, 8)))
+// selective calls: every owned node in one launch - a wave per node that is not fused (heavy rows
+// first), then the fused nodes
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) SNGNN_BWDF_ATTR void k_bwd_w(const BwdArgs a)
+{
+    __shared__ __align__(16) int lds[WAVES][2 * WAVE_T];
+    const int b = blockIdx.x;
+    int *lw = lds[threadIdx.x >> 6];
+    // The wave-per-node items are chains of dependent round trips with one node per wave, the
+    // fused items move four nodes per wave: spread over the grid (every nbB-th workgroup) the
+    // chains hide behind the fused items' traffic; in front of them they were 10 us of an idle
+    // memory system (62 -> 5x us).
+    const int stride = a.nbB;
+    const int cw = min(a.nbA, (b + stride - 1) / stride);          // wave-per-node workgroups before b
+    if (b % stride == 0 && b / stride < a.nbA) { if (a.role_mask & 1) w_role_node<VEC, G, R>(a, b / stride, lw); }
+    else if (a.role_mask & 2) f_role_node<VEC, G, R>(a, b - cw, lw);
+}
+
 // pass T of the targets that are not fused (split-row tasks, wave rows, small targets with a
 // long out-list) and the fused nodes, in one launch
-#ifndef SNGNN_BWDF_OCC
-#define SNGNN_BWDF_OCC 0
-#endif
-#if SNGNN_BWDF_OCC
-#define SNGNN_BWDF_ATTR __attribute__((amdgpu_waves_per_eu(SNGNN_BWDF_OCC, SNGNN_BWDF_OCC)))
-#else
-#define SNGNN_BWDF_ATTR
-#endif
 template <int VEC, int G, int R>
 __global__ __launch_bounds__(BLOCK) SNGNN_BWDF_ATTR void k_bwd_f(const BwdArgs a)
 {
@@ -695,10 +841,26 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
     constexpr int RPW = 64 / G;
     BwdArgs a = a0;
     if (a.mode == 0) {
-        // node-centric: kept bits packed from the forward's weights, then the targets' pass with
-        // the fused nodes, then pass S for the sources that are left
+        // node-centric: kept bits packed from the forward's weights, then ...
         if (a.kmask_words > 0)
             k_pack_kept<<<ceil_div(a.Ep, 256 * WAVES), 256, 0, st>>>(a.wsel, a.Ep, (unsigned long long *)a.kmask);
+        if (a.top_k >= 1 && a.top_k <= WAVE_T && a.N == a.Ntot) {
+            // ... selective call on a whole graph: every node in one launch; pass S is left with
+            // the split sources' tasks
+            a.nbA = ceil_div(a.n_med_end + a.n_trest, WAVES);
+            const int nbF = ceil_div(a.n_fused, (int64_t)WAVES * RPW);
+            a.nbB = std::max(1, (a.nbA + nbF) / std::max(a.nbA, 1));          // k_bwd_w: spacing of the wave-per-node workgroups
+            if (a.nbA + nbF > 0) k_bwd_w<VEC, G, R><<<a.nbA + nbF, BLOCK, 0, st>>>(a);
+            if (a.n_stasks > 0) {
+                a.nbA = ceil_div(a.n_stasks, WAVES);
+                a.nbB = 0;
+                k_bwd_s<VEC, G, R, false, true><<<a.nbA, BLOCK, 0, st>>>(a);
+                k_bwd_s_fin<VEC, G, R><<<a.n_ssplit, 64, 0, st>>>(a);
+            }
+            SN_HIP(hipGetLastError());
+            return SNGNN_OK;
+        }
+        // ... the targets' pass with the fused nodes, then pass S for the sources that are left
         a.nbA = ceil_div(a.n_tasks, WAVES);
         a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
         a.nbC = ceil_div(a.n_trest, (int64_t)WAVES * RPW);

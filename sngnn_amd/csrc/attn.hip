@@ -68,7 +68,7 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
     a.nbA = a.nbB = a.nbC = 0;
-    a.mode = 1; a.s_small_end = (int)g->Ntot; a.Ep = g->Ep;
+    a.mode = 1; a.top_k = -1; a.role_mask = 3; a.s_small_end = (int)g->Ntot; a.Ep = g->Ep;
     a.fdesc = nullptr; a.trest = nullptr; a.n_fused = a.n_trest = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {

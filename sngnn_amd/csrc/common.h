@@ -38,7 +38,8 @@ int wgrad_mfma_partials(int64_t N, int C, int F);
 int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, float *part, float *part_b,
                       hipStream_t st);
 
-int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knob 3)
+int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knobs 3, 4)
+int set_bwd_roles(int v);
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -348,7 +348,7 @@ class _HaloAggregate(torch.autograd.Function):
         if plan.n_boundary:
             ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 1, out, wsel, inv)
         if need_grad:
-            ctx.plan, ctx.graph = plan, graph
+            ctx.plan, ctx.graph, ctx.top_k = plan, graph, top_k
             ctx.save_for_backward(table, wsel)
         return out
 
@@ -356,7 +356,7 @@ class _HaloAggregate(torch.autograd.Function):
     def backward(ctx, grad_out):
         from . import ops
         table, wsel = ctx.saved_tensors
-        grad_table = ops.aggregate_backward(ctx.graph, table, grad_out.contiguous(), wsel)
+        grad_table = ops.aggregate_backward(ctx.graph, table, grad_out.contiguous(), wsel, ctx.top_k)
         return return_halo_gradients(grad_table, ctx.plan), None, None, None, None, None
 
 

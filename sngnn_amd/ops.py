@@ -164,7 +164,9 @@ def aggregate_forward_normalized(graph: Graph, n: torch.Tensor, nrm: torch.Tenso
 
 
 def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
-                       wsel: torch.Tensor) -> torch.Tensor:
+                       wsel: torch.Tensor, top_k: Optional[int] = None) -> torch.Tensor:
+    """``top_k``: the forward's top_k (a bound on the kept in-edges per row; lets the library
+    take every node in one launch) or None when unknown / nothing was selected."""
     lib = _lib.load()
     h = _check_rows(h, graph.num_total_nodes, "h")
     grad_out = _check_rows(grad_out, graph.num_nodes, "grad_out")
@@ -172,10 +174,10 @@ def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
     grad_h = torch.empty_like(h)
     ws = graph.workspace(c)
     with torch.cuda.device(h.device):
-        rc = lib.sngnn_agg_backward(graph.handle, h.data_ptr(), c, grad_out.data_ptr(),
-                                    wsel.data_ptr(), grad_h.data_ptr(), ws.data_ptr(),
-                                    _stream(h.device))
-    _lib.check(rc, "sngnn_agg_backward")
+        rc = lib.sngnn_agg_backward_topk(graph.handle, h.data_ptr(), c, grad_out.data_ptr(),
+                                         wsel.data_ptr(), -1 if top_k is None else int(top_k),
+                                         grad_h.data_ptr(), ws.data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_agg_backward_topk")
     return grad_h
 
 
@@ -193,14 +195,14 @@ class _Aggregate(torch.autograd.Function):
             out, wsel, _, _, _ = aggregate_forward(graph, h, top_k, thr,
                                                    save_for_backward=need_grad)
         if need_grad:
-            ctx.graph = graph
+            ctx.graph, ctx.top_k = graph, top_k
             ctx.save_for_backward(h, wsel)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         h, wsel = ctx.saved_tensors
-        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel)
+        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
         return grad_h, None, None, None, None
 
 

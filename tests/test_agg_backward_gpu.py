@@ -198,12 +198,10 @@ def test_partitioned_adjacency_branch_reproduces_the_whole_graph(cuda, parts, re
     assert_grad_close(db, b_full.grad, "db")
 
 
-def _grad_in_mode(lib, mode, g, h, gout, k, thr):
+def _backward_in_mode(lib, mode, g, h, gout, wsel, hint):
     from sngnn_amd import ops
     lib.sngnn_tuning_set(3, mode)
-    hp = h.clone().requires_grad_(True)
-    (ops.aggregate(hp, g, k, thr) * gout).sum().backward()
-    return hp.grad
+    return ops.aggregate_backward(g, h, gout, wsel, hint)
 
 
 @pytest.mark.parametrize("n,e,C,hubs,rem,k,thr", CASES + [
@@ -211,12 +209,17 @@ def _grad_in_mode(lib, mode, g, h, gout, k, thr):
     (3000, 9000, 32, (), True, 2, 0.3),                            # G = 8: two trips over the lists
     (2000, 30000, 1, ((1, 1500),), True, 4, 0.0),
     (50, 0, 12, (), False, 3, 0.0),                                # loops only
+    (2500, 40000, 40, ((2, 2400),), True, 120, -1.0),              # up to 120 kept edges in a row's list
 ])
 def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k, thr):
     """sngnn_tuning_set(3, mode): a node small both as target and as source does its pass-T and
-    pass-S parts in one work item (dnT in registers, kept bits from k_kept_csc); the sums keep the
-    two passes' order, so grad_h is the same bit for bit - whole graphs and node-range partitions."""
-    from sngnn_amd import _lib
+    pass-S parts in one work item (dnT in registers, kept bits from the packed mask); the sums keep
+    the two passes' order, so grad_h is the same bit for bit - whole graphs and node-range
+    partitions.  With the forward's top_k as a hint every node is one work item (rows of any
+    in-degree scanned by one wave): split rows then sum their kept edges in one chain instead of
+    per-task partial rows - equal to rounding; a hint that is NOT true changes nothing but the
+    speed."""
+    from sngnn_amd import _lib, ops
     from sngnn_amd.graph import Graph
     lib = _lib.load()
     ei = random_graph(n, e, seed=3 * n + e + C, hubs=hubs) if e else torch.zeros(2, 0, dtype=torch.long)
@@ -226,12 +229,25 @@ def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k
     h = torch.randn(n, C, generator=gen).to(cuda)
     h[7] = 0.0
     gout = torch.randn(n, C, generator=gen).to(cuda)
+
+    def close(x, y):
+        return float((x - y).abs().max()) <= 2e-6 * max(float(y.abs().max()), 1e-30)
+
     try:
         g = Graph(ei, n, True, rem)
-        assert torch.equal(_grad_in_mode(lib, 0, g, h, gout, k, thr), _grad_in_mode(lib, 1, g, h, gout, k, thr))
+        _, wsel, *_ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+        two = _backward_in_mode(lib, 1, g, h, gout, wsel, None)
+        assert torch.equal(_backward_in_mode(lib, 0, g, h, gout, wsel, None), two)
+        if k is not None:
+            hinted = _backward_in_mode(lib, 0, g, h, gout, wsel, k)
+            assert close(hinted, two)
+            assert torch.equal(hinted, _backward_in_mode(lib, 0, g, h, gout, wsel, k))      # deterministic
+        # a promise that does not hold (rows keep far more than 1 edge)
+        assert close(_backward_in_mode(lib, 0, g, h, gout, wsel, 1), two)
         lo, hi = n // 4, n // 4 + n // 3
         gp = Graph(ei, n, True, rem, row_range=(lo, hi))
-        assert torch.equal(_grad_in_mode(lib, 0, gp, h, gout[lo:hi], k, thr),
-                           _grad_in_mode(lib, 1, gp, h, gout[lo:hi], k, thr))
+        _, wsel_p, *_ = ops.aggregate_forward(gp, h, k, thr, save_for_backward=True)
+        two_p = _backward_in_mode(lib, 1, gp, h, gout[lo:hi].contiguous(), wsel_p, None)
+        assert torch.equal(_backward_in_mode(lib, 0, gp, h, gout[lo:hi].contiguous(), wsel_p, k), two_p)
     finally:
         lib.sngnn_tuning_set(3, 0)

@@ -26,22 +26,37 @@ def main():
     _, wsel, *_ = ops.aggregate_forward(g, h, k if k > 0 else None, thr, save_for_backward=True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     res = {}
-    for mode in (1, 0, 1, 0):
-        lib.sngnn_tuning_set(3, mode)
+    for mode in (1, 0, 2, 1, 0, 2):                   # 2 = node-centric with the top_k hint
+        lib.sngnn_tuning_set(3, min(mode, 1) if mode != 2 else 0)
         ts = []
         for _ in range(8):
             ev[0].record()
             for _ in range(10):
-                gh = ops.aggregate_backward(g, h, gout, wsel)
+                gh = ops.aggregate_backward(g, h, gout, wsel, k if (mode == 2 and k > 0) else None)
             ev[1].record()
             ev[1].synchronize()
             ts.append(ev[0].elapsed_time(ev[1]) * 100)
         res.setdefault(mode, []).append(float(np.mean(ts[2:])))
         res[("g", mode)] = gh
     lib.sngnn_tuning_set(3, 0)
+    for roles in (1, 2, 3):                           # timing only: results incomplete unless 3
+        lib.sngnn_tuning_set(4, roles)
+        ts = []
+        for _ in range(6):
+            ev[0].record()
+            for _ in range(10):
+                ops.aggregate_backward(g, h, gout, wsel, k if k > 0 else None)
+            ev[1].record()
+            ev[1].synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]) * 100)
+        print("with top_k, roles %d (1 wave-per-node items, 2 fused items): %.1f us/call" % (roles, float(np.mean(ts[2:]))))
+    lib.sngnn_tuning_set(4, 3)
     print("two passes   us/call:", res[1])
     print("node-centric us/call:", res[0])
-    print("equal bits:", bool(torch.equal(res[("g", 0)], res[("g", 1)])))
+    print("with top_k   us/call:", res[2])
+    print("equal bits:", bool(torch.equal(res[("g", 0)], res[("g", 1)])),
+          " hint vs two passes max |diff| / max |g|:",
+          float((res[("g", 2)] - res[("g", 1)]).abs().max() / res[("g", 1)].abs().max()))
 
 
 if __name__ == "__main__":
