@@ -17,13 +17,20 @@ def main():
     c = int(os.environ.get("C", 40))
     k = int(os.environ.get("TOP_K", 16))
     thr = float(os.environ.get("THR", 0.0))
-    d = synth.make_dataset(os.environ.get("GRAPH", "arxiv"))
-    n = d.x.shape[0]
-    g = Graph(d.edge_index.to(dev), n, True, True)
-    gen = torch.Generator().manual_seed(0)
-    h = torch.randn(n, c, generator=gen).to(dev)
-    gout = torch.randn(n, c, generator=gen).to(dev)
+    if os.environ.get("INPUTS", "bench") == "bench":          # bench.py's graph and h = lin(x)
+        import bench
+        n, c, ei, _, h, _ = bench.make_rank_inputs(os.environ.get("GRAPH", "arxiv"), 0, 1, 1234, dev, c)
+        g = Graph(ei, n, True, True)
+        gout = torch.randn(n, c, generator=torch.Generator().manual_seed(0)).to(dev)
+    else:                                                     # the test generator's graph, Gaussian rows
+        d = synth.make_dataset(os.environ.get("GRAPH", "arxiv"))
+        n = d.x.shape[0]
+        g = Graph(d.edge_index.to(dev), n, True, True)
+        gen = torch.Generator().manual_seed(0)
+        h = torch.randn(n, c, generator=gen).to(dev)
+        gout = torch.randn(n, c, generator=gen).to(dev)
     _, wsel, *_ = ops.aggregate_forward(g, h, k if k > 0 else None, thr, save_for_backward=True)
+    print("kept edges:", int((wsel > -3.0).sum()), "of", g.num_edges)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     res = {}
     for mode in (1, 0, 2, 1, 0, 2):                   # 2 = node-centric with the top_k hint
