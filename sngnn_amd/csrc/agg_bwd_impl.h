@@ -561,10 +561,13 @@ __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_
     int *s_i = lds_wave + WAVE_T;                // [WAVE_T] kept out-edges: target row
     int n = 0;
     // gather the n listed source rows into fin.t (per-group partial sums), two per group in flight
+    bool have_ids = false;                       // the list already holds source ids (rows <= WAVE_T)
     auto flush = [&]() {
         wave_lds_sync();
-        for (int t = lane; t < n; t += 64) elist[t] = a.col[elist[t]];
-        wave_lds_sync();
+        if (!have_ids) {
+            for (int t = lane; t < n; t += 64) elist[t] = a.col[elist[t]];
+            wave_lds_sync();
+        }
         for (int q0 = 0; q0 < n; q0 += 2 * NG) {
             const int qa = min(q0 + gid, n - 1), qb = min(q0 + NG + gid, n - 1);
             RowT xa, xb;
@@ -589,18 +592,32 @@ __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_
         n += total;
     };
     const int e_end = rs + deg;
-    for (int w0 = rs >> 5; w0 * 32 < e_end; w0 += 64) {
-        const int wi = w0 + lane;
-        unsigned word = (int64_t)wi * 32 < e_end ? a.kmask[wi] : 0u;
-        if (wi * 32 < rs) word &= ~0u << (rs & 31);                   // bits of the previous row
-        if (wi * 32 + 32 > e_end) word &= wi * 32 >= e_end ? 0u : ~0u >> ((32 - (e_end & 31)) & 31);
-        const int total = wave_sum_i(__popc(word));
-        if (total <= WAVE_T) append(word, wi, total);
-        else                                                          // (a hint that was not true)
-            for (int sb = 0; sb < 16; ++sb) {
-                const unsigned ws = (lane >> 2) == sb ? word : 0u;    // 4 words = 128 edges at a time
-                append(ws, wi, wave_sum_i(__popc(ws)));
-            }
+    if (deg <= WAVE_T) {
+        // a row one wave covers lane by edge: bits and source ids in one round trip (the word scan
+        // below needs a second one for the ids of the edges it found)
+        for (int base = 0; base < deg; base += 64) {
+            const int t = base + lane;
+            const bool kept = t < deg && kept_csr(a, rs + t);
+            const int j = t < deg ? a.col[rs + t] : 0;
+            const unsigned long long m = __ballot(kept);
+            if (kept) elist[n + prefix_popc(m)] = j;
+            n += __popcll(m);
+        }
+        have_ids = true;
+    } else {
+        for (int w0 = rs >> 5; w0 * 32 < e_end; w0 += 64) {
+            const int wi = w0 + lane;
+            unsigned word = (int64_t)wi * 32 < e_end ? a.kmask[wi] : 0u;
+            if (wi * 32 < rs) word &= ~0u << (rs & 31);                   // bits of the previous row
+            if (wi * 32 + 32 > e_end) word &= wi * 32 >= e_end ? 0u : ~0u >> ((32 - (e_end & 31)) & 31);
+            const int total = wave_sum_i(__popc(word));
+            if (total <= WAVE_T) append(word, wi, total);
+            else                                                          // (a hint that was not true)
+                for (int sb = 0; sb < 16; ++sb) {
+                    const unsigned ws = (lane >> 2) == sb ? word : 0u;    // 4 words = 128 edges at a time
+                    append(ws, wi, wave_sum_i(__popc(ws)));
+                }
+        }
     }
     // kept out-edges (pass-S part, out-degree <= WAVE_T): listed while the in-edge rows travel
     int nso = 0;

@@ -1,5 +1,6 @@
-"""Backward of the aggregation at config 4 (arxiv size, C 40, top_k 16, thr 0): device time of one
-backward call, node-centric (sngnn_tuning_set(3, 0), default) against the two passes (3, 1)."""
+"""Backward of the aggregation at config 4 (arxiv size, C 40, top_k 16, thr 0; GRAPH=products C=48
+for config 5's graph): device time of one backward call, node-centric (sngnn_tuning_set(3, 0),
+default) without and with the forward's top_k, against the two passes (3, 1)."""
 import os
 import sys
 
