@@ -65,6 +65,14 @@ while time.time() < t_end:
             sc = hr.grad.abs().max().clamp_min(1e-20)
             ge = (hg.grad.cpu() - hr.grad).abs().max()
             assert ge <= 5e-5 * sc, f"grad err {ge:.3e} scale {sc:.3e}"
+        # the backward's forms (csrc/agg_bwd_impl.h): two passes == node-centric without the
+        # forward's top_k, bit for bit; with it (what ops.aggregate just ran) equal to rounding
+        wsel_b = ops.aggregate_forward(g, hg.detach(), k, thr, save_for_backward=True)[1]
+        _lib.load().sngnn_tuning_set(3, 1)
+        two = ops.aggregate_backward(g, hg.detach(), gout.to(dev), wsel_b)
+        _lib.load().sngnn_tuning_set(3, 0)
+        assert torch.equal(ops.aggregate_backward(g, hg.detach(), gout.to(dev), wsel_b), two), "node-centric != two passes"
+        assert (hg.grad - two).abs().max() <= 2e-6 * max(float(two.abs().max()), 1e-30), "top_k form vs two passes"
         # --- partition of the same graph (two ranges) equals the whole
         if n >= 4:
             cut = int(rng.integers(1, n))
@@ -88,6 +96,8 @@ while time.time() < t_end:
             un, nrm, filt = ops.normalize_rows_filter(hg.detach())
             if filt is not None and not ops.filter_wanted(g, C, k, thr):
                 filt = None
+            if k is None:                     # nothing selected: sngnn_agg_forward scores on the fly from h
+                un, nrm, filt = hg.detach(), None, None
             o2, w2, i2 = torch.full_like(o1, float("nan")), torch.full_like(w1, float("nan")), torch.full_like(i1, float("nan"))
             for want in (0, 1):
                 ops.aggregate_forward_rows(g, un, nrm, filt, k, thr, flag, want, o2, w2, i2)
