@@ -42,6 +42,33 @@ __global__ __launch_bounds__(256) void k32(float *out, int iters, float a0, floa
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// the same with a DIFFERENT A and B register for every instruction of a 32-step block - the shape of
+// k_linear_rows' multiply block (A from 8 ds_read_b128, B = 96 resident W registers)
+template <int NCH>
+__global__ __launch_bounds__(256) void k16d(float *out, int iters, float a0, float b0)
+{
+    f32x4 acc[NCH];
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0, 0, 0, 0};
+    float a[32], b[NCH][32];
+    for (int u = 0; u < 32; ++u) {
+        a[u] = a0 + threadIdx.x + u;
+        for (int c = 0; c < NCH; ++c) b[c][u] = b0 + u + 32 * c;
+    }
+    for (int u = 0; u < 32; ++u) {
+        asm volatile("" : "+v"(a[u]));
+        for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(b[c][u]));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[c][u], acc[c], 0, 0, 0);
+    }
+    float s = 0;
+    for (int c = 0; c < NCH; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename K> void run(const char *name, K kern, int grid, int iters, double flop_per_mfma, int mfma_per_iter)
 {
     float *out;
@@ -70,6 +97,8 @@ int main()
         run("16x16x4 f32, 2 chains", k16<2>, grid, 200, 2048.0, 64);
         run("16x16x4 f32, 3 chains", k16<3>, grid, 200, 2048.0, 96);
         run("16x16x4 f32, 4 chains", k16<4>, grid, 200, 2048.0, 128);
+        run("16x16x4 f32, 3 chains, distinct A/B", k16d<3>, grid, 200, 2048.0, 96);
+        run("16x16x4 f32, 2 chains, distinct A/B", k16d<2>, grid, 200, 2048.0, 64);
         run("32x32x2 f32, 1 chain", k32<1>, grid, 200, 4096.0, 16);
         run("32x32x2 f32, 2 chains", k32<2>, grid, 200, 4096.0, 32);
     }

@@ -11,4 +11,6 @@ from sngnn_amd.train import epoch_time_ms  # noqa: E402
 
 dev = torch.device("cuda:0")
 n, c, ei, x, h, lin = bench.make_rank_inputs("arxiv", 0, 1, 1234, dev)
-print("epoch ms (graphed):", epoch_time_ms("arxiv", x, ei, n, c, 16, 0.0, graphed=True, epochs=20))
+share = os.environ.get("SHARE_EVAL", "0") == "1"          # default: the reference's three forwards
+print("epoch ms (graphed, share_eval_forward=%s):" % share,
+      epoch_time_ms("arxiv", x, ei, n, c, 16, 0.0, graphed=True, epochs=20, share_eval_forward=share))
