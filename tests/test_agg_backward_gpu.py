@@ -210,6 +210,9 @@ def _backward_in_mode(lib, mode, g, h, gout, wsel, hint):
     (2000, 30000, 1, ((1, 1500),), True, 4, 0.0),
     (50, 0, 12, (), False, 3, 0.0),                                # loops only
     (2500, 40000, 40, ((2, 2400),), True, 120, -1.0),              # up to 120 kept edges in a row's list
+    (700, 30000, 8, ((1, 650), (4, 300)), True, 128, -1.5),        # the largest top_k the hint serves
+    (4, 3, 4, (), True, 1, -1.5),                                  # a handful of edges: mask of one word
+    (3, 1, 2, (), False, 2, 0.0),
 ])
 def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k, thr):
     """sngnn_tuning_set(3, mode): a node small both as target and as source does its pass-T and
@@ -223,11 +226,11 @@ def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k
     from sngnn_amd.graph import Graph
     lib = _lib.load()
     ei = random_graph(n, e, seed=3 * n + e + C, hubs=hubs) if e else torch.zeros(2, 0, dtype=torch.long)
-    ei = torch.cat([ei, torch.stack([torch.full((n // 2,), 3), torch.arange(n // 2) * 2 + 1])], 1)
+    ei = torch.cat([ei, torch.stack([torch.full((n // 2,), min(3, n - 1)), torch.arange(n // 2) * 2 + 1])], 1)
     ei = torch.unique(ei, dim=1).to(cuda)
     gen = torch.Generator().manual_seed(C + n)
     h = torch.randn(n, C, generator=gen).to(cuda)
-    h[7] = 0.0
+    h[min(7, n - 1)] = 0.0
     gout = torch.randn(n, C, generator=gen).to(cuda)
 
     def close(x, y):
