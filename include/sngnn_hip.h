@@ -206,7 +206,9 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * the same selections, bit for bit);
  * knob 3 = sngnn_agg_backward: 0 (default) = node-centric (a node small both as target and as
  * source does both passes in one work item; with a top_k hint every node), 1 = the two passes for
- * every node (same bits without the hint; equal to rounding on split rows with it) */
+ * every node (same bits without the hint; equal to rounding on split rows with it);
+ * knob 4 = which items the hinted node-centric backward runs (bit 0 wave-per-node, bit 1 fused;
+ * default 3 - anything else leaves grad_h incomplete: timing only) */
 int sngnn_tuning_set(int which, int value);
 /* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
 int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,
