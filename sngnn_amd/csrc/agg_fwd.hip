@@ -69,7 +69,8 @@ static int g_role_mask = 7;
 static int g_table_mode = 0;
 extern "C" int sngnn_tuning_set(int which, int value)
 {
-    SN_REQUIRE(which == 0 || (which >= 2 && which <= 4), SNGNN_EINVAL, "unknown tuning knob");
+    SN_REQUIRE(which == 0 || (which >= 2 && which <= 5), SNGNN_EINVAL, "unknown tuning knob");
+    if (which == 5) return sngnn::set_lin_mode(value);
     if (which == 3) return sngnn::set_bwd_mode(value);
     if (which == 4) return sngnn::set_bwd_roles(value);
     if (which == 0) g_role_mask = value & 7;

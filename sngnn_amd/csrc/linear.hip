@@ -113,6 +113,50 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 
+// ---- fp32 products on the bf16 matrix cores (BF3 = true) --------------------------------------
+// The fp32 MFMAs (`v_mfma_f32_16x16x4_f32`) are not XDL operations: they run on the vector ALU's
+// pipes, 32 cycles each, and nothing else of the wave executes beside them - 13.5 us of the
+// 128 -> 40 kernel's 30, in front of which the LDS transpose and (NORM) the epilogue's divisions
+// queue up.  A float is the exact sum of three bf16 values (8 + 8 + 8 significant bits: truncate
+// to the top 16 bits, subtract, repeat - every step exact), a product of two bf16 values is
+// exact in fp32, and `v_mfma_f32_16x16x32_bf16` multiplies 8 k-slots per lane in 16 cycles on
+// the XDL pipe while the vector ALU stays free.  x W^T is therefore computed as the eight partial
+// products x_i w_j, i + j <= 5 (all but x_3 w_3, which is below 2^-32 of the result), accumulated
+// in fp32 by the matrix core, smallest terms first: the rounding is that of an fp32 dot product
+// (tests/test_head_linear_gpu.py checks it against float64 beside the fp32-MFMA form), the
+// matrix work drops from 3 072 to 1 536 cycles per tile and hides the split, the transpose and
+// the epilogue behind it.  Non-finite inputs: an infinity or a NaN in x (in W) makes its whole
+// output row (column) NaN - the second plane of inf is inf - inf - where fp32 arithmetic gives
+// +-inf for an infinity times a non-zero weight: the one deviation (such rows are NaN one line
+// later in the reference too: F.normalize of a row with an infinity, models.py:238).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
+
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], u32x4v &p1, u32x4v &p2, u32x4v &p3)
+{
+    unsigned u1[8], u2[8], u3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u1[i] = __float_as_uint(v[i]);
+        const float f1 = __uint_as_float(u1[i] & 0xFFFF0000u);
+        const float r1 = v[i] - f1;                             // exact; <= 16 significant bits (inf, NaN -> NaN)
+        u2[i] = __float_as_uint(r1);
+        const float f2 = __uint_as_float(u2[i] & 0xFFFF0000u);
+        u3[i] = __float_as_uint(r1 - f2);                       // exact; <= 8 significant bits
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                               // top halves of two floats -> one register
+        p1[q] = __builtin_amdgcn_perm(u1[2 * q + 1], u1[2 * q], 0x07060302u);
+        p2[q] = __builtin_amdgcn_perm(u2[2 * q + 1], u2[2 * q], 0x07060302u);
+        p3[q] = __builtin_amdgcn_perm(u3[2 * q + 1], u3[2 * q], 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4v &a, const u32x4v &b, const f32x4 &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // (one wave per SIMD is what is launched; the widest configuration - 64 output columns of 128
 // inputs: W^T alone is 128 registers - is allowed the whole register file, the others keep the
 // two-wave budget they were tuned with: at 256 registers the wide one spilled and took 65 us
@@ -123,8 +167,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 // wave-private LDS tile into the aggregation's row layout (VEC 4, G = 8 or 16 lanes per row),
 // there the same fma chain, the same DPP tree, the same IEEE square root and division.  Needs
 // C % 4 == 0.  h itself then leaves from that layout too (16-byte stores).
-template <int NT, int FQ, bool NORM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NT == 4 && FQ == 8) ? 1 : 2, (NT == 4 && FQ == 8) ? 1 : 2)))
+// BF3: the products on the bf16 matrix cores (above; FQ even); W^T is then three bf16 planes -
+// 1.5x the registers - and the kernel gets the whole register file of its one wave per SIMD.
+template <int NT, int FQ, bool NORM, bool BF3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((NT == 4 && FQ == 8) || BF3) ? 1 : 2, ((NT == 4 && FQ == 8) || BF3) ? 1 : 2)))
 void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                    int N, int C, float *__restrict__ h, int ntiles, float *__restrict__ un,
                    float *__restrict__ unrm, void *__restrict__ filt)
@@ -178,16 +224,28 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
 
     // B operands: W[c = 16 t + r16][kq KS + s].  (Columns >= C are clamped, not masked: they
     // only feed outputs that are never stored.)
-    float bw[NT][KS];
+    constexpr int NS = BF3 ? FQ / 2 : 1;              // bf16 steps of 8 k-slots per lane
+    float bw[BF3 ? 1 : NT][BF3 ? 1 : KS];
+    u32x4v bw1[BF3 ? NT : 1][NS], bw2[BF3 ? NT : 1][NS], bw3[BF3 ? NT : 1][NS];
     float bias[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int c = min(16 * t + r16, C - 1);
         bias[t] = b != nullptr ? b[c] : 0.f;
+        if constexpr (!BF3) {
 #pragma unroll
-        for (int j = 0; j < FQ; ++j) {
-            const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)c * F + kq * KS + 4 * j);
-            bw[t][4 * j + 0] = v.x; bw[t][4 * j + 1] = v.y; bw[t][4 * j + 2] = v.z; bw[t][4 * j + 3] = v.w;
+            for (int j = 0; j < FQ; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)c * F + kq * KS + 4 * j);
+                bw[t][4 * j + 0] = v.x; bw[t][4 * j + 1] = v.y; bw[t][4 * j + 2] = v.z; bw[t][4 * j + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(w + (size_t)c * F + kq * KS + 8 * sb);
+                const float4 v1 = *reinterpret_cast<const float4 *>(w + (size_t)c * F + kq * KS + 8 * sb + 4);
+                const float wv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split_bf16x8(wv, bw1[t][sb], bw2[t][sb], bw3[t][sb]);
+            }
         }
     }
     // D: col = lane & 15, row = 4 (lane >> 4) + reg.  Byte offset of this lane's element (t, r)
@@ -209,6 +267,68 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
         nr = make_rsrc(unrm, (unsigned)N * 4u);
         fr = make_rsrc(filt, filt != nullptr ? (unsigned)N * 128u : 0u);
     }
+    // NORM epilogue: part 1 writes the finished tile into the wave's LDS tile, part 2 reads it back
+    // in the aggregation's row layout.  (Carried INSIDE the next tile's multiply block - sliced
+    // between the MFMAs, fp32 or bf16 - it was no faster: 38.3 against 36.9 us.)
+    auto epi_write = [&](const f32x4 (&v)[NT]) {
+        float *ht = hts[wave];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ht[(4 * kq + r) * HLD + 16 * t + r16] = v[t][r];
+    };
+    auto epi_rest = [&](int tl_) {
+        // Stage by stage over ALL the tile's passes (4 rows of 16 lanes, or 8 of 8, per pass): one
+        // wave per SIMD has nobody to hide a dependent instruction's latency behind, so the
+        // independent rows are laid side by side (38.9 -> 36.9 us at 128 -> 40).
+        using RowT = Row<4, GN, 1>;
+        using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
+        constexpr int NP = 16 / RPWN;
+        float *ht = hts[wave];
+        const bool in = 4 * lgn < C;
+        RowT xr[NP];
+        unsigned roff[NP], grow[NP];
+        float q[NP], d[NP];
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx) {
+            const int rt = sidx * RPWN + gidn;
+            grow[sidx] = (unsigned)tl_ * 16u + (unsigned)rt;
+            const float4 tv = *reinterpret_cast<const float4 *>(ht + rt * HLD + (in ? 4 * lgn : 0));
+            xr[sidx].x[0][0] = in ? tv.x : 0.f; xr[sidx].x[0][1] = in ? tv.y : 0.f;
+            xr[sidx].x[0][2] = in ? tv.z : 0.f; xr[sidx].x[0][3] = in ? tv.w : 0.f;
+            roff[sidx] = in ? (grow[sidx] * (unsigned)C + 4u * lgn) * 4u : BUF_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4n{__float_as_uint(xr[sidx].x[0][0]), __float_as_uint(xr[sidx].x[0][1]),
+                       __float_as_uint(xr[sidx].x[0][2]), __float_as_uint(xr[sidx].x[0][3])}, hr, roff[sidx], 0, 0);
+        }
+        // F.normalize, exactly as k_normalize_rows does it
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx) q[sidx] = xr[sidx].dot_partial(xr[sidx]);
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx) q[sidx] = group_sum<GN>(q[sidx]);
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx) d[sidx] = fmaxf(ieee_sqrt(q[sidx]), EPS_NORM);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+            for (int sidx = 0; sidx < NP; ++sidx)
+                xr[sidx].x[0][cc] = ieee_div(xr[sidx].x[0][cc], d[sidx]);        // == Row::div_rn
+            }
+#pragma unroll
+        for (int sidx = 0; sidx < NP; ++sidx) {
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4n{__float_as_uint(xr[sidx].x[0][0]), __float_as_uint(xr[sidx].x[0][1]),
+                       __float_as_uint(xr[sidx].x[0][2]), __float_as_uint(xr[sidx].x[0][3])}, ur, roff[sidx], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[sidx]), nr, lgn == 0 ? grow[sidx] * 4u : BUF_OOB, 0, 0);
+            if constexpr (GN == 16) {
+                using u32x2n = __attribute__((ext_vector_type(2))) unsigned;
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    u32x2n{pack_half2(xr[sidx].x[0][0] * FILT_SCALE, xr[sidx].x[0][1] * FILT_SCALE),
+                           pack_half2(xr[sidx].x[0][2] * FILT_SCALE, xr[sidx].x[0][3] * FILT_SCALE)},
+                    fr, grow[sidx] * 128u + 8u * lgn, 0, 0);
+            }
+        }
+    };
     auto store_tile = [&](int tl_, const f32x4 (&v)[NT]) {
         if constexpr (!NORM) {
             const unsigned to = (unsigned)tl_ * 16u * (unsigned)C * 4u;
@@ -218,43 +338,9 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
                 for (int r = 0; r < 4; ++r)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[t][r]), hr, hoff[t][r] + to, 0, 0);
         } else {
-            using RowT = Row<4, GN, 1>;
-            using u32x4n = __attribute__((ext_vector_type(4))) unsigned;
-            float *ht = hts[wave];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ht[(4 * kq + r) * HLD + 16 * t + r16] = v[t][r];
+            epi_write(v);
             wave_barrier_lds();
-            const bool in = 4 * lgn < C;
-#pragma unroll
-            for (int sidx = 0; sidx < 16 / RPWN; ++sidx) {
-                const int rt = sidx * RPWN + gidn;
-                const unsigned grow = (unsigned)tl_ * 16u + (unsigned)rt;
-                RowT xrow;
-                const float4 tv = *reinterpret_cast<const float4 *>(ht + rt * HLD + (in ? 4 * lgn : 0));
-                xrow.x[0][0] = in ? tv.x : 0.f; xrow.x[0][1] = in ? tv.y : 0.f;
-                xrow.x[0][2] = in ? tv.z : 0.f; xrow.x[0][3] = in ? tv.w : 0.f;
-                const unsigned roff = in ? (grow * (unsigned)C + 4u * lgn) * 4u : BUF_OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    u32x4n{__float_as_uint(xrow.x[0][0]), __float_as_uint(xrow.x[0][1]),
-                           __float_as_uint(xrow.x[0][2]), __float_as_uint(xrow.x[0][3])}, hr, roff, 0, 0);
-                // F.normalize, exactly as k_normalize_rows does it
-                const float q = group_sum<GN>(xrow.dot_partial(xrow));
-                const float d = fmaxf(ieee_sqrt(q), EPS_NORM);
-                xrow.div_rn(d);
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    u32x4n{__float_as_uint(xrow.x[0][0]), __float_as_uint(xrow.x[0][1]),
-                           __float_as_uint(xrow.x[0][2]), __float_as_uint(xrow.x[0][3])}, ur, roff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d), nr, lgn == 0 ? grow * 4u : BUF_OOB, 0, 0);
-                if constexpr (GN == 16) {
-                    using u32x2n = __attribute__((ext_vector_type(2))) unsigned;
-                    __builtin_amdgcn_raw_buffer_store_b64(
-                        u32x2n{pack_half2(xrow.x[0][0] * FILT_SCALE, xrow.x[0][1] * FILT_SCALE),
-                               pack_half2(xrow.x[0][2] * FILT_SCALE, xrow.x[0][3] * FILT_SCALE)},
-                        fr, grow * 128u + 8u * lgn, 0, 0);
-                }
-            }
+            epi_rest(tl_);
         }
     };
     // The finished values of tile i (bias added) stay in their own registers and are stored
@@ -274,8 +360,19 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         asm volatile("" : "+v"(bias[t]));
+        if constexpr (!BF3) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(bw[t][k]));
+            for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(bw[t][k]));
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    asm volatile("" : "+v"(bw1[t][sb][q]));
+                    asm volatile("" : "+v"(bw2[t][sb][q]));
+                    asm volatile("" : "+v"(bw3[t][sb][q]));
+                }
+        }
     }
     auto multiply = [&](int tcur) {
         float4 a[FQ];
@@ -288,14 +385,35 @@ void k_linear_rows(const float *__restrict__ x, const float *__restrict__ w, con
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!BF3) {
 #pragma unroll
-        for (int j = 0; j < FQ; ++j) {
-            const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+            for (int j = 0; j < FQ; ++j) {
+                const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[t][4 * j + e], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bw[t][4 * j + e], acc[t], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                const float av[8] = {a[2 * sb].x, a[2 * sb].y, a[2 * sb].z, a[2 * sb].w,
+                                     a[2 * sb + 1].x, a[2 * sb + 1].y, a[2 * sb + 1].z, a[2 * sb + 1].w};
+                u32x4v a1, a2, a3;
+                split_bf16x8(av, a1, a2, a3);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {                 // smallest partial products first
+                    acc[t] = mfma_bf16(a3, bw2[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a2, bw3[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a3, bw1[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a2, bw2[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a1, bw3[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a2, bw1[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a1, bw2[t][sb], acc[t]);
+                    acc[t] = mfma_bf16(a1, bw1[t][sb], acc[t]);
+                }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -525,6 +643,11 @@ int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, f
     }
 }
 
+// sngnn_tuning_set(5, v): 0 (default) = the products of k_linear_rows on the bf16 matrix cores
+// (exact split, fp32 accumulation), 1 = fp32 MFMAs
+static int g_lin_fp32_mfma = 0;
+int set_lin_mode(int v) { g_lin_fp32_mfma = v ? 1 : 0; return SNGNN_OK; }
+
 template <int FQ>
 static int launch_linear_rows(const float *x, const float *w, const float *b, int N, int C, float *h,
                               float *un, float *unrm, void *filt, hipStream_t st)
@@ -536,22 +659,30 @@ static int launch_linear_rows(const float *x, const float *w, const float *b, in
 #define SNGNN_LIN_NORM_WGS 1
 #endif
     int grid = std::min(256, (ntiles + 3) / 4);
-    if (un != nullptr) {
-        grid = std::min(256 * SNGNN_LIN_NORM_WGS, (ntiles + 3) / 4);
-        switch ((C + 15) / 16) {
-        case 1: k_linear_rows<1, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
-        case 2: k_linear_rows<2, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
-        case 3: k_linear_rows<3, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
-        default: k_linear_rows<4, FQ, true><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt); break;
-        }
-    } else {
-        switch ((C + 15) / 16) {
-        case 1: k_linear_rows<1, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
-        case 2: k_linear_rows<2, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
-        case 3: k_linear_rows<3, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
-        default: k_linear_rows<4, FQ, false><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, nullptr, nullptr, nullptr); break;
+    if (un != nullptr) grid = std::min(256 * SNGNN_LIN_NORM_WGS, (ntiles + 3) / 4);
+    const int nt = std::min((C + 15) / 16, 4);
+    // products on the bf16 matrix cores (exact three-way split of both operands) unless switched
+    // off (sngnn_tuning_set(5, 1)) or the lane holds fewer than 8 k-slots (F = 16)
+    const bool bf3 = g_lin_fp32_mfma == 0 && FQ % 2 == 0;
+#define SNGNN_LIN_LAUNCH(NTV, NORMV, BF3V)                                                              \
+    k_linear_rows<NTV, FQ, NORMV, BF3V><<<grid, 256, 0, st>>>(x, w, b, N, C, h, ntiles, un, unrm, filt)
+#define SNGNN_LIN_NT(NORMV, BF3V)                                                                       \
+    switch (nt) {                                                                                      \
+    case 1: SNGNN_LIN_LAUNCH(1, NORMV, BF3V); break;                                                    \
+    case 2: SNGNN_LIN_LAUNCH(2, NORMV, BF3V); break;                                                    \
+    case 3: SNGNN_LIN_LAUNCH(3, NORMV, BF3V); break;                                                    \
+    default: SNGNN_LIN_LAUNCH(4, NORMV, BF3V); break;                                                   \
+    }
+    if constexpr (FQ % 2 == 0) {
+        if (bf3) {
+            if (un != nullptr) { SNGNN_LIN_NT(true, true) } else { SNGNN_LIN_NT(false, true) }
+            SN_HIP(hipGetLastError());
+            return SNGNN_OK;
         }
     }
+    if (un != nullptr) { SNGNN_LIN_NT(true, false) } else { SNGNN_LIN_NT(false, false) }
+#undef SNGNN_LIN_NT
+#undef SNGNN_LIN_LAUNCH
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }

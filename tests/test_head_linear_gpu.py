@@ -172,3 +172,56 @@ def test_model_path_uses_the_epilogue_and_matches_the_pass(cuda):
     assert torch.equal(out, out2)
     for a, p in zip(g1, conv.parameters()):
         assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize("n,f,c,scale", [(6000, 128, 40, 1.0), (5000, 64, 64, 1e-3), (4100, 32, 17, 1e4),
+                                         (4500, 128, 48, 1.0), (4097, 64, 5, 1.0)])
+def test_lin_on_the_bf16_matrix_cores_rounds_like_fp32(cuda, n, f, c, scale):
+    """sngnn_tuning_set(5, mode): k_linear_rows multiplies on the bf16 matrix cores after an EXACT
+    three-way split of both operands (eight partial products, fp32 accumulation; default) or with
+    fp32 MFMAs.  Against float64: both forms are fp32 dot products - the split form's error is no
+    larger than the fp32 form's (to 1.5x + one ulp of the result's scale), and far below what a
+    bf16 or even a tf32-like product would give; cancelling rows, a wide dynamic range inside a row,
+    a row with an infinity or a NaN comes out NaN (documented deviation: fp32 gives +-inf for inf)."""
+    from sngnn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + f + c)
+    x = torch.randn(n, f, generator=g) * scale
+    x[:, ::3] *= 2.0 ** -9                                   # a wide dynamic range inside every row
+    w = torch.randn(c, f, generator=g) / f ** 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    x[7] = 0.0
+    x[11, 1::2] = -x[11, 0::2]                               # products that cancel: set w so that they do
+    w[:, 1::2] = w[:, 0::2]
+    ref = (x.double() @ w.double().t() + b.double())
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.sngnn_tuning_set(5, mode)
+            h = torch.empty(n, c, device=cuda)
+            _lib.check(lib.sngnn_linear_forward(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), n, f, c, h.data_ptr(), st), "lin")
+            out[mode] = h.cpu().double()
+    finally:
+        lib.sngnn_tuning_set(5, 0)
+    # the bound of an fp32 dot product: (f + 2) roundings of 2^-24 on the sum of |x w|
+    mag = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    err = {m: ((out[m] - ref).abs() / mag.clamp_min(1e-300)).max().item() for m in out}
+    assert err[1] <= (f + 2) * 2.0 ** -24 and err[0] <= (f + 2) * 2.0 ** -24, err
+    assert err[0] <= 1.5 * err[1] + 2.0 ** -24, err
+    assert torch.equal(out[0][7], b.double()) and (out[0][11] - b.double()).abs().max() <= 1e-6 * scale
+    # non-finite inputs: the affected rows come out non-finite (NaN: the split of an infinity
+    # holds inf - inf), every other row is untouched
+    x2 = x[:4096].clone()
+    x2[3, 5] = float("inf")
+    x2[4, 6] = float("-inf")
+    x2[5, 0] = float("nan")
+    h2 = torch.empty(4096, c, device=cuda)
+    xx = x2.to(cuda)
+    _lib.check(lib.sngnn_linear_forward(xx.data_ptr(), wd.data_ptr(), bd.data_ptr(), 4096, f, c, h2.data_ptr(), st), "lin")
+    got = h2.cpu()
+    assert not torch.isfinite(got[3:6]).any()
+    keep = torch.ones(4096, dtype=torch.bool)
+    keep[3:6] = False
+    assert torch.equal(got[keep].double(), out[0][:4096][keep])

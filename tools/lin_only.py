@@ -1,4 +1,4 @@
-"""Tuning aid: 50 calls of self.lin's forward at arxiv size, plain and with the normalising
+"""Tuning aid: 200 calls of self.lin's forward at arxiv size, plain and with the normalising
 epilogue (run under tools/profile_cmd.sh for rocprofv3 kernel times)."""
 import os
 import sys
@@ -13,8 +13,8 @@ f, c = int(os.environ.get("F", 128)), int(os.environ.get("C", 40))
 x = torch.randn(169343, f, device=dev)
 lin = torch.nn.Linear(f, c).to(dev)
 with torch.no_grad():
-    for _ in range(50):
+    for _ in range(200):
         ops.linear(x, lin)
-    for _ in range(50):
+    for _ in range(200):
         ops._Linear.apply(x, lin.weight, lin.bias, None, None, ops.UnitRows(False))
 torch.cuda.synchronize()
