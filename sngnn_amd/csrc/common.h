@@ -41,6 +41,7 @@ int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, f
 int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knobs 3, 4)
 int set_bwd_roles(int v);
 int set_lin_mode(int v);       // linear.hip (knob 5)
+bool fp32_mfma_only();         // knob 5 == 1: the fp32 contractions stay on fp32 MFMAs
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -647,6 +647,7 @@ int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, f
 // (exact split, fp32 accumulation), 1 = fp32 MFMAs
 static int g_lin_fp32_mfma = 0;
 int set_lin_mode(int v) { g_lin_fp32_mfma = v ? 1 : 0; return SNGNN_OK; }
+bool fp32_mfma_only() { return g_lin_fp32_mfma != 0; }
 
 template <int FQ>
 static int launch_linear_rows(const float *x, const float *w, const float *b, int N, int C, float *h,

@@ -98,13 +98,47 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // the contraction is split over ks workgroups per tile, each writes its raw partial tile
 // (both orientations) to part[s] and k_cosine_reduce adds the ks partials in a fixed order
 // and applies the inverse norms.
+// BF3 (default): the products on the BF16 matrix cores.  fp32 MFMAs run on the vector ALU's pipes
+// (a 32x32x2 takes 64 cycles); a float is the exact sum of three bf16 values and a product of two
+// bf16 values is exact in fp32, so every panel is split ONCE, when it is staged into LDS (three
+// bf16 planes, rows of 64 + 16 bytes: conflict-free 16-byte reads), and a K-step of 32 is
+// 2 x 8 `v_mfma_f32_32x32x16_bf16` per output block - the eight partial products x_i y_j with
+// i + j <= 5, smallest first, fp32 accumulation - instead of 16 fp32 MFMAs: half the matrix
+// cycles at an fp32 dot product's rounding (linear.hip has the argument and the measurements).
+constexpr int TB_PS = 80;                     // bytes per row of a bf16 plane: 32 k-slots + 16 bytes of padding
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4t = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2t = __attribute__((ext_vector_type(2))) unsigned;
+
+// three bf16 planes of four floats (truncating split: v = p1 + p2 + p3 exactly)
+__device__ __forceinline__ void split_bf16x4(const f4 &v, u32x2t &p1, u32x2t &p2, u32x2t &p3)
+{
+    unsigned u1[4], u2[4], u3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u1[i] = __float_as_uint(v[i]);
+        const float r1 = v[i] - __uint_as_float(u1[i] & 0xFFFF0000u);
+        u2[i] = __float_as_uint(r1);
+        u3[i] = __float_as_uint(r1 - __uint_as_float(u2[i] & 0xFFFF0000u));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        p1[q] = __builtin_amdgcn_perm(u1[2 * q + 1], u1[2 * q], 0x07060302u);
+        p2[q] = __builtin_amdgcn_perm(u2[2 * q + 1], u2[2 * q], 0x07060302u);
+        p3[q] = __builtin_amdgcn_perm(u3[2 * q + 1], u3[2 * q], 0x07060302u);
+    }
+}
+
+template <bool BF3>
 __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x, int64_t N,
                                                      int64_t ld, const float *__restrict__ inv,
                                                      float *__restrict__ S, int nb, int ks, int64_t k_per,
                                                      float *__restrict__ part)
 {
-    __shared__ __align__(16) float sA[TB_M * TB_LD];
-    __shared__ __align__(16) float sB[TB_M * TB_LD];
+    constexpr int PANEL_BYTES = BF3 ? 3 * TB_M * TB_PS : TB_M * TB_LD * 4;
+    __shared__ __align__(16) unsigned char smemA[PANEL_BYTES];
+    __shared__ __align__(16) unsigned char smemB[PANEL_BYTES];
+    float *sA = reinterpret_cast<float *>(smemA), *sB = reinterpret_cast<float *>(smemB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;          // wave's 64x64 quadrant
     // linear workgroup id -> (by <= bx) of the upper triangle, row by row
@@ -162,16 +196,65 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
             *(f4 *)(wb + 64 * TB_LD) = (ob2 && kin_) ? vb2 : z; *(f4 *)(wb + 96 * TB_LD) = (ob3 && kin_) ? vb3 : z; \
         }                                                                                    \
     }
+    // BF3 staging: the same vectors, split, 8 bytes per plane at [plane][row][4 kq ..]
+#define SN_STAGE3(K0)                                                                        \
+    {                                                                                        \
+        const bool kin_ = 4 * kq + (K0) < k_end;                                             \
+        auto put = [&](unsigned char *base, int row, const f4 &v) {                          \
+            u32x2t p1, p2, p3;                                                               \
+            split_bf16x4(v, p1, p2, p3);                                                     \
+            unsigned char *d_ = base + row * TB_PS + 8 * kq;                                 \
+            *(u32x2t *)(d_) = p1;                                                            \
+            *(u32x2t *)(d_ + TB_M * TB_PS) = p2;                                             \
+            *(u32x2t *)(d_ + 2 * TB_M * TB_PS) = p3;                                         \
+        };                                                                                   \
+        const f4 s0 = (oa0 && kin_) ? va0 : z, s1 = (oa1 && kin_) ? va1 : z;                 \
+        const f4 s2 = (oa2 && kin_) ? va2 : z, s3 = (oa3 && kin_) ? va3 : z;                 \
+        put(smemA, r0, s0); put(smemA, r0 + 32, s1); put(smemA, r0 + 64, s2); put(smemA, r0 + 96, s3); \
+        if (diag) {                                                                          \
+            put(smemB, r0, s0); put(smemB, r0 + 32, s1); put(smemB, r0 + 64, s2); put(smemB, r0 + 96, s3); \
+        } else {                                                                             \
+            put(smemB, r0, (ob0 && kin_) ? vb0 : z); put(smemB, r0 + 32, (ob1 && kin_) ? vb1 : z);     \
+            put(smemB, r0 + 64, (ob2 && kin_) ? vb2 : z); put(smemB, r0 + 96, (ob3 && kin_) ? vb3 : z); \
+        }                                                                                    \
+    }
     vb0 = vb1 = vb2 = vb3 = z;
     SN_FETCH(k_begin)
     const int li = lane & 31, lh = lane >> 5;
     const float *pa0 = sA + (wr * 64 + li) * TB_LD + 16 * lh, *pa1 = pa0 + 32 * TB_LD;
     const float *pb0 = sB + (wc * 64 + li) * TB_LD + 16 * lh, *pb1 = pb0 + 32 * TB_LD;
+    // BF3: lane (li, lh) of k-group g reads the 8 k-slots 16 g + 8 lh .. of its row from each plane
+    const unsigned char *qa = smemA + (wr * 64 + li) * TB_PS + 16 * lh;
+    const unsigned char *qb = smemB + (wc * 64 + li) * TB_PS + 16 * lh;
     for (int64_t k0 = k_begin; k0 < k_end; k0 += TB_K) {
         __syncthreads();                                  // previous step's LDS reads are done
-        SN_STAGE(k0)
+        if constexpr (BF3) SN_STAGE3(k0) else SN_STAGE(k0)
         __syncthreads();
         if (k0 + TB_K < k_end) SN_FETCH(k0 + TB_K)        // in flight during the MFMAs below
+        if constexpr (BF3) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                u32x4t A[2][3], B[2][3];
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        A[blk][pl] = *(const u32x4t *)(qa + (pl * TB_M + blk * 32) * TB_PS + 32 * g);
+                        B[blk][pl] = *(const u32x4t *)(qb + (pl * TB_M + blk * 32) * TB_PS + 32 * g);
+                    }
+#define SN_M3(a_, b_, PA, PB)                                                                           \
+                acc[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[a_][PA]), \
+                                                                      __builtin_bit_cast(bf16x8, B[b_][PB]), acc[a_][b_], 0, 0, 0);
+#pragma unroll
+                for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+                    for (int b_ = 0; b_ < 2; ++b_) {              // smallest partial products first
+                        SN_M3(a_, b_, 2, 1) SN_M3(a_, b_, 1, 2) SN_M3(a_, b_, 2, 0) SN_M3(a_, b_, 1, 1)
+                        SN_M3(a_, b_, 0, 2) SN_M3(a_, b_, 1, 0) SN_M3(a_, b_, 0, 1) SN_M3(a_, b_, 0, 0)
+                    }
+#undef SN_M3
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f4 ca0 = *(const f4 *)(pa0 + 4 * q), ca1 = *(const f4 *)(pa1 + 4 * q);
@@ -187,6 +270,7 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
     }
 #undef SN_FETCH
 #undef SN_STAGE
+#undef SN_STAGE3
     // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     // The tile itself leaves with the lanes along a row of S; its mirror image is transposed
     // through LDS (the panels are dead) so that it leaves the same way.
@@ -421,7 +505,10 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     ks = (int)((ld + k_per - 1) / k_per);
     AsyncBuf part(st);
     if (ks > 1) SN_REQUIRE(part.alloc((size_t)ks * N * N * 4) == 0, SNGNN_ENOMEM, "out of device memory");
-    k_cosine_mfma<<<tiles * ks, 256, 0, st>>>(xs, N, ld, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
+    if (sngnn::fp32_mfma_only())
+        k_cosine_mfma<false><<<tiles * ks, 256, 0, st>>>(xs, N, ld, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
+    else
+        k_cosine_mfma<true><<<tiles * ks, 256, 0, st>>>(xs, N, ld, inv.as<float>(), S, nb, ks, k_per, part.as<float>());
     if (ks > 1) {
         SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "internal: split contraction is for small N only");
         k_cosine_reduce<<<dim3((unsigned)std::min<int64_t>((N + 255) / 256, 8), (unsigned)N), 256, 0, st>>>(

@@ -26,7 +26,8 @@ def _stream(t):
 
 
 def cosine_similarity_dense_small(x: torch.Tensor) -> torch.Tensor:
-    """dense.py:138-141: S = normalize(x) @ normalize(x).T, [N, N] (fp32 MFMA)."""
+    """dense.py:138-141: S = normalize(x) @ normalize(x).T, [N, N] (matrix cores: exact bf16 split of
+    both operands, fp32 accumulation - an fp32 contraction's rounding; csrc/toolbox.hip)."""
     x = _x(x)
     n, f = x.shape
     s = torch.empty((n, n), dtype=torch.float32, device=x.device)

@@ -365,3 +365,31 @@ def test_class_sums_are_deterministic_and_atomics_free(cuda):
     want = m @ m.t()
     assert (a.cpu() - want).abs().max() <= 1e-6 * want.abs().max()
     assert abs(float(da) - n) < 1e-3
+
+
+@pytest.mark.parametrize("n,f", [(700, 128), (1500, 1433), (2277, 200), (300, 36)])
+def test_cosine_dense_on_the_bf16_cores_rounds_like_fp32(cuda, n, f):
+    """sngnn_tuning_set(5, mode): the dense cosine's products on the bf16 matrix cores after an exact
+    three-way split of both panels (default) or with fp32 MFMAs - against float64 the split form is
+    no worse than the fp32 form, and both are far inside the fp32 cosine tolerance."""
+    from sngnn_amd import _lib, toolbox as T
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + f)
+    x = torch.randn(n, f, generator=g)
+    x[:, ::5] *= 2.0 ** -7                                    # a dynamic range inside the rows
+    x[3] = x[4] * 3.0                                         # cosine exactly 1
+    x[9] = 0.0
+    xn = torch.nn.functional.normalize(x.double(), dim=1)
+    ref = xn @ xn.t()
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.sngnn_tuning_set(5, mode)
+            out[mode] = T.cosine_similarity_dense_small(x.to(cuda)).cpu().double()
+    finally:
+        lib.sngnn_tuning_set(5, 0)
+    err = {m: float((out[m] - ref).abs().max()) for m in out}
+    assert err[0] <= COS_TOL and err[1] <= COS_TOL, err
+    assert err[0] <= 1.5 * err[1] + 2.0 ** -24, err
+    assert float((out[0] - out[0].t()).abs().max()) <= 2.0 ** -22          # (mirror tiles: same bits; diagonal tiles: to rounding)
+    assert (out[0][9] == 0).all()

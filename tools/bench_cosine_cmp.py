@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sngnn_amd import synth, toolbox  # noqa: E402
 
 dev = torch.device("cuda:0")
-PEAK = 157.3          # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK = 157.3          # TFLOP/s, dense fp32 MFMA (MI355X_MICROARCH.md); the hand-written kernel's products run on the
+                      # bf16 matrix cores (exact split, 8 partial products): its column is fp32-equivalent flops / this peak
 
 
 def timed(fn, reps=20, warm=3):
