@@ -209,7 +209,7 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * every node (same bits without the hint; equal to rounding on split rows with it);
  * knob 4 = which items the hinted node-centric backward runs (bit 0 wave-per-node, bit 1 fused;
  * default 3 - anything else leaves grad_h incomplete: timing only);
- * knob 5 = sngnn_linear_forward* and sngnn_cosine_dense: 0 (default) = products on the bf16 matrix
+ * knob 5 = sngnn_linear_forward*, sngnn_cosine_dense, sngnn_knn_graph: 0 (default) = products on the bf16 matrix
  * cores after an exact three-way split of both operands (fp32 accumulation, an fp32 contraction's
  * rounding), 1 = fp32 MFMAs */
 int sngnn_tuning_set(int which, int value);

@@ -85,6 +85,55 @@ __device__ __forceinline__ unsigned long long sel_key(float s, unsigned idx)
     return ((unsigned long long)f2key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
 
+// ---- fp32 operands for the bf16 matrix cores --------------------------------------------------
+// A float is the EXACT sum of three bf16 values (truncate to the top 16 bits, subtract, repeat:
+// 8 + 8 + 8 significant bits; every step exact), and a product of two bf16 values is exact in
+// fp32.  The fp32 contractions of the library (lin, dense cosine, kNN builder) therefore run as
+// eight bf16 partial products x_i y_j, i + j <= 5, accumulated in fp32 by `v_mfma_f32_*_bf16`
+// (XDL pipe, 8 k-slots per lane and instruction) instead of fp32 MFMAs, which execute on the
+// vector ALU's own pipes at a quarter of the k-slots per cycle (linear.hip has the measurements).
+using sn_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using sn_u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using sn_u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+// one float -> its three planes' bit patterns (the bf16 value of plane p is the top half of u[p])
+__device__ __forceinline__ void split_bf16_bits(float v, unsigned &u1, unsigned &u2, unsigned &u3)
+{
+    u1 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u1 & 0xFFFF0000u);     // exact; <= 16 significant bits (inf, NaN -> NaN)
+    u2 = __float_as_uint(r1);
+    u3 = __float_as_uint(r1 - __uint_as_float(u2 & 0xFFFF0000u));   // exact; <= 8 significant bits
+}
+// top halves of two floats' bits -> one register (even element in the low half)
+__device__ __forceinline__ unsigned pack_bf16_hi(unsigned even, unsigned odd)
+{
+    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+__device__ __forceinline__ void split_bf16x8(const float (&v)[8], sn_u32x4 &p1, sn_u32x4 &p2, sn_u32x4 &p3)
+{
+    unsigned u1[8], u2[8], u3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split_bf16_bits(v[i], u1[i], u2[i], u3[i]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        p1[q] = pack_bf16_hi(u1[2 * q], u1[2 * q + 1]);
+        p2[q] = pack_bf16_hi(u2[2 * q], u2[2 * q + 1]);
+        p3[q] = pack_bf16_hi(u3[2 * q], u3[2 * q + 1]);
+    }
+}
+__device__ __forceinline__ void split_bf16x4(const float (&v)[4], sn_u32x2 &p1, sn_u32x2 &p2, sn_u32x2 &p3)
+{
+    unsigned u1[4], u2[4], u3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_bf16_bits(v[i], u1[i], u2[i], u3[i]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        p1[q] = pack_bf16_hi(u1[2 * q], u1[2 * q + 1]);
+        p2[q] = pack_bf16_hi(u2[2 * q], u2[2 * q + 1]);
+        p3[q] = pack_bf16_hi(u3[2 * q], u3[2 * q + 1]);
+    }
+}
+
 // Correctly rounded fp32 square root and division.  Plain sqrtf() and `/` ARE that under
 // hipcc's defaults (-fhip-fp32-correctly-rounded-divide-sqrt; the build passes no fast-math
 // flag) - unlike HIP's __fsqrt_rn(), which ROCm 7.2's headers map to the approximate

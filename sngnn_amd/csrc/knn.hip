@@ -72,14 +72,21 @@ __device__ __forceinline__ unsigned long long merge_row(unsigned long long *list
 // lane (row, half h) keeps the contiguous half k in [h FH, (h + 1) FH) of its row - and only
 // the column panel streams through LDS (half the staging, 4 LDS reads per 4 MFMAs).
 // FH == 0: any F, both panels through LDS.
-template <int FH>
+// BF3 (with FH > 0; default): the products on the bf16 matrix cores (device_utils.h: exact
+// three-way split of both operands, eight partial products, fp32 accumulation) - the rows'
+// operands are split once, into registers; the column panel is split when it is staged (three
+// bf16 planes, rows of 64 + 16 bytes); a step of 16 k-slots per half is 2 x 8
+// `v_mfma_f32_32x32x16_bf16` per column block instead of 16 fp32 MFMAs.
+constexpr int KN_PS = 80;                      // bytes per row of a bf16 plane of the column panel
+template <int FH, bool BF3>
 __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, int64_t N, int64_t F,
                                                   const float *__restrict__ inv, int k, int exclude_self,
                                                   int tiles_per_split, unsigned long long *__restrict__ part,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_sim)
 {
+    static_assert(!BF3 || FH > 0, "the bf16 form is the register-operand path's");
     __shared__ float sA[FH > 0 ? 1 : KN_M * KN_LD];
-    __shared__ float sB[KN_M * KN_LD];
+    __shared__ __align__(16) float sB[BF3 ? 3 * KN_M * KN_PS / 4 : KN_M * KN_LD];
     __shared__ unsigned long long s_list[4][32][KNN_MAX_K];     // running top-k keys per row
     __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
     __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
@@ -96,13 +103,24 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
     const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_split;
     const int64_t ct_end = min(ncol_tiles, ct_begin + tiles_per_split);
 
-    float areg[FH > 0 ? FH : 1];
+    float areg[(FH > 0 && !BF3) ? FH : 1];
+    sn_u32x4 ap1[BF3 ? FH / 8 : 1], ap2[BF3 ? FH / 8 : 1], ap3[BF3 ? FH / 8 : 1];     // the rows' three bf16 planes
     if constexpr (FH > 0) {
         const int64_t ar = min(row0 + wave * 32 + l32, N - 1);          // (rows >= N are never used)
+        if constexpr (!BF3) {
 #pragma unroll
-        for (int q = 0; q < FH / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + ar * F + half * FH + 4 * q);
-            areg[4 * q] = v.x; areg[4 * q + 1] = v.y; areg[4 * q + 2] = v.z; areg[4 * q + 3] = v.w;
+            for (int q = 0; q < FH / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + ar * F + half * FH + 4 * q);
+                areg[4 * q] = v.x; areg[4 * q + 1] = v.y; areg[4 * q + 2] = v.z; areg[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < FH / 8; ++q) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(x + ar * F + half * FH + 8 * q);
+                const float4 v1 = *reinterpret_cast<const float4 *>(x + ar * F + half * FH + 8 * q + 4);
+                const float av[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split_bf16x8(av, ap1[q], ap2[q], ap3[q]);
+            }
         }
     }
 
@@ -135,16 +153,52 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             if (ct == ct_begin) SN_KNN_FETCH(col0, 0)
             float *wb = sB + pr * KN_LD + 4 * seg;
             const float *pb = sB + l32 * KN_LD + half * 16;
+            // BF3: plane p of column row r at byte (p * KN_M + r) * KN_PS; its 32 k-slots are the
+            // step's 16 of half 0 followed by the 16 of half 1 (seg 0..3 | 4..7, 8 bytes each)
+            unsigned char *wb3 = reinterpret_cast<unsigned char *>(sB) + pr * KN_PS + 8 * seg;
+            const unsigned char *pb3 = reinterpret_cast<const unsigned char *>(sB) + l32 * KN_PS + 32 * half;
 #pragma unroll
             for (int s0 = 0; s0 < FH; s0 += 16) {
                 __syncthreads();
-                *(knn_f4 *)(wb) = rb0;
-                *(knn_f4 *)(wb + 32 * KN_LD) = rb1;
-                *(knn_f4 *)(wb + 64 * KN_LD) = rb2;
-                *(knn_f4 *)(wb + 96 * KN_LD) = rb3;
+                if constexpr (!BF3) {
+                    *(knn_f4 *)(wb) = rb0;
+                    *(knn_f4 *)(wb + 32 * KN_LD) = rb1;
+                    *(knn_f4 *)(wb + 64 * KN_LD) = rb2;
+                    *(knn_f4 *)(wb + 96 * KN_LD) = rb3;
+                } else {
+                    auto put = [&](int u, const knn_f4 &v) {
+                        const float vv[4] = {v[0], v[1], v[2], v[3]};
+                        sn_u32x2 p1, p2, p3;
+                        split_bf16x4(vv, p1, p2, p3);
+                        unsigned char *d_ = wb3 + 32 * u * KN_PS;
+                        *(sn_u32x2 *)(d_) = p1;
+                        *(sn_u32x2 *)(d_ + KN_M * KN_PS) = p2;
+                        *(sn_u32x2 *)(d_ + 2 * KN_M * KN_PS) = p3;
+                    };
+                    put(0, rb0); put(1, rb1); put(2, rb2); put(3, rb3);
+                }
                 __syncthreads();
                 if (s0 + 16 < FH) SN_KNN_FETCH(col0, s0 + 16)
                 else if (ct + 1 < ct_end) SN_KNN_FETCH(col0 + KN_M, 0)
+                if constexpr (BF3) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {          // 8 k-slots of each half per MFMA
+                        const int aq = s0 / 8 + g;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const unsigned char *r_ = pb3 + 32 * b * KN_PS + 16 * g;
+                            const sn_u32x4 b1 = *(const sn_u32x4 *)(r_);
+                            const sn_u32x4 b2 = *(const sn_u32x4 *)(r_ + KN_M * KN_PS);
+                            const sn_u32x4 b3 = *(const sn_u32x4 *)(r_ + 2 * KN_M * KN_PS);
+#define SN_KNN_M3(PA, PB)                                                                                   \
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sn_bf16x8, PA), \
+                                                                             __builtin_bit_cast(sn_bf16x8, PB), acc[b], 0, 0, 0);
+                            SN_KNN_M3(ap3[aq], b2) SN_KNN_M3(ap2[aq], b3) SN_KNN_M3(ap3[aq], b1) SN_KNN_M3(ap2[aq], b2)
+                            SN_KNN_M3(ap1[aq], b3) SN_KNN_M3(ap2[aq], b1) SN_KNN_M3(ap1[aq], b2) SN_KNN_M3(ap1[aq], b1)
+#undef SN_KNN_M3
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const knn_f4 b0 = *(const knn_f4 *)(pb + 4 * q), b1 = *(const knn_f4 *)(pb + 32 * KN_LD + 4 * q);
@@ -411,11 +465,12 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     dim3 grid((unsigned)nrb, (unsigned)ns_used);
     unsigned long long *pp = ns_used > 1 ? part : nullptr;
     const bool areg = (uintptr_t)x % 16 == 0;
-    if (areg && F == 128) k_knn_mfma<64><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
-    else if (areg && F == 96) k_knn_mfma<48><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
-    else if (areg && F == 64) k_knn_mfma<32><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
-    else if (areg && F == 32) k_knn_mfma<16><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
-    else k_knn_mfma<0><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    const bool bf3 = !sngnn::fp32_mfma_only();          // sngnn_tuning_set(5, 1): fp32 MFMAs
+    if (areg && F == 128) { if (bf3) k_knn_mfma<64, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<64, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
+    else if (areg && F == 96) { if (bf3) k_knn_mfma<48, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<48, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
+    else if (areg && F == 64) { if (bf3) k_knn_mfma<32, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<32, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
+    else if (areg && F == 32) { if (bf3) k_knn_mfma<16, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<16, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
+    else k_knn_mfma<0, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
     if (ns_used > 1) k_knn_merge<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(part, N, k, ns_used, nbr_idx, nbr_sim);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;

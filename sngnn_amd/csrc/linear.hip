@@ -129,32 +129,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 // output row (column) NaN - the second plane of inf is inf - inf - where fp32 arithmetic gives
 // +-inf for an infinity times a non-zero weight: the one deviation (such rows are NaN one line
 // later in the reference too: F.normalize of a row with an infinity, models.py:238).
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4v = __attribute__((ext_vector_type(4))) unsigned;
-
-__device__ __forceinline__ void split_bf16x8(const float (&v)[8], u32x4v &p1, u32x4v &p2, u32x4v &p3)
-{
-    unsigned u1[8], u2[8], u3[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u1[i] = __float_as_uint(v[i]);
-        const float f1 = __uint_as_float(u1[i] & 0xFFFF0000u);
-        const float r1 = v[i] - f1;                             // exact; <= 16 significant bits (inf, NaN -> NaN)
-        u2[i] = __float_as_uint(r1);
-        const float f2 = __uint_as_float(u2[i] & 0xFFFF0000u);
-        u3[i] = __float_as_uint(r1 - f2);                       // exact; <= 8 significant bits
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                               // top halves of two floats -> one register
-        p1[q] = __builtin_amdgcn_perm(u1[2 * q + 1], u1[2 * q], 0x07060302u);
-        p2[q] = __builtin_amdgcn_perm(u2[2 * q + 1], u2[2 * q], 0x07060302u);
-        p3[q] = __builtin_amdgcn_perm(u3[2 * q + 1], u3[2 * q], 0x07060302u);
-    }
-}
+using u32x4v = sn_u32x4;
 
 __device__ __forceinline__ f32x4 mfma_bf16(const u32x4v &a, const u32x4v &b, const f32x4 &c)
 {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sn_bf16x8, a), __builtin_bit_cast(sn_bf16x8, b), c, 0, 0, 0);
 }
 
 // (one wave per SIMD is what is launched; the widest configuration - 64 output columns of 128

@@ -13,7 +13,7 @@
 //                            one wave per edge, norms from the same pass.
 #include <hipcub/hipcub.hpp>
 
-#include "common.h"
+#include "device_utils.h"
 
 namespace sngnn {
 
@@ -106,28 +106,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // i + j <= 5, smallest first, fp32 accumulation - instead of 16 fp32 MFMAs: half the matrix
 // cycles at an fp32 dot product's rounding (linear.hip has the argument and the measurements).
 constexpr int TB_PS = 80;                     // bytes per row of a bf16 plane: 32 k-slots + 16 bytes of padding
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using u32x4t = __attribute__((ext_vector_type(4))) unsigned;
-using u32x2t = __attribute__((ext_vector_type(2))) unsigned;
-
-// three bf16 planes of four floats (truncating split: v = p1 + p2 + p3 exactly)
-__device__ __forceinline__ void split_bf16x4(const f4 &v, u32x2t &p1, u32x2t &p2, u32x2t &p3)
-{
-    unsigned u1[4], u2[4], u3[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        u1[i] = __float_as_uint(v[i]);
-        const float r1 = v[i] - __uint_as_float(u1[i] & 0xFFFF0000u);
-        u2[i] = __float_as_uint(r1);
-        u3[i] = __float_as_uint(r1 - __uint_as_float(u2[i] & 0xFFFF0000u));
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        p1[q] = __builtin_amdgcn_perm(u1[2 * q + 1], u1[2 * q], 0x07060302u);
-        p2[q] = __builtin_amdgcn_perm(u2[2 * q + 1], u2[2 * q], 0x07060302u);
-        p3[q] = __builtin_amdgcn_perm(u3[2 * q + 1], u3[2 * q], 0x07060302u);
-    }
-}
+using bf16x8 = sn_bf16x8;
+using u32x4t = sn_u32x4;
+using u32x2t = sn_u32x2;
 
 template <bool BF3>
 __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x, int64_t N,
@@ -202,7 +183,8 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
         const bool kin_ = 4 * kq + (K0) < k_end;                                             \
         auto put = [&](unsigned char *base, int row, const f4 &v) {                          \
             u32x2t p1, p2, p3;                                                               \
-            split_bf16x4(v, p1, p2, p3);                                                     \
+            const float vv_[4] = {v[0], v[1], v[2], v[3]};                                   \
+            split_bf16x4(vv_, p1, p2, p3);                                                   \
             unsigned char *d_ = base + row * TB_PS + 8 * kq;                                 \
             *(u32x2t *)(d_) = p1;                                                            \
             *(u32x2t *)(d_ + TB_M * TB_PS) = p2;                                             \
