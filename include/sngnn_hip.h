@@ -370,7 +370,10 @@ int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *
 /*
  * Replaces: self.lin's forward for narrow layers, h = x W^T + b with C <= 64
  * (models.py:121,237,324).  x dev f32 [N, F], weight dev f32 [C, F], bias dev f32 [C]
- * or NULL, h dev f32 [N, C].  Exact-fp32 MFMA; HBM-bound (x read once).
+ * or NULL, h dev f32 [N, C].  fp32 in, fp32 out, an fp32 dot product's rounding: for F in
+ * {32, 64, 128} the products run on the bf16 matrix cores after an EXACT three-way split of both
+ * operands, accumulated in fp32 (knob 5 of sngnn_tuning_set: fp32 MFMAs instead); HBM-bound (x
+ * read once).  An infinity or NaN in a row of x makes that output row NaN.
  */
 int sngnn_linear_forward(const float *x, const float *weight, const float *bias,
                          int64_t N, int F, int C, float *h, void *stream);
@@ -426,8 +429,8 @@ int sngnn_sparse_pair_dot(const int64_t *colptr, const int32_t *rowidx, const fl
 /*
  * kNN similarity graph (the north star's "Node-Similarity build"):
  * for every node the k most cosine-similar nodes, without storing the N x N similarity
- * the reference materialises (dense.py:138-141) - tiled exact-fp32 MFMA with a fused
- * per-row top-k.  Order (cosine desc, node id asc), k <= 32.
+ * the reference materialises (dense.py:138-141) - tiled matrix-core products (fp32 rounding:
+ * exact bf16 split or fp32 MFMAs, knob 5) with a fused per-row top-k.  Order (cosine desc, node id asc), k <= 32.
  *   nbr_idx dev i32 [N, k]   neighbour ids in rank order, -1 padded when N - 1 < k
  *   nbr_sim dev f32 [N, k]   their cosines (0 padded)
  *   exclude_self             a node is not its own neighbour

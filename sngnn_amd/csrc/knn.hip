@@ -5,8 +5,8 @@
 // SimGFAToolbox/dense.py:138-141, and has no graph builder).
 //
 // Workgroup = 4 waves = 128 rows; it walks ALL column tiles of 128 nodes.  A tile
-// S[128 x 128] = diag(inv) X_rows X_cols^T diag(inv) comes from exact-fp32 MFMA
-// (v_mfma_f32_32x32x2_f32) like sngnn_cosine_dense; each WAVE owns 32 whole rows of it
+// S[128 x 128] = diag(inv) X_rows X_cols^T diag(inv) comes from the matrix cores at fp32 rounding
+// (exact bf16 split or v_mfma_f32_32x32x2_f32) like sngnn_cosine_dense; each WAVE owns 32 whole rows of it
 // (1 x 4 blocks of 32 x 32), so a row's 128 new similarities sit in one half-wave and
 // its running top-k list (LDS, k 64-bit keys) is private to the wave: no atomics, no
 // workgroup barrier in the selection.  A similarity only enters the selection when it

@@ -3,8 +3,10 @@
 // is HBM-bound - x is read once (4 N F bytes), h written once - and the BLAS kernel
 // picked for it reaches ~2.3 TB/s; here a workgroup streams a 128-row panel of x
 // through LDS in coalesced 128-byte segments with the next panel already in
-// registers, and multiplies with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): 4 waves x
-// (32 rows x NT*32 columns).  W^T panels come from L2.
+// registers, and multiplies with fp32 MFMAs (v_mfma_f32_32x32x2_f32): 4 waves x
+// (32 rows x NT*32 columns).  W^T panels come from L2.  (This panel kernel serves the shapes the
+// row-tile kernel below does not: F outside {16, 32, 64, 128}.  The row-tile kernel - every
+// shape of the benchmarked models - multiplies on the bf16 matrix cores after an exact split.)
 #include <algorithm>
 #include <cstdlib>
 
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 
 // ---------------------------------------------------------------------------
 // Row-tile variant for F in {16, 32, 64, 128} (F = 16 FQ): persistent waves, each
-// owning 16-row tiles.  v_mfma_f32_16x16x4_f32 contracts 4 k's per step and the order
+// owning 16-row tiles.  (fp32-MFMA form; the default bf16-split form, BF3 below, keeps this
+// layout with 8 k's per lane and step.)  v_mfma_f32_16x16x4_f32 contracts 4 k's per step and the order
 // of the k's is free, so lane (row r = l & 15, quarter q = l >> 4) takes the
 // CONTIGUOUS quarter k in [q F/4, (q+1) F/4) of its row (A) / of its output column's
 // weight row (B): the whole W^T slice a lane ever needs is NT * F/4 registers, loaded

@@ -2,7 +2,8 @@
 // SimGFAToolbox/dense.py without Python row/block loops.
 //
 //   sngnn_cosine_dense       S = n n^T  (dense.py:138-141)  - the one dense contraction
-//                            of the repo: fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32),
+//                            of the repo: matrix cores at fp32 rounding (exact bf16 split of both
+//                            panels, or v_mfma_f32_32x32x2_f32),
 //                            128x128 tiles staged through LDS, epilogue scales by the
 //                            two inverse norms (x is never normalised in memory).
 //   sngnn_cosine_class_sums  block sums of S per class pair (dense.py:9-30, 104-130,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(1024) void k_sum_fixed_d(const double *__restrict__
 }
 
 // ---------------------------------------------------------------------------
-// S = diag(inv) X X^T diag(inv) with fp32 MFMA.  Workgroup = 256 threads = 2x2
+// S = diag(inv) X X^T diag(inv) on the matrix cores (fp32 rounding).  Workgroup = 256 threads = 2x2
 // waves, 128x128 output tile, each wave 64x64 = 2x2 MFMA blocks of 32x32.
 //   * S is symmetric: only tiles with row block <= column block are computed, each
 //     writes its mirror image as well (half the flops of the reference's full mm); the

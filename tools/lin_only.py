@@ -10,7 +10,8 @@ from sngnn_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 f, c = int(os.environ.get("F", 128)), int(os.environ.get("C", 40))
-x = torch.randn(169343, f, device=dev)
+n = int(os.environ.get("N", 169343))
+x = torch.randn(n, f, device=dev)
 lin = torch.nn.Linear(f, c).to(dev)
 with torch.no_grad():
     for _ in range(200):
