@@ -69,7 +69,7 @@ for name, kind, mk in CONFIGS:
 # the kernel computes the upper triangle of the symmetric S and mirrors it: N (N + 128) F flop are
 # DONE (tiles of 128 on and above the diagonal); the rate is priced on those, not on the nominal
 # 2 N^2 F of a full product (which would read above 100 % of the peak at Actor's size)
-print("\ndense cosine S = n n^T (fp32 MFMA): flops done = 2 F 128^2 x (upper-triangle tiles)")
+print("\ndense cosine S = n n^T (bf16 matrix cores after an exact split, fp32 rounding): fp32-equivalent flops done = 2 F 128^2 x (upper-triangle tiles)")
 for name in ("cora", "chameleon", "actor"):
     data = synth.make_dataset(name)
     x = data.x.to(dev)

@@ -4,7 +4,7 @@
 TAG=${1:-r03}
 OUT=gpurun_out/${TAG}_tools_record.txt
 : > $OUT
-for t in bench_modes.py bench_configs.py bench_epochs.py sweep_fwd.py bench_cosine_cmp.py bench_plumbing.py bench_pp.py; do
+for t in bench_modes.py bench_configs.py bench_epochs.py sweep_fwd.py bench_bwd.py bench_cosine_cmp.py bench_knn.py bench_plumbing.py lin_error.py bench_pp.py; do
   echo "== tools/$t ==" >> $OUT
   python tools/$t 2>&1 | grep -v amdgpu.ids >> $OUT
   echo >> $OUT
