@@ -141,3 +141,56 @@ def test_alternating_inputs_on_one_graph_never_see_stale_candidates(cuda):
         assert np.array_equal(sel_src.cpu().numpy().astype(np.int64), refs[w]["sel_src"]), it
         assert_close(out, torch.from_numpy(refs[w]["out"]), what=f"launch {it}")
         assert int((wsel > -3).sum()) == int((sel_src >= 0).sum())
+
+
+@pytest.mark.parametrize("k,thr", [(16, 0.0), (1, 0.0), (10, 0.9)])
+def test_backward_at_full_arxiv_size_properties(cuda, k, thr):
+    """Config 4's backward at full size, through properties that need no oracle: the backward is
+    LINEAR in grad_out (grad(a g1 + g2) = a grad(g1) + grad(g2) to rounding); its three forms agree
+    (two passes == node-centric bit for bit; with the forward's top_k to rounding); the adjoint
+    identity <grad_h, dh> = d/deps <out(h + eps dh), g> holds to finite-difference accuracy while the
+    selection does not move; rows nobody keeps and that keep nobody get a zero gradient."""
+    from sngnn_amd import _lib, ops, synth
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    d = synth.make_dataset("arxiv", with_features=False)
+    n = d.x.size(0)
+    gen = torch.Generator().manual_seed(9)
+    h = torch.randn(n, 40, generator=gen).to(cuda)
+    g1 = torch.randn(n, 40, generator=gen).to(cuda)
+    g2 = torch.randn(n, 40, generator=gen).to(cuda)
+    g = Graph(d.edge_index.to(cuda), n, True, True)
+    out, wsel, *_ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+    b = lambda go, hint=k: ops.aggregate_backward(g, h, go, wsel, hint)       # noqa: E731
+    r1, r2, r12 = b(g1), b(g2), b(2.5 * g1 + g2)
+    scale = float(r12.abs().max())
+    assert float((r12 - (2.5 * r1 + r2)).abs().max()) <= 4e-6 * scale
+    try:
+        lib.sngnn_tuning_set(3, 1)
+        two = b(g1, None)
+    finally:
+        lib.sngnn_tuning_set(3, 0)
+    assert torch.equal(b(g1, None), two)
+    assert float((r1 - two).abs().max()) <= 2e-6 * float(two.abs().max())
+    # adjoint identity by central differences in float64 on the host side of the inner products
+    dh = torch.randn(n, 40, generator=gen).to(cuda)
+    eps = 1e-3
+    op, wp, *_ = ops.aggregate_forward(g, h + eps * dh, k, thr, save_for_backward=True)
+    om, wm, *_ = ops.aggregate_forward(g, h - eps * dh, k, thr, save_for_backward=True)
+    same = ((wp > -3.0) == (wsel > -3.0)) & ((wm > -3.0) == (wsel > -3.0))          # edges whose state did not move
+    ei_dst = torch.repeat_interleave(torch.arange(n, device=cuda), torch.from_numpy(
+        np.diff(g.array("rowptr")).astype(np.int64)).to(cuda))                                        # target row of every CSR edge
+    moved = torch.zeros(n, dtype=torch.bool, device=cuda)
+    moved[ei_dst[~same]] = True                                                     # rows whose selection moved: excluded
+    gm = g1.clone()
+    gm[moved] = 0.0
+    fd = float((((op - om).double() * gm.double()).sum()) / (2 * eps))
+    an = float((b(gm).double() * dh.double()).sum())
+    assert abs(fd - an) <= 2e-3 * max(abs(an), 1.0), (fd, an, int(moved.sum()))
+    # an isolated, unselected node: zero gradient
+    kept = wsel > -3.0
+    indeg_kept = torch.zeros(n, device=cuda).index_add_(0, ei_dst[kept], torch.ones(int(kept.sum()), device=cuda))
+    col = torch.from_numpy(g.array("col")).to(cuda).long()
+    used = torch.zeros(n, device=cuda).index_add_(0, col[kept], torch.ones(int(kept.sum()), device=cuda))
+    idle = (indeg_kept == 0) & (used == 0)
+    assert bool((r1[idle] == 0).all()) and int(idle.sum()) > 0
