@@ -492,9 +492,9 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
     except Exception:
         traffic = None
     return {"bound": "hbm", "kernels": ("k_pack_kept + k_bwd_w (node-centric: one backward call as the autograd function makes it, "
-                        "with the forward's top_k)" if e_prime <= (4 << 20) else
-                        "k_clear_words + k_bwd_t + k_bwd_t_fin + k_bwd_s (the two passes: the kept-bit mask of a graph "
-                        "this size is not cache resident)"),
+                        "with the forward's top_k)" if 2 * graph.num_fused_nodes >= graph.num_nodes else
+                        "k_clear_words + k_bwd_t + k_bwd_t_fin + k_bwd_s (the two passes: fewer than half of this graph's "
+                        "nodes are small both as target and as source)"),
             "kernel_ms": bwd_ms, "kept_edges": n_sel, "algorithmic_bytes": b_bwd, "traffic": traffic,
             "achieved": b_bwd / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": b_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -97,6 +97,9 @@ int64_t sngnn_graph_row_offset(const sngnn_graph_t *g);      /* row_begin       
 int64_t sngnn_graph_num_edges(const sngnn_graph_t *g);      /* E' */
 int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g);
 int64_t sngnn_graph_src_min(const sngnn_graph_t *g);         /* models.py:125 */
+/* owned nodes with in-degree and out-degree <= 16: the one-work-item nodes of the node-centric
+ * backward, which sngnn_agg_backward* takes when they are at least half of the owned nodes */
+int64_t sngnn_graph_num_fused_nodes(const sngnn_graph_t *g);
 /* bytes of device workspace sngnn_agg_forward/backward need for C channels */
 int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C);
 
@@ -205,8 +208,10 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * 2 = on the fly always (fast cosine, exact normalise-then-dot wherever a decision is in doubt:
  * the same selections, bit for bit);
  * knob 3 = sngnn_agg_backward: 0 (default) = node-centric (a node small both as target and as
- * source does both passes in one work item; with a top_k hint every node), 1 = the two passes for
- * every node (same bits without the hint; equal to rounding on split rows with it);
+ * source does both passes in one work item; with a top_k hint every node) on graphs where such
+ * nodes are at least half of the owned nodes, the two passes otherwise; 1 = the two passes for
+ * every node (same bits without the hint; equal to rounding on split rows with it); 2 =
+ * node-centric whatever the graph;
  * knob 4 = which items the hinted node-centric backward runs (bit 0 wave-per-node, bit 1 fused;
  * default 3 - anything else leaves grad_h incomplete: timing only);
  * knob 5 = sngnn_linear_forward*, sngnn_cosine_dense, sngnn_knn_graph: 0 (default) = products on the bf16 matrix

@@ -32,6 +32,7 @@ SIGNATURES = {
     "sngnn_graph_num_edges": (_i64, [_vp]),
     "sngnn_graph_max_in_degree": (_i64, [_vp]),
     "sngnn_graph_src_min": (_i64, [_vp]),
+    "sngnn_graph_num_fused_nodes": (_i64, [_vp]),
     "sngnn_graph_workspace_bytes": (_i64, [_vp, _i32]),
     "sngnn_graph_copy_array": (_i32, [_vp, _i32, _vp]),
     "sngnn_graph_array_dev": (_vp, [_vp, _i32]),

@@ -3,11 +3,11 @@
 
 using namespace sngnn;
 
-// sngnn_tuning_set(3, v): 0 = node-centric backward (default), 1 = the two passes for every node
-// (the same bits; measurement / test aid)
+// sngnn_tuning_set(3, v): 0 = node-centric backward when most nodes are fused work items (default),
+// 1 = the two passes for every node, 2 = node-centric whatever the graph (the same bits;
+// measurement / test aid)
 static int g_bwd_mode = 0, g_bwd_roles = 3;
-constexpr int64_t NODE_CENTRIC_MAX_EDGES = 4 << 20;      // mask <= 512 KB: an eighth of one XCD's L2
-int sngnn::set_bwd_mode(int v) { g_bwd_mode = v ? 1 : 0; return SNGNN_OK; }
+int sngnn::set_bwd_mode(int v) { g_bwd_mode = (v == 1 || v == 2) ? v : 0; return SNGNN_OK; }
 int sngnn::set_bwd_roles(int v) { g_bwd_roles = v & 3; return SNGNN_OK; }
 
 extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
@@ -55,11 +55,15 @@ extern "C" int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, i
     a.n_ssplit = g->n_ssplit; a.n_smed_end = g->srcs_gt(SMALL_T); a.n_stasks = g->n_stasks;
     a.stask_slot = g->stask_slot; a.stask_chunk = g->stask_chunk; a.ssplit_task0 = g->ssplit_task0;
     a.nbA = a.nbB = a.nbC = 0;
-    // The node-centric path looks up one kept bit per out-edge at a random place of the packed
-    // mask: that is free while the mask (E'/8 bytes) stays cache resident and ruinous when it does
-    // not (products size, 15 MB of bits, 123.5 M lookups: 4.9 - 5.6 ms against the two passes'
-    // 4.2 ms, whose pass T scatters only the 22 M KEPT bits and whose pass S streams them).
-    a.mode = (g_bwd_mode == 0 && g->Ep <= NODE_CENTRIC_MAX_EDGES) ? 0 : 1;
+    // The node-centric path pays when most nodes are FUSED work items (small both as target and as
+    // source: four nodes per wave, both passes in one go) - 95 % at arxiv's degree law, where it wins
+    // at every size tried (x1 .. x32: 1.2 M .. 37 M edges, 60 vs 77 us .. 2.26 vs 2.72 ms).  Where
+    // nodes mostly have 17..128 out-edges (products' degree law: no fused node at all) every node
+    // would be a wave-per-node item, one node per wave with a longer dependent chain than either
+    // pass has: 4.9 ms against the two passes' 4.2 ms at products size.  So: node-centric when at
+    // least half of the owned nodes are fused.
+    const bool mostly_fused = (int64_t)g->n_fused * 2 >= g->N;
+    a.mode = (g_bwd_mode == 2 || (g_bwd_mode == 0 && mostly_fused)) ? 0 : 1;   // (2: node-centric whatever the graph - measurement)
     a.top_k = top_k;
     a.role_mask = g_bwd_roles;
     a.fdesc = g->fdesc; a.trest = g->trest;

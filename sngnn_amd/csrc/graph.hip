@@ -545,6 +545,7 @@ int64_t sngnn_graph_row_offset(const sngnn_graph_t *g) { return g ? g->row_off :
 int64_t sngnn_graph_num_edges(const sngnn_graph_t *g) { return g ? g->Ep : -1; }
 int64_t sngnn_graph_max_in_degree(const sngnn_graph_t *g) { return g ? g->max_in_deg : -1; }
 int64_t sngnn_graph_src_min(const sngnn_graph_t *g) { return g ? g->src_min : -1; }
+int64_t sngnn_graph_num_fused_nodes(const sngnn_graph_t *g) { return g ? g->n_fused : -1; }
 
 int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {

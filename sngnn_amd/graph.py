@@ -52,6 +52,7 @@ class Graph:
         self.row_offset = int(lib.sngnn_graph_row_offset(handle))
         self.num_edges = int(lib.sngnn_graph_num_edges(handle))
         self.max_in_degree = int(lib.sngnn_graph_max_in_degree(handle))
+        self.num_fused_nodes = int(lib.sngnn_graph_num_fused_nodes(handle))    # in- and out-degree <= 16 (node-centric backward)
         self.src_min = int(lib.sngnn_graph_src_min(handle))
         self._ws: Dict[Tuple[int, int], torch.Tensor] = {}
 

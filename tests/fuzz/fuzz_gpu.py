@@ -70,8 +70,10 @@ while time.time() < t_end:
         wsel_b = ops.aggregate_forward(g, hg.detach(), k, thr, save_for_backward=True)[1]
         _lib.load().sngnn_tuning_set(3, 1)
         two = ops.aggregate_backward(g, hg.detach(), gout.to(dev), wsel_b)
+        _lib.load().sngnn_tuning_set(3, 2)
+        nc = ops.aggregate_backward(g, hg.detach(), gout.to(dev), wsel_b)
         _lib.load().sngnn_tuning_set(3, 0)
-        assert torch.equal(ops.aggregate_backward(g, hg.detach(), gout.to(dev), wsel_b), two), "node-centric != two passes"
+        assert torch.equal(nc, two), "node-centric != two passes"
         assert (hg.grad - two).abs().max() <= 2e-6 * max(float(two.abs().max()), 1e-30), "top_k form vs two passes"
         # --- partition of the same graph (two ranges) equals the whole
         if n >= 4:

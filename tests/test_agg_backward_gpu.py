@@ -215,7 +215,7 @@ def _backward_in_mode(lib, mode, g, h, gout, wsel, hint):
     (3, 1, 2, (), False, 2, 0.0),
 ])
 def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k, thr):
-    """sngnn_tuning_set(3, mode): a node small both as target and as source does its pass-T and
+    """sngnn_tuning_set(3, mode) (2 = node-centric whatever the graph): a node small both as target and as source does its pass-T and
     pass-S parts in one work item (dnT in registers, kept bits from the packed mask); the sums keep
     the two passes' order, so grad_h is the same bit for bit - whole graphs and node-range
     partitions.  With the forward's top_k as a hint every node is one work item (rows of any
@@ -240,17 +240,17 @@ def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k
         g = Graph(ei, n, True, rem)
         _, wsel, *_ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
         two = _backward_in_mode(lib, 1, g, h, gout, wsel, None)
-        assert torch.equal(_backward_in_mode(lib, 0, g, h, gout, wsel, None), two)
+        assert torch.equal(_backward_in_mode(lib, 2, g, h, gout, wsel, None), two)
         if k is not None:
-            hinted = _backward_in_mode(lib, 0, g, h, gout, wsel, k)
+            hinted = _backward_in_mode(lib, 2, g, h, gout, wsel, k)
             assert close(hinted, two)
-            assert torch.equal(hinted, _backward_in_mode(lib, 0, g, h, gout, wsel, k))      # deterministic
+            assert torch.equal(hinted, _backward_in_mode(lib, 2, g, h, gout, wsel, k))      # deterministic
         # a promise that does not hold (rows keep far more than 1 edge)
-        assert close(_backward_in_mode(lib, 0, g, h, gout, wsel, 1), two)
+        assert close(_backward_in_mode(lib, 2, g, h, gout, wsel, 1), two)
         lo, hi = n // 4, n // 4 + n // 3
         gp = Graph(ei, n, True, rem, row_range=(lo, hi))
         _, wsel_p, *_ = ops.aggregate_forward(gp, h, k, thr, save_for_backward=True)
         two_p = _backward_in_mode(lib, 1, gp, h, gout[lo:hi].contiguous(), wsel_p, None)
-        assert torch.equal(_backward_in_mode(lib, 0, gp, h, gout[lo:hi].contiguous(), wsel_p, k), two_p)
+        assert torch.equal(_backward_in_mode(lib, 2, gp, h, gout[lo:hi].contiguous(), wsel_p, k), two_p)
     finally:
         lib.sngnn_tuning_set(3, 0)

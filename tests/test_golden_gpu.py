@@ -170,6 +170,7 @@ def test_backward_at_full_arxiv_size_properties(cuda, k, thr):
         two = b(g1, None)
     finally:
         lib.sngnn_tuning_set(3, 0)
+    assert g.num_fused_nodes * 2 >= n                       # arxiv's degree law: the node-centric path is the default
     assert torch.equal(b(g1, None), two)
     assert float((r1 - two).abs().max()) <= 2e-6 * float(two.abs().max())
     # adjoint identity by central differences in float64 on the host side of the inner products

@@ -20,7 +20,8 @@ def main():
     thr = float(os.environ.get("THR", 0.0))
     if os.environ.get("INPUTS", "bench") == "bench":          # bench.py's graph and h = lin(x)
         import bench
-        n, c, ei, _, h, _ = bench.make_rank_inputs(os.environ.get("GRAPH", "arxiv"), 0, 1, 1234, dev, c)
+        n, c, ei, _, h, _ = bench.make_rank_inputs(os.environ.get("GRAPH", "arxiv"), 0, 1, 1234, dev, c,
+                                                   scale=float(os.environ.get("SCALE", 1.0)))
         g = Graph(ei, n, True, True)
         gout = torch.randn(n, c, generator=torch.Generator().manual_seed(0)).to(dev)
     else:                                                     # the test generator's graph, Gaussian rows
@@ -35,7 +36,8 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     res = {}
     for mode in (1, 0, 2, 1, 0, 2):                   # 2 = node-centric with the top_k hint
-        lib.sngnn_tuning_set(3, min(mode, 1) if mode != 2 else 0)
+        # FORCE=1: the node-centric forms also above the size rule's limit (knob value 2)
+        lib.sngnn_tuning_set(3, 1 if mode == 1 else 2 * int(os.environ.get("FORCE", 0)))
         ts = []
         for _ in range(8):
             ev[0].record()
@@ -46,7 +48,7 @@ def main():
             ts.append(ev[0].elapsed_time(ev[1]) * 100)
         res.setdefault(mode, []).append(float(np.mean(ts[2:])))
         res[("g", mode)] = gh
-    lib.sngnn_tuning_set(3, 0)
+    lib.sngnn_tuning_set(3, 2 * int(os.environ.get("FORCE", 0)))
     for roles in (1, 2, 3):                           # timing only: results incomplete unless 3
         lib.sngnn_tuning_set(4, roles)
         ts = []
@@ -59,6 +61,7 @@ def main():
             ts.append(ev[0].elapsed_time(ev[1]) * 100)
         print("with top_k, roles %d (1 wave-per-node items, 2 fused items): %.1f us/call" % (roles, float(np.mean(ts[2:]))))
     lib.sngnn_tuning_set(4, 3)
+    lib.sngnn_tuning_set(3, 0)
     print("two passes   us/call:", res[1])
     print("node-centric us/call:", res[0])
     print("with top_k   us/call:", res[2])
