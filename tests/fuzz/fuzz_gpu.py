@@ -64,7 +64,18 @@ while time.time() < t_end:
             assert (err <= 4e-6 + 2e-5 * ref["out"].abs()).all(), f"out err {err.max():.3e}"
             sc = hr.grad.abs().max().clamp_min(1e-20)
             ge = (hg.grad.cpu() - hr.grad).abs().max()
-            assert ge <= 5e-5 * sc, f"grad err {ge:.3e} scale {sc:.3e}"
+            if not ge <= 5e-5 * sc:
+                # the fp32 CPU oracle itself loses digits when a zero row puts 1 / eps = 1e12 into
+                # the gradient (seed 90031: oracle fp32 vs fp64 9.3e-5 of the scale, GPU vs fp64
+                # 1.2e-5): the float64 oracle arbitrates
+                h64 = h.double().clone().requires_grad_(True)
+                r64 = O.aggregate_reference(h64, ei, add_loops=True, remove_loops=rem, top_k=k, thr=thr)
+                (r64["out"] * gout.double()).sum().backward()
+                ge64 = (hg.grad.cpu().double() - h64.grad).abs().max()
+                assert ge64 <= 5e-5 * h64.grad.abs().max().clamp_min(1e-20), \
+                    f"grad err {ge:.3e} (fp32 oracle) / {ge64:.3e} (fp64 oracle) scale {sc:.3e}"
+                n_arbitrated = globals().get("n_arbitrated", 0) + 1
+                globals()["n_arbitrated"] = n_arbitrated
         # the backward's forms (csrc/agg_bwd_impl.h): two passes == node-centric without the
         # forward's top_k, bit for bit; with it (what ops.aggregate just ran) equal to rounding
         wsel_b = ops.aggregate_forward(g, hg.detach(), k, thr, save_for_backward=True)[1]
@@ -143,4 +154,4 @@ while time.time() < t_end:
     seed += 1
     if n_cases % 50 == 0:
         print(f"{n_cases} cases ok (last {tag})", flush=True)
-print(f"done: {n_cases} random cases passed, next seed {seed}")
+print(f"done: {n_cases} random cases passed ({globals().get('n_arbitrated', 0)} where the fp32 oracle's gradient was off and the fp64 oracle sided with the GPU), next seed {seed}")
