@@ -421,6 +421,16 @@ int sngnn_edge_cosine(const float *x, int64_t N, int64_t F,
                       const int64_t *edge_index_dev, int64_t E, float *sim,
                       void *stream);
 /*
+ * dense.py:163 `scatter_mean(sim, edge_index[0], dim=0)` (torch_scatter) and
+ * the per-node means of dense.py:85-96 / sparse.py:98-115: mean[m] = (sum of val[e] over the
+ * entries with index[e] == m, added in ENTRY ORDER in fp32) / max(count, 1); an empty group
+ * reads 0.  No atomics: the same additions in the same order as the CPU's serial scatter, on
+ * every run.  val dev f32 [E], index dev int64 [E] with values in [0, M), mean dev f32 [M],
+ * count dev int32 [M] or NULL.
+ */
+int sngnn_segment_mean(const float *val, const int64_t *index, int64_t E, int64_t M, float *mean,
+                       int32_t *count, void *stream);
+/*
  * sparse.py:8-14 without forming the product: entries (pair_a[p], pair_b[p]) of
  * M_n^T M_n, M_n = the column-normalised sparse input in CSC form (colptr int64
  * [n_cols + 1], rowidx int32 ascending inside a column, vals = the NORMALISED values).

@@ -159,14 +159,17 @@ def edge_cosine(norm: Tensor, edge_index: Tensor) -> Tensor:
 
 
 def topk_threshold_weights(s: Tensor, index: Tensor, top_k: int, thr: float,
-                           use_loop: bool = False) -> Tuple[Tensor, List[Tensor]]:
+                           use_loop: bool = False, smax=None) -> Tuple[Tensor, List[Tensor]]:
     """models.py:141-156 / 246-261: ``top_k`` rounds of scatter_max, the -2 mask
     for empty groups, the fp32 ``>= thr`` compare, the -1.1 knock-out, then
     ``weight.scatter(-1, idx, s[idx])`` per round.
 
     Returns (weight [E'], list of the per-round selected edge positions).
+    ``smax``: another ``scatter_max(src, index) -> (out, arg)`` to run the rounds with - the real
+    ``torch_scatter.scatter_max`` where that package imports (tests/third_party_cases.py).
     """
-    smax = scatter_max_loop if use_loop else scatter_max
+    if smax is None:
+        smax = scatter_max_loop if use_loop else scatter_max
     tmp_weight = s.clone()
     weight = torch.zeros(s.shape, dtype=s.dtype)
     max_indexes: List[Tensor] = []

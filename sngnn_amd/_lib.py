@@ -75,6 +75,7 @@ SIGNATURES = {
     "sngnn_cosine_dense": (_i32, [_vp, _i64, _i64, _vp, _vp]),
     "sngnn_cosine_class_sums": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_edge_cosine": (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "sngnn_segment_mean": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "sngnn_sparse_pair_dot": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
 }
 

@@ -431,6 +431,49 @@ __global__ __launch_bounds__(256) void k_edge_cosine(const float *__restrict__ x
         sim[e] = d * ((1.0f / fmaxf(sqrtf(qa), EPS_NORM)) * (1.0f / fmaxf(sqrtf(qb), EPS_NORM)));
 }
 
+// ---------------------------------------------------------------------------
+// Mean of per-edge values grouped by an index, in the reference's arithmetic: torch_scatter's
+// scatter_mean (dense.py:163) adds the values of a group in EDGE ORDER in
+// fp32, counts every entry, clamps the count to 1 and divides.  The entries are brought into
+// (index, edge position) order by a stable radix sort; one thread then walks one group's entries
+// serially: the same additions in the same order, no atomics - bit for bit the CPU result, and
+// the same bits on every run.
+// ---------------------------------------------------------------------------
+__global__ void k_seg_keys(const int64_t *__restrict__ index, int64_t E, int64_t M, int32_t *__restrict__ key,
+                           int32_t *__restrict__ pos, int *__restrict__ bad)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E) return;
+    const int64_t i = index[t];
+    if (i < 0 || i >= M) { atomicOr(bad, 1); key[t] = 0; pos[t] = (int32_t)t; return; }
+    key[t] = (int32_t)i;
+    pos[t] = (int32_t)t;
+}
+
+__global__ void k_seg_bounds(const int32_t *__restrict__ key_s, int64_t E, int32_t *__restrict__ first,
+                             int32_t *__restrict__ last)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E) return;
+    const int32_t k = key_s[t];
+    if (t == 0 || key_s[t - 1] != k) first[k] = (int32_t)t;
+    if (t == E - 1 || key_s[t + 1] != k) last[k] = (int32_t)t + 1;
+}
+
+__global__ void k_seg_mean(const float *__restrict__ val, const int32_t *__restrict__ pos_s,
+                           const int32_t *__restrict__ first, const int32_t *__restrict__ last, int64_t M,
+                           float *__restrict__ mean, int32_t *__restrict__ count)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int32_t a = first[m], b = last[m];       // both 0 for an empty group
+    float s = 0.f;
+    for (int32_t p = a; p < b; ++p) s += val[pos_s[p]];
+    const int32_t c = b - a;
+    mean[m] = s / (float)(c < 1 ? 1 : c);
+    if (count) count[m] = c;
+}
+
 struct AsyncBuf {
     void *p = nullptr;
     hipStream_t st;
@@ -617,5 +660,41 @@ extern "C" int sngnn_edge_cosine(const float *x, int64_t N, int64_t F, const int
     SN_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
     SN_HIP(hipStreamSynchronize(st));
     SN_REQUIRE(!h_bad, SNGNN_ERANGE, "edge_index contains a node id outside [0, N)");
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_segment_mean(const float *val, const int64_t *index, int64_t E, int64_t M, float *mean,
+                                  int32_t *count, void *stream)
+{
+    SN_REQUIRE(E >= 0 && M >= 0, SNGNN_EINVAL, "bad shape");
+    SN_REQUIRE(E < ((int64_t)1 << 31) && M < ((int64_t)1 << 31), SNGNN_EINVAL, "too many entries / groups");
+    if (M == 0) { SN_REQUIRE(E == 0, SNGNN_ERANGE, "index outside [0, M)"); return SNGNN_OK; }
+    SN_REQUIRE(mean && (E == 0 || (val && index)), SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    AsyncBuf key(st), pos(st), key_s(st), pos_s(st), bounds(st), bad(st), tmp(st);
+    SN_REQUIRE(!key.alloc((size_t)E * 4) && !pos.alloc((size_t)E * 4) && !key_s.alloc((size_t)E * 4) &&
+                   !pos_s.alloc((size_t)E * 4) && !bounds.alloc((size_t)M * 8) && !bad.alloc(4),
+               SNGNN_ENOMEM, "out of device memory");
+    SN_HIP(hipMemsetAsync(bad.p, 0, 4, st));
+    SN_HIP(hipMemsetAsync(bounds.p, 0, (size_t)M * 8, st));
+    int32_t *first = bounds.as<int32_t>(), *last = first + M;
+    if (E > 0) {
+        const unsigned ge = (unsigned)((E + 255) / 256);
+        k_seg_keys<<<ge, 256, 0, st>>>(index, E, M, key.as<int32_t>(), pos.as<int32_t>(), bad.as<int>());
+        int bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < M) ++bits;
+        size_t tb = 0;
+        SN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.as<int32_t>(), key_s.as<int32_t>(),
+                                                  pos.as<int32_t>(), pos_s.as<int32_t>(), (int)E, 0, bits, st));
+        SN_REQUIRE(tmp.alloc(tb) == 0, SNGNN_ENOMEM, "out of device memory");
+        SN_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.as<int32_t>(), key_s.as<int32_t>(),
+                                                  pos.as<int32_t>(), pos_s.as<int32_t>(), (int)E, 0, bits, st));
+        k_seg_bounds<<<ge, 256, 0, st>>>(key_s.as<int32_t>(), E, first, last);
+    }
+    k_seg_mean<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(val, pos_s.as<int32_t>(), first, last, M, mean, count);
+    int h_bad = 0;
+    SN_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
+    SN_HIP(hipStreamSynchronize(st));
+    SN_REQUIRE(!h_bad, SNGNN_ERANGE, "index outside [0, M)");
     return SNGNN_OK;
 }

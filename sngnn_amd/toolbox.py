@@ -119,31 +119,42 @@ def _sort_edge_index(edge_index):
     return edge_index[:, torch.argsort(key, stable=True)]
 
 
-def _mean_by_source(sim, src, length):
-    tot = torch.zeros(length, dtype=torch.float64, device=sim.device)
-    tot.index_add_(0, src, sim.double())
-    cnt = torch.bincount(src, minlength=length)
-    return tot, cnt
+def segment_mean(val: torch.Tensor, index: torch.Tensor, length: int):
+    """``sngnn_segment_mean``: torch_scatter's ``scatter_mean(val, index, dim=0)`` (dense.py:163) in
+    its own arithmetic - each group's values added in ENTRY order in fp32, divided by
+    max(count, 1), 0 for an empty group - by a kernel without atomics (bit-identical runs, and
+    bit-identical to the CPU's serial scatter).  Returns (mean fp32 [length], count int32 [length])."""
+    val = val.to(torch.float32).contiguous()
+    if not val.is_cuda:
+        raise ValueError("val must live on the GPU (there is no CPU path)")
+    idx = index.to(device=val.device, dtype=torch.int64).contiguous()
+    if idx.numel() != val.numel() or val.dim() != 1:
+        raise ValueError("val and index must be 1-D and of one length")
+    mean = torch.empty(int(length), dtype=torch.float32, device=val.device)
+    cnt = torch.empty(int(length), dtype=torch.int32, device=val.device)
+    with torch.cuda.device(val.device):
+        rc = _lib.load().sngnn_segment_mean(val.data_ptr(), idx.data_ptr(), val.numel(), int(length),
+                                            mean.data_ptr(), cnt.data_ptr(), _stream(val))
+    _lib.check(rc, "sngnn_segment_mean")
+    return mean, cnt
 
 
 def neighborhood_similarity_dense_small(x, edge_index):
-    """dense.py:158-164: per-edge cosine, mean grouped by SOURCE (edge_index[0]);
+    """dense.py:158-164: per-edge cosine, mean grouped by SOURCE (edge_index[0]) in edge order;
     output length max(src) + 1 like torch_scatter.scatter_mean without dim_size."""
     sim = edge_cosine(x, edge_index)
     src = edge_index[0].to(sim.device)
     length = int(src.max()) + 1 if src.numel() else 0
-    tot, cnt = _mean_by_source(sim, src, length)
-    weight = (tot / cnt.clamp(min=1)).to(torch.float32)
+    weight, _ = segment_mean(sim, src, length)
     return weight, torch.mean(weight)
 
 
 def neighborhood_similarity_dense_large(x, edge_index):
-    """dense.py:65-101: one value per node (0 for a node without out-edges) and the
-    mean over ALL nodes."""
+    """dense.py:65-101: one value per node - the mean over its out-edges in (src, dst) order
+    (``sort_edge_index``, dense.py:66), 0 for a node without out-edges - and the mean over ALL nodes."""
     n = x.size(0)
-    sim = edge_cosine(x, edge_index)
-    tot, cnt = _mean_by_source(sim, edge_index[0].to(sim.device), n)
-    per_node = torch.where(cnt > 0, tot / cnt.clamp(min=1), torch.zeros_like(tot)).to(torch.float32)
+    ei = _sort_edge_index(edge_index)
+    per_node, _ = segment_mean(edge_cosine(x, ei), ei[0], n)
     return per_node.reshape(-1, 1), per_node.sum() / n
 
 
@@ -259,10 +270,9 @@ def neighborhood_similarity_sparse(x, edge_index, device=None):
     """sparse.py:80-120: per node the mean similarity to its out-neighbours (0 for a
     node without out-edges) and the mean over all nodes."""
     sp = _SparseCols(x, device)
-    ei = edge_index.to(sp.device)
+    ei = _sort_edge_index(edge_index.to(sp.device))          # sparse.py:86
     n = sp.shape[1]
-    tot, cnt = _mean_by_source(sp.pair_dot(ei[0], ei[1]), ei[0], n)
-    per_node = torch.where(cnt > 0, tot / cnt.clamp(min=1), torch.zeros_like(tot)).to(torch.float32)
+    per_node, _ = segment_mean(sp.pair_dot(ei[0], ei[1]), ei[0], n)
     return per_node.reshape(-1, 1), per_node.sum() / n
 
 

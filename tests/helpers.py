@@ -8,7 +8,19 @@ from oracle import sngnn_oracle as O
 
 RTOL = 1e-5          # north_star: aggregated features within 1e-5 rtol
 ATOL = 2e-6          # absolute floor for entries that cancel to ~0 (|h| ~ 1, fp32)
-TIE_TOL = 6e-7       # a "near tie": two cosines closer than a few fp32 ulps at |s| <= 1
+# A "near tie": two cosines (or a cosine and thr) whose ORDER depends on the summation order of
+# whoever computes them (torch's vectorised CPU sum, a serial C loop and the kernel's lane order
+# all differ in the last bits).  BASELINE.md's gate: every mismatch must be a <= 2-ulp near tie and
+# the count is reported.  The unit is the fp32 ulp at the scale of the operands - a cosine is a sum
+# of products of UNIT rows, so its rounding error is in ulps of 1.0 (2^-23) whatever the sum
+# cancels to (a cosine of 1e-9 against thr = 0 is a near tie, although it is 1e7 of its own ulps).
+# Every row that needed the rule is logged with the gap it needed (NEAR_TIE_GAPS, printed in the
+# pytest summary: count, maximum in ulps), so the gate is a measured quantity, not a tolerance
+# things hide in.  Round 3 allowed 6e-7 (5 ulps); the measured maximum is what justifies the 2.
+ULP32 = 2.0 ** -23
+TIE_ULPS = 2.0
+TIE_TOL = TIE_ULPS * ULP32          # 2.38e-7
+NEAR_TIE_GAPS = []                  # gap (absolute) each tolerated row needed, over all tests of the run
 
 
 def random_graph(n, e, seed, hubs=()):
@@ -25,20 +37,33 @@ def random_graph(n, e, seed, hubs=()):
     return torch.from_numpy(np.stack([key // n, key % n]))
 
 
-def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None):
+def log_operator_rows(differ, rows, label=None):
+    """One operator-level comparison for the pytest summary (tests/conftest.py)."""
+    import os
+    if label is None:
+        label = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    OPERATOR_TIE_LOG.append((label, differ, rows))
+
+
+def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie_ulps=None, gaps=None):
     """Compare the GPU's per-row selection with the oracle's.
 
     Rows that agree exactly pass.  A row that differs is accepted only when the
     difference is explained by a near tie (oracle cosines within TIE_TOL of each
     other or of thr) - and never when ``strict``.  With ``h`` (the operator's input rows) a
     differing row must not involve a structural exact tie either.  Returns the number of rows
-    that needed the near-tie rule."""
+    that needed the near-tie rule.  ``tie_ulps``: the gate in ulps of 1.0 (default TIE_ULPS);
+    ``gaps``: the list the needed gaps are appended to (default NEAR_TIE_GAPS)."""
+    tol = (TIE_ULPS if tie_ulps is None else float(tie_ulps)) * ULP32
+    gaps = NEAR_TIE_GAPS if gaps is None else gaps
     unit = None
     if h is not None:
         unit = torch.nn.functional.normalize(torch.as_tensor(h).detach().cpu().float(), p=2., dim=-1).numpy()
     sel_o = res["sel_src"].numpy()
     sel_g = sel_src_gpu.cpu().numpy().astype(np.int64)
     diff_rows = np.flatnonzero((sel_o != sel_g).any(axis=1))
+    if tie_ulps is None:
+        log_operator_rows(int(diff_rows.size), int(sel_o.shape[0]))
     if diff_rows.size == 0:
         return 0
     assert not strict, f"selection differs in rows {diff_rows[:10]} (strict case)"
@@ -88,16 +113,25 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None):
                 ranks = [rank_of[q] for q in taken]
                 assert ranks == sorted(ranks), \
                     f"row {i}: structurally tied sources {srcs[taken].tolist()} listed out of edge-position order"
-        assert (picked >= thr32 - TIE_TOL).all(), f"row {i}: kept an edge below thr"
-        assert (np.diff(picked) <= TIE_TOL).all(), f"row {i}: not in rank order"
+        # the smallest tolerance that explains this row: how far below thr a kept edge is in the
+        # oracle's scores, how far out of rank order the kept list is, and how much better than the
+        # worst kept edge (list full) or than thr (room left) an edge that was NOT kept is
+        need = 0.0
+        if picked.size:
+            need = max(need, float(thr32 - picked.min()))
+            if picked.size > 1:
+                need = max(need, float(np.diff(picked).max()))
         rest = sc[~used]
-        if rest.size and picked.size:
-            worst = picked.min()
-            better = rest[(rest > worst + TIE_TOL) & (rest >= thr32 + TIE_TOL)]
-            assert picked.size == top_k or better.size == 0
-            assert better.size == 0, f"row {i}: missed a clearly better edge"
-        elif rest.size:
-            assert not (rest >= thr32 + TIE_TOL).any() or top_k == 0
+        if rest.size and top_k > 0:
+            if picked.size == top_k:
+                need = max(need, float(rest.max() - picked.min()))
+            else:
+                elig = rest[rest >= thr32]
+                if elig.size:
+                    need = max(need, float(elig.max() - thr32))
+        assert need <= tol, (f"row {i}: selection differs by more than a near tie: needs {need:.3e} "
+                             f"= {need / ULP32:.2f} ulp (gate {tol / ULP32:.1f} ulp); kept {picked.tolist()}")
+        gaps.append(need)
     return int(diff_rows.size)
 
 
@@ -117,6 +151,14 @@ def oracle_aggregate(h, ei, add_loops, remove_loops, top_k, thr):
 
 
 NEAR_TIE_LOG = []       # (test id, rows that needed the near-tie rule, rows compared): printed by conftest
+REPORT_LINES = []       # free-form lines for the summary (measured errors of the full-size tests)
+OPERATOR_TIE_LOG = []   # the same at operator level (same inputs on both sides)
+# Model level: the two sides' ``lin`` results differ in the last ulp (rocBLAS / MFMA vs the CPU's
+# GEMM), so the cosines differ by an INPUT perturbation on top of the summation order: one more
+# ulp per operand.  Gate 3 ulps (2 + 1 for the perturbed operand; round 3 allowed 5; the measured
+# maximum over the full-size configs is 1.5), gaps logged separately.
+MODEL_TIE_ULPS = 3.0
+MODEL_TIE_GAPS = []
 
 
 def model_selection_report(ours, ref, data_cpu, data_gpu, label):
@@ -124,7 +166,7 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
     compare the rows' selections on each side's OWN ``h = lin(x)`` - the two ``lin`` results
     differ in the last ulp (rocBLAS / MFMA vs the CPU's GEMM), which is where a model-level
     near-tie flip comes from.  A differing row must pass ``check_selection``'s near-tie rule
-    (oracle cosines within TIE_TOL, no structural tie involved).  Returns and logs
+    (oracle cosines within MODEL_TIE_ULPS ulps, no structural tie involved).  Returns and logs
     (rows that differ, rows compared)."""
     from sngnn_amd import conv as CV
     from sngnn_amd import ops
@@ -155,7 +197,8 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
         g = GLOBAL_CACHE.get(data_gpu.edge_index, h_g.size(0), True, rem)
         _, _, _, sel_src, sel_w = ops.aggregate_forward(g, h_g.contiguous(), int(k), float(cr.thr),
                                                         want_selection=True)
-        differ += check_selection(res, sel_src, sel_w, int(k), float(cr.thr), strict=False, h=h_r)
+        differ += check_selection(res, sel_src, sel_w, int(k), float(cr.thr), strict=False, h=h_r,
+                                  tie_ulps=MODEL_TIE_ULPS, gaps=MODEL_TIE_GAPS)
         rows += h_r.size(0)
     NEAR_TIE_LOG.append((label, differ, rows))
     return differ, rows

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import TIE_TOL, assert_close
+from tests.helpers import assert_close, check_selection
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -58,8 +58,8 @@ def test_attention_against_committed_golden_vectors(cuda, path):
 @pytest.mark.parametrize("k,thr", [(16, 0.0), (1, 0.99), (16, 0.9)])
 def test_full_arxiv_size_against_c_oracle(cuda, k, thr):
     """Config 4 at full size: out within rtol 1e-5; selected indices bit-exact except
-    for rows where the oracle's own cosines are within a few ulps of each other or of
-    thr (counted and bounded)."""
+    for rows where the oracle's own cosines are within 2 ulps of each other or of
+    thr (counted - the count is printed in the pytest summary - and bounded: 8 of 169 343)."""
     from oracle import c_oracle as CO
     from sngnn_amd import ops, synth
     from sngnn_amd.graph import Graph
@@ -76,18 +76,11 @@ def test_full_arxiv_size_against_c_oracle(cuda, k, thr):
     assert g.num_edges == ref["ei"].shape[1]
     sel_g = sel_src.cpu().numpy().astype(np.int64)
     bad_rows = np.flatnonzero((sel_g != ref["sel_src"]).any(axis=1))
-    # every mismatching row must be a near tie in the ORACLE's scores
-    if bad_rows.size:
-        ei, s = ref["ei"], ref["s"]
-        order = np.argsort(ei[1], kind="stable")
-        dsts = ei[1][order]
-        for i in bad_rows[:200]:
-            lo, hi = np.searchsorted(dsts, [i, i + 1])
-            sc = np.sort(s[order[lo:hi]])[::-1]
-            gaps = np.abs(np.diff(sc)).min() if sc.size > 1 else np.inf
-            near_thr = np.abs(sc - np.float32(thr)).min()
-            assert min(gaps, near_thr) <= TIE_TOL, f"row {i}: mismatch without a near tie"
-    assert bad_rows.size <= n // 2000, f"{bad_rows.size} rows differ"
+    # every mismatching row must be a near tie in the ORACLE's scores: tests/helpers.check_selection
+    # measures the gap each one needs (gate: 2 ulps) and the count goes to the pytest summary
+    res = dict(sel_src=torch.from_numpy(ref["sel_src"]), ei=torch.from_numpy(ref["ei"]), s=torch.from_numpy(ref["s"]))
+    assert check_selection(res, sel_src, sel_w, k, thr, strict=False, h=h) == bad_rows.size
+    assert bad_rows.size <= n // 20000, f"{bad_rows.size} rows differ"
     good = np.ones(n, bool)
     good[bad_rows] = False
     assert_close(out.cpu()[good], torch.from_numpy(ref["out"])[good])
@@ -195,3 +188,61 @@ def test_backward_at_full_arxiv_size_properties(cuda, k, thr):
     used = torch.zeros(n, device=cuda).index_add_(0, col[kept], torch.ones(int(kept.sum()), device=cuda))
     idle = (indeg_kept == 0) & (used == 0)
     assert bool((r1[idle] == 0).all()) and int(idle.sum()) > 0
+
+
+@pytest.mark.parametrize("k,thr", [(16, 0.0), (1, 0.0)])
+def test_backward_at_full_arxiv_size_against_oracle_autograd(cuda, k, thr):
+    """Config 4's gradient at FULL size against autograd through the torch oracle - the reference's
+    own op sequence (models.py:238-263 + scatter-mean), differentiated by torch on the CPU - through
+    the DEFAULT backward of ``ops.aggregate`` (node-centric with the forward's top_k; the 13 k-edge
+    hub is one wave-per-node item).  Rows whose selection differs between the two sides (near ties,
+    counted) get a zero ``grad_out`` on both sides: nothing reaches the gradient through a row
+    whose output gradient is zero, so the comparison stays exact to rounding.  Gate: 2e-5 of the
+    gradient's max-norm against the fp32 oracle; a float64 evaluation of the same expressions with
+    the fp32 oracle's kept mask arbitrates (both errors are printed in the pytest summary)."""
+    from oracle import sngnn_oracle as O
+    from sngnn_amd import ops, synth
+    from sngnn_amd.graph import Graph
+    from tests.helpers import REPORT_LINES
+    d = synth.make_dataset("arxiv", with_features=False)
+    n, C = d.x.size(0), 40
+    gen = torch.Generator().manual_seed(12)
+    h = torch.randn(n, C, generator=gen)
+    gout = torch.randn(n, C, generator=gen)
+    hr = h.clone().requires_grad_(True)
+    ref = O.aggregate_reference(hr, d.edge_index, add_loops=True, remove_loops=True, top_k=k, thr=thr)
+    g = Graph(d.edge_index.to(cuda), n, True, True)
+    assert g.num_fused_nodes * 2 >= n                    # the node-centric path is what runs
+    hg = h.to(cuda).requires_grad_(True)
+    out = ops.aggregate(hg, g, k, thr)
+    _, _, _, sel_src, sel_w = ops.aggregate_forward(g, hg.detach(), k, thr, want_selection=True)
+    differ = check_selection(ref, sel_src, sel_w, k, thr, strict=False, h=h)
+    bad = (sel_src.cpu().long() != ref["sel_src"]).any(1)
+    assert int(bad.sum()) == differ <= n // 20000
+    gout[bad] = 0.0
+    (ref["out"] * gout).sum().backward()
+    (out * gout.to(cuda)).sum().backward()
+    scale = float(hr.grad.abs().max())
+    err32 = float((hg.grad.cpu() - hr.grad).abs().max())
+    # float64 arbiter: the same expressions (cosine of F.normalize'd rows, weight = cosine on the
+    # kept edges, weight * x_j, mean over ALL in-edges) in double, selection fixed to the oracle's
+    ei = ref["ei"]
+    kept = torch.zeros(ei.size(1), dtype=torch.bool)
+    kept[ref["sel_pos"][ref["sel_pos"] >= 0]] = True
+    h64 = h.double().requires_grad_(True)
+    n64 = torch.nn.functional.normalize(h64, p=2., dim=-1)
+    s64 = O.edge_cosine(n64, ei)
+    w64 = torch.where(kept, s64, torch.zeros_like(s64))
+    o64 = O.scatter_mean(w64.view(-1, 1) * h64.index_select(0, ei[0]), ei[1], n)
+    (o64 * gout.double()).sum().backward()
+    e_gpu = float((hg.grad.cpu().double() - h64.grad).abs().max())
+    e_cpu = float((hr.grad.double() - h64.grad).abs().max())
+    REPORT_LINES.append(f"config-4 gradient at full size (top_k {k}, thr {thr}): |gpu - oracle autograd| {err32:.2e}, "
+                        f"|gpu - f64| {e_gpu:.2e}, |oracle - f64| {e_cpu:.2e}, of scale {scale:.2e}; "
+                        f"{differ} near-tie rows masked")
+    assert err32 <= 2e-5 * scale, (err32, scale)
+    assert e_gpu <= 2e-5 * scale, (e_gpu, scale)
+    # the rows the comparison is really about: the biggest hub's own row and its sources
+    hub = int(torch.bincount(ei[1], minlength=n).argmax())
+    assert int((ei[1] == hub).sum()) > 10000
+    assert float((hg.grad.cpu()[hub] - hr.grad[hub]).abs().max()) <= 2e-5 * scale

@@ -393,3 +393,45 @@ def test_cosine_dense_on_the_bf16_cores_rounds_like_fp32(cuda, n, f):
     assert err[0] <= 1.5 * err[1] + 2.0 ** -24, err
     assert float((out[0] - out[0].t()).abs().max()) <= 2.0 ** -22          # (mirror tiles: same bits; diagonal tiles: to rounding)
     assert (out[0][9] == 0).all()
+
+
+def test_segment_mean_is_the_cpu_scatter_mean_bit_for_bit(cuda):
+    """``sngnn_segment_mean`` (dense.py:163's ``scatter_mean(sim, edge_index[0], dim=0)``): every
+    group's values added in ENTRY order in fp32, divided by max(count, 1) - equal to the oracle's
+    serial scatter bit for bit on an UNSORTED index with hubs, empty groups and trailing empty
+    groups, and the same bits on every run (no atomics)."""
+    from sngnn_amd import toolbox as T
+    g = torch.Generator().manual_seed(21)
+    e, m = 200_000, 5000
+    index = torch.randint(0, m - 40, (e,), generator=g)          # the last 40 groups are empty
+    index[index == 17] = 18                                      # an empty group in the middle
+    index[torch.randperm(e, generator=g)[:30_000]] = 99          # a 30 000-entry hub
+    val = torch.randn(e, generator=g)
+    want = O.scatter_mean(val, index, m)
+    cnt_want = torch.bincount(index, minlength=m)
+    got, cnt = T.segment_mean(val.to(cuda), index.to(cuda), m)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(cnt.cpu().long(), cnt_want)
+    again, _ = T.segment_mean(val.to(cuda), index.to(cuda), m)
+    assert torch.equal(got, again)
+    assert float(got[17]) == 0.0 and bool((got[m - 40:] == 0).all())
+    # degenerate shapes
+    z, c = T.segment_mean(torch.empty(0, device=cuda), torch.empty(0, dtype=torch.long, device=cuda), 7)
+    assert bool((z == 0).all()) and bool((c == 0).all())
+    with pytest.raises(ValueError):
+        T.segment_mean(val[:10].to(cuda), torch.full((10,), m, dtype=torch.long, device=cuda), m)
+
+
+def test_neighborhood_similarity_mean_matches_the_reference_order_exactly(cuda):
+    """dense.py:158-164 end to end: given the SAME per-edge cosines, the kernel's mean by source is
+    the oracle's ``scatter_mean`` bit for bit (the cosines themselves differ in the last ulp between
+    the CPU's and the GPU's dot products, hence the tolerance in test_neighborhood_similarity)."""
+    from sngnn_amd import toolbox as T
+    n, f = 400, 48
+    x = bow(n, f, 9, 0.15)
+    ei = random_graph(n, 6000, 11, hubs=((3, 350),))
+    ei = ei.flip(0)                              # the hub as a SOURCE; edges now unsorted by source
+    sim = T.edge_cosine(x.to(cuda), ei.to(cuda))
+    length = int(ei[0].max()) + 1
+    got, _ = T.segment_mean(sim, ei[0].to(cuda), length)
+    assert torch.equal(got.cpu(), O.scatter_mean_1d(sim.cpu(), ei[0]))
