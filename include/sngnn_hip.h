@@ -273,6 +273,37 @@ int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C,
                         void *workspace, void *stream);
 
 /*
+ * Signed cosine attention of the same gather skeleton.
+ * Replaces: GGCNlayer_SP.forward's use_sign branch after ``fcn`` (models.py:1512-1519 get_sparse_att,
+ * :1529-1537 the two sparse products): with s_e = cos(Wh_i, Wh_j) for every entry e = (i, j),
+ * i != j, of the adjacency and a_e = adj_e * softplus(deg_coeff_0 * degree_e + deg_coeff_1),
+ *     out_i = sum_e a_e * (c_pos * relu(s_e) - c_neg * relu(-s_e)) * Wh_j
+ *           = c_pos * prop_pos_i + c_neg * prop_neg_i            (coeff_0 / coeff_1 of :1541)
+ * - the two propagations share every gathered row, so they are one gather.  Build the graph from
+ * edge_index = [adj column; adj row] (source = column, target = row) with remove_loops = 1
+ * (adj_remove_diag); per-edge arrays are in the graph's CSR order (array "eid" maps a CSR position
+ * to its position in the loop-free entry list).
+ *
+ *   wh     dev f32 [N_total, C]
+ *   coef   dev f32 [E']   a_e, CSR order
+ *   c2     dev f32 [2]    c_pos, c_neg (device scalars: they are functions of a parameter)
+ *   out    dev f32 [N, C]
+ *   s      dev f32 [E'] or NULL   the cosines, CSR order (what sngnn_signed_backward needs)
+ */
+int sngnn_signed_forward(const sngnn_graph_t *g, const float *wh, int C, const float *coef,
+                         const float *c2, float *out, float *s, void *workspace, void *stream);
+/*
+ * autograd of the lines above: grad_wh [N_total, C] through the message values, both rows of
+ * every cosine and the normalisation's Jacobian (no floating-point atomics: two gather passes in
+ * fixed order, like sngnn_attn_backward), and u [E'] (CSR order) = s_e * <grad_out_i, Wh_j>, from
+ * which the caller finishes the small gradients: d a_e = kappa_e u_e with kappa_e = c_pos (s_e > 0)
+ * | c_neg (s_e < 0) | 0, d c_pos = sum_{s_e > 0} a_e u_e, d c_neg = sum_{s_e < 0} a_e u_e.
+ */
+int sngnn_signed_backward(const sngnn_graph_t *g, const float *wh, int C, const float *grad_out,
+                          const float *coef, const float *s, const float *c2, float *grad_wh, float *u,
+                          void *workspace, void *stream);
+
+/*
  * Replaces: the SNGNN++ blend  out = beta * out_0 + (1 - beta) * out_1  (models.py:134)
  * and its autograd, one pass over the n = N * C elements each way instead of five
  * elementwise launches.  beta: dev f32 [1] (the layer's Parameter).  Backward writes

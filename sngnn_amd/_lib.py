@@ -53,6 +53,8 @@ SIGNATURES = {
     "sngnn_agg_backward_topk": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_signed_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_signed_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_blend_workspace_bytes": (_i64, []),
     "sngnn_blend_forward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sngnn_blend_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

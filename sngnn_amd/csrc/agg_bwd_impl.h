@@ -392,7 +392,9 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
             else if constexpr (CSRM) kept = kept_csr(a, a.csc_eid[q]);
             else kept = (a.kmask[q >> 5] >> (q & 31)) & 1u;
         }
-        if constexpr (REC) kept = is_kept(rec.x);
+        // (REC: every out-edge carries a record - softmax terms in the attention mode, signed
+        // weights of either sign and any size in the signed mode, signed_impl.h)
+        if constexpr (REC) kept = t < od;
         const unsigned long long gm = group_bits<G>(__ballot(kept), gid);
         if (kept) {
             const int pos = nk + __popcll(gm & ((1ull << lg) - 1ull));
@@ -756,7 +758,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
         bool kept;
         if constexpr (REC) {
             if (t < e1) rec = a.wd[q];
-            kept = is_kept(rec.x);
+            kept = t < e1;
         } else if constexpr (CSRM) {
             kept = t < e1 && kept_csr(a, a.csc_eid[q]);
         } else {

@@ -248,26 +248,65 @@ template <int G> __device__ __forceinline__ unsigned long long fwd_group_bits(un
 // ---------------------------------------------------------------------------
 constexpr int CAND_MAX_K = 32;   // split rows: chunk-local candidates are kept for k <= this
 
+// NK keys per lane (64 NK slots).  The search runs over the SCORE word first (32-bit compares) and
+// stops as soon as a prefix separates exactly k keys from the rest - for unrelated scores that is
+// the first bit in which the k-th and the (k+1)-th differ, ~15 of the 32 + lowbits steps of a full
+// search; the position bits are searched only when equal scores straddle the cut.  The kept set
+// is the full search's, bit for bit.
+template <int NK>
+__device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)[NK], int k, int lowbits,
+                                                 bool (&kept)[NK])
+{
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < NK; ++q) cnt += __popcll(__ballot(key[q] != 0ull));
+    if (cnt <= k) {                                           // everything that passed thr fits
+#pragma unroll
+        for (int q = 0; q < NK; ++q) kept[q] = key[q] != 0ull;
+        return;
+    }
+    unsigned hi[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) hi[q] = (unsigned)(key[q] >> 32);
+    unsigned Th = 0;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned cand = Th | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(hi[q] >= cand));
+        if (c >= k) {
+            Th = cand;
+            if (c == k) {                                     // (wave-uniform) no further bit changes the set
+#pragma unroll
+                for (int q = 0; q < NK; ++q) kept[q] = hi[q] >= Th;
+                return;
+            }
+        }
+    }
+    // equal scores on both sides of the cut: the edge position decides
+    unsigned long long T = ((unsigned long long)Th << 32) | (0xFFFFFFFFull & ~((1ull << lowbits) - 1ull));
+    for (int b = lowbits - 1; b >= 0; --b) {
+        const unsigned long long cand = T | (1ull << b);
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(key[q] >= cand));
+        if (c >= k) {
+            T = cand;
+            if (c == k) break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NK; ++q) kept[q] = key[q] >= T;      // T > 0 here, so empty slots (key 0) stay out
+}
+
 __device__ __forceinline__ void wave_topk_keys(unsigned long long key0, unsigned long long key1,
                                                int k, int lowbits, bool &kept0, bool &kept1)
 {
-    const bool v0 = key0 != 0ull, v1 = key1 != 0ull;
-    const int cnt = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-    if (cnt <= k) { kept0 = v0; kept1 = v1; return; }     // everything that passed thr fits
-    unsigned long long T = 0;
-    for (int b = 63; b >= 32; --b) {
-        const unsigned long long cand = T | (1ull << b);
-        const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
-        if (c >= k) T = cand;
-    }
-    T |= 0xFFFFFFFFull & ~((1ull << lowbits) - 1ull);
-    for (int b = lowbits - 1; b >= 0; --b) {
-        const unsigned long long cand = T | (1ull << b);
-        const int c = __popcll(__ballot(key0 >= cand)) + __popcll(__ballot(key1 >= cand));
-        if (c >= k) T = cand;
-    }
-    kept0 = key0 >= T;      // T > 0 here, so empty slots (key 0) stay out
-    kept1 = key1 >= T;
+    const unsigned long long key[2] = {key0, key1};
+    bool kept[2];
+    wave_topk_keys_n<2>(key, k, lowbits, kept);
+    kept0 = kept[0];
+    kept1 = kept[1];
 }
 
 __device__ __forceinline__ float key_score(unsigned long long key)
@@ -1170,18 +1209,29 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         sA[q] = a.cand_src[(size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k];
     }
     __syncthreads();
+    // tournament level: 256 keys per wave (4 per lane), so the biggest hub of an arxiv-like graph
+    // (13 k in-edges: 102 tasks x 16 = 1 632 keys) is down to 7 x 16 = 112 keys - one wave-level
+    // selection - after ONE level (128 per wave needed two levels and a third selection)
     while (n > 128) {
-        const int groups = (n + 127) / 128;
+        const int groups = (n + 255) / 256;
         for (int g = wave; g < groups; g += FINC_WAVES) {
-            const int q0 = g * 128 + lane, q1 = q0 + 64;
-            const unsigned long long key0 = q0 < n ? kA[q0] : 0ull, key1 = q1 < n ? kA[q1] : 0ull;
-            bool k0, k1;
-            wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
-            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-            const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
-            if (k0) { const int o = g * a.k + prefix_popc(m0); kB[o] = key0; sB[o] = sA[q0]; }
-            if (k1) { const int o = g * a.k + n0 + prefix_popc(m1); kB[o] = key1; sB[o] = sA[q1]; }
-            if (lane >= ns && lane < a.k) kB[g * a.k + lane] = 0ull;
+            unsigned long long key[4];
+            int q[4];
+            bool kp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q[u] = g * 256 + u * 64 + lane;
+                key[u] = q[u] < n ? kA[q[u]] : 0ull;
+            }
+            wave_topk_keys_n<4>(key, a.k, a.lowbits, kp);
+            int off = g * a.k;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(kp[u]);
+                if (kp[u]) { const int o = off + prefix_popc(m); kB[o] = key[u]; sB[o] = sA[q[u]]; }
+                off += __popcll(m);
+            }
+            if (g * a.k + lane >= off && lane < a.k) kB[g * a.k + lane] = 0ull;      // empty slots (k <= 32 < 64)
         }
         __syncthreads();
         n = groups * a.k;

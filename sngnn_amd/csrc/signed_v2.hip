@@ -1,0 +1,16 @@
+// Instantiates the signed cosine-attention kernels for rows read 2 float(s) per lane.
+#include "signed_impl.h"
+
+namespace sngnn {
+
+int launch_signed_fwd_v2(const RowCfg &cfg, const SignedArgs &a, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_signed_fwd, 2, cfg, a, st)
+}
+
+int launch_signed_bwd_v2(const RowCfg &cfg, const BwdArgs &a, const SignedBwdExtra &x, hipStream_t st)
+{
+    SNGNN_DISPATCH_GR(launch_signed_bwd, 2, cfg, a, x, st)
+}
+
+}  // namespace sngnn
