@@ -541,6 +541,69 @@ class AGNN(_Stack):
 
 
 # --------------------------------------------------------------------------
+# GGCN's sparse layer (models.py:1453-1553) - the signed cosine attention that shares the
+# gather skeleton.  All core torch in the reference: pinned by running the
+# reference class itself (tests/golden/pin_reference.py: pin_ggcn), no third-party stand-in.
+# --------------------------------------------------------------------------
+
+def ggcn_degree_precompute(adj: Tensor) -> Tensor:
+    """models.py:1691-1707 (GGCN.precompute_degree_s): a sparse matrix on adj's pattern with the
+    value ``adj[i, i] / adj[i, j] - 1`` at entry (i, j) - the reference's Python loop, vectorised
+    (``adj_diag`` lists the diagonal values in entry order and is indexed by ROW id, i.e. every
+    row is assumed to have its diagonal entry, as a normalised adjacency with self-loops does)."""
+    idx, val = adj._indices(), adj._values()
+    diag = val[idx[0] == idx[1]]
+    return torch.sparse_coo_tensor(idx, diag[idx[0]] / val - 1, adj.size())
+
+
+def signed_attention_values(idx: Tensor, wh: Tensor) -> Tuple[Tensor, Tensor]:
+    """models.py:1512-1519 (get_sparse_att): F.cosine_similarity of the rows at (idx[0], idx[1]),
+    split into its positive and negative parts."""
+    sim = F.cosine_similarity(wh[idx[0], :], wh[idx[1], :])
+    return F.relu(sim), -F.relu(-sim)
+
+
+class GGCNlayer_SP(nn.Module):
+    """models.py:1453-1553."""
+
+    def __init__(self, in_features, out_features, device, use_degree=True, use_sign=True, use_decay=True,
+                 scale_init=0.5, deg_intercept_init=0.5):
+        super().__init__()
+        self.fcn = nn.Linear(in_features, out_features)
+        self.use_degree, self.use_sign = use_degree, use_sign
+        if use_degree:
+            self.deg_coeff = Parameter(torch.tensor([0.5 if use_decay else deg_intercept_init, 0.0]))
+        if use_sign:
+            self.coeff = Parameter(torch.zeros(3))
+            self.scale = Parameter((2.0 if use_decay else scale_init) * torch.ones(1))
+        self.adj_remove_diag = None
+
+    def forward(self, h, adj, degree_precompute):
+        idx = adj._indices()
+        if self.use_degree:        # :1508-1510 non_linear_degree
+            sc = torch.sparse_coo_tensor(degree_precompute._indices(),
+                                         F.softplus(self.deg_coeff[0] * degree_precompute._values() + self.deg_coeff[1]),
+                                         degree_precompute.size())
+        wh = self.fcn(h)
+        if not self.use_sign:      # :1544-1549
+            return torch.sparse.mm(adj * sc if self.use_degree else adj, wh)
+        if self.adj_remove_diag is None:      # :1501-1506
+            keep = idx[0] != idx[1]
+            self.adj_remove_diag = torch.sparse_coo_tensor(idx[:, keep], adj._values()[keep], adj.size())
+        pos, neg = signed_attention_values(idx, wh)
+        e_pos = torch.sparse_coo_tensor(idx, pos, adj.size())
+        e_neg = torch.sparse_coo_tensor(idx, neg, adj.size())
+        if self.use_degree:
+            att_pos, att_neg = self.adj_remove_diag * sc * e_pos, self.adj_remove_diag * sc * e_neg
+        else:
+            att_pos, att_neg = self.adj_remove_diag * e_pos, self.adj_remove_diag * e_neg
+        prop_pos, prop_neg = torch.sparse.mm(att_pos, wh), torch.sparse.mm(att_neg, wh)
+        coeff = F.softmax(self.coeff, dim=-1)
+        scale = F.softplus(self.scale)
+        return scale * (coeff[0] * prop_pos + coeff[1] * prop_neg + coeff[2] * wh)
+
+
+# --------------------------------------------------------------------------
 # Operator-level entry used by the parity tests: everything after ``lin``
 # --------------------------------------------------------------------------
 

@@ -298,6 +298,61 @@ def attention(h: torch.Tensor, graph: Graph) -> torch.Tensor:
     return _Attention.apply(h, graph)
 
 
+class _SignedPropagate(torch.autograd.Function):
+    """GGCNlayer_SP's two signed propagations as ONE gather (models.py:1512-1519 + 1529-1537):
+    ``c2[0] * prop_pos + c2[1] * prop_neg`` with prop_+- = (adj_remove_diag * sc * e_+-) @ Wh.
+    ``coef`` [E'] = adj_e * sc_e in the graph's CSR order, ``c2`` [2] device scalars.  Gradients:
+    Wh from the kernels (no atomics), coef and c2 finished here from the kernel's per-edge
+    ``u_e = s_e <G_i, Wh_j>``."""
+
+    @staticmethod
+    def forward(ctx, wh, coef, c2, graph):
+        lib = _lib.load()
+        wh = _check_rows(wh, graph.num_total_nodes, "wh")
+        c = wh.size(1)
+        if coef.dtype != torch.float32 or coef.numel() != graph.num_edges or not coef.is_cuda:
+            raise ValueError("coef must be a float32 GPU tensor with one entry per edge of the graph")
+        if c2.dtype != torch.float32 or c2.numel() != 2 or not c2.is_cuda:
+            raise ValueError("c2 must be a float32 GPU tensor of 2 elements")
+        coef, c2 = coef.contiguous(), c2.contiguous()
+        out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=wh.device)
+        s = torch.empty(graph.num_edges, dtype=torch.float32, device=wh.device)
+        with torch.cuda.device(wh.device):
+            rc = lib.sngnn_signed_forward(graph.handle, wh.data_ptr(), c, coef.data_ptr(), c2.data_ptr(),
+                                          out.data_ptr(), s.data_ptr(), graph.workspace(c).data_ptr(),
+                                          _stream(wh.device))
+        _lib.check(rc, "sngnn_signed_forward")
+        ctx.graph = graph
+        ctx.save_for_backward(wh, coef, c2, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        wh, coef, c2, s = ctx.saved_tensors
+        graph = ctx.graph
+        lib = _lib.load()
+        g = _check_rows(g.contiguous(), graph.num_nodes, "grad_out")
+        c = wh.size(1)
+        grad_wh = torch.empty_like(wh)
+        u = torch.empty_like(s)
+        with torch.cuda.device(wh.device):
+            rc = lib.sngnn_signed_backward(graph.handle, wh.data_ptr(), c, g.data_ptr(), coef.data_ptr(),
+                                           s.data_ptr(), c2.data_ptr(), grad_wh.data_ptr(), u.data_ptr(),
+                                           graph.workspace(c).data_ptr(), _stream(wh.device))
+        _lib.check(rc, "sngnn_signed_backward")
+        pos, neg = s > 0, s < 0
+        zero = torch.zeros((), dtype=torch.float32, device=s.device)
+        kappa = torch.where(pos, c2[0], torch.where(neg, c2[1], zero))
+        au = coef * u
+        grad_c2 = torch.stack([torch.where(pos, au, zero).sum(), torch.where(neg, au, zero).sum()])
+        return grad_wh, kappa * u, grad_c2, None
+
+
+def signed_propagate(wh: torch.Tensor, coef: torch.Tensor, c2: torch.Tensor, graph: Graph) -> torch.Tensor:
+    """Differentiable signed cosine propagation: [N_total, C] -> [N, C] (see ``_SignedPropagate``)."""
+    return _SignedPropagate.apply(wh, coef, c2, graph)
+
+
 def adj_linear_forward(graph: Graph, wt: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     lib = _lib.load()
     wt = _check_rows(wt, graph.num_nodes, "wt")

@@ -684,6 +684,97 @@ def pin_toolbox(write):
                             **{k: torch.as_tensor(v).detach().numpy() for k, v in out.items()})
 
 
+# ---------------------------------------------------------------------------
+# GGCN's sparse layer (models.py:1453-1553): all core torch, so the reference class runs
+# verbatim here with NO third-party stand-in on its path
+# ---------------------------------------------------------------------------
+def ggcn_case(n, e, f, c, seed, hubs=()):
+    """A GGCN-style input: symmetric normalised adjacency with self-loops (coalesced sparse COO),
+    features, an output gradient; node n - 1 is isolated (only its loop)."""
+    from tests.helpers import random_graph
+    ei = random_graph(n - 1, e, seed=seed, hubs=hubs)
+    a = torch.zeros(n, n)
+    a[ei[1], ei[0]] = 1.0
+    a = ((a + a.t()) > 0).float()
+    a.fill_diagonal_(1.0)
+    d = a.sum(1)
+    adj = (a / torch.sqrt(d[:, None] * d[None, :])).to_sparse().coalesce()
+    gen = torch.Generator().manual_seed(seed + 1)
+    h = torch.randn(n, f, generator=gen)
+    h[3] = h[4]                      # duplicate rows: cosine exactly 1 on their edge (if linked)
+    gout = torch.randn(n, c, generator=gen)
+    return adj, h, gout
+
+
+GGCN_CASES = {
+    "ggcn_sp_c8": dict(shape=(120, 500, 16, 8, 41, ()), kw=dict()),
+    "ggcn_sp_c5_hub": dict(shape=(400, 1500, 24, 5, 42, ((7, 300), (9, 140))), kw=dict(use_decay=False)),
+    "ggcn_sp_c40_nodeg": dict(shape=(200, 900, 12, 40, 43, ()), kw=dict(use_degree=False)),
+}
+
+
+def pin_ggcn(R, write):
+    import contextlib
+    import io
+
+    class _Q:
+        def __enter__(self):
+            self.c = [contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO())]
+            for c in self.c:
+                c.__enter__()
+
+        def __exit__(self, *a):
+            for c in reversed(self.c):
+                c.__exit__(*a)
+    quiet = _Q()      # tqdm bar + the deprecated sparse constructor's warning
+    for name, spec in GGCN_CASES.items():
+        n, e, f, c, seed, hubs = spec["shape"]
+        adj, h, gout = ggcn_case(n, e, f, c, seed, hubs)
+        wrap = R.GGCN(f, 2, 16, c, 0.0, 1.0, 3.0, "cpu", use_sparse=True)
+        with quiet:
+            wrap.precompute_degree_s(adj)               # the reference's own loop (models.py:1691-1707)
+        dp = wrap.degree_precompute
+        _eq(dp._values(), O.ggcn_degree_precompute(adj)._values(), f"{name}.degree_precompute")
+        torch.manual_seed(seed)
+        lr = R.GGCNlayer_SP(f, c, "cpu", **spec["kw"])
+        torch.manual_seed(seed)
+        lo = O.GGCNlayer_SP(f, c, "cpu", **spec["kw"])
+        assert list(lr.state_dict()) == list(lo.state_dict())
+        with torch.no_grad():           # away from the symmetric initial point (coeff = 0)
+            for layer in (lr, lo):
+                layer.coeff.copy_(torch.tensor([0.3, -0.4, 0.1]))
+                if hasattr(layer, "deg_coeff"):
+                    layer.deg_coeff.copy_(torch.tensor([0.7, 0.2]))
+        for k, v in lr.state_dict().items():
+            _eq(v, lo.state_dict()[k], f"{name}.init.{k}")
+        hr, ho = h.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        with quiet:
+            out_r = lr(hr, adj, dp)
+        out_o = lo(ho, adj, dp)
+        _eq(out_r, out_o, f"{name}.out")
+        (out_r * gout).sum().backward()
+        (out_o * gout).sum().backward()
+        # (forward: bit for bit.  The gradients go through torch's multi-threaded CPU backward of
+        # the sparse products, whose summation order changes from run to run - the oracle differs
+        # from ITSELF in the last bits between two runs - so they are compared to rounding.)
+        dmax = _near(hr.grad, ho.grad, f"{name}.grad_h", 2e-6 * float(ho.grad.abs().max()))
+        grads = {}
+        for (k, pr), (_, po) in zip(lr.named_parameters(), lo.named_parameters()):
+            dmax = max(dmax, _near(pr.grad, po.grad, f"{name}.grad.{k}", 2e-6 * max(float(po.grad.abs().max()), 1.0)))
+            grads["grad_" + k.replace(".", "_")] = pr.grad.numpy()
+        print(f"  {name}: reference GGCNlayer_SP == oracle: forward bit for bit, {len(grads)} parameter gradients "
+              f"+ grad_h within {dmax:.1e} (n = {n}, nnz = {adj._nnz()})")
+        if write:
+            flags = spec["kw"]
+            np.savez_compressed(
+                os.path.join(OUT, f"{name}.npz"), adj_indices=adj._indices().numpy(), adj_values=adj._values().numpy(),
+                degree_values=dp._values().numpy(), h=h.numpy(), gout=gout.numpy(), out=out_r.detach().numpy(),
+                grad_h=hr.grad.numpy(), n=np.array([n, f, c], np.int64),
+                flags=np.array([int(flags.get("use_degree", True)), int(flags.get("use_sign", True)),
+                                int(flags.get("use_decay", True))], np.int64),
+                **{"param_" + k.replace(".", "_"): v.numpy() for k, v in lr.state_dict().items()}, **grads)
+
+
 def main():
     global USE_LOOP_SCATTER_MAX
     ap = argparse.ArgumentParser()
@@ -710,6 +801,8 @@ def main():
     make_actor_real(R, write=not args.check)
     print("Sim-GFA toolbox (SimGFAToolbox/dense.py, sparse.py):")
     pin_toolbox(write=not args.check)
+    print("GGCN sparse layer (models.py:1453-1553):")
+    pin_ggcn(R, write=not args.check)
     print("OK: the reference's in-tree lines agree with the oracle bit for bit; "
           "Appendix A (third-party kernels) remains unpinned")
 

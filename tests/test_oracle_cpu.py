@@ -251,3 +251,33 @@ def test_oracle_toolbox_sparse_fixture():
     for got, key in zip(O.neighborhood_similarity_sparse(adj, ei), ("nbr_sim", "nbr_mean")):
         np.testing.assert_allclose(torch.as_tensor(got).numpy(), z[key], atol=1e-7)
     np.testing.assert_allclose(O.class_similarity_sparse(adj, y).numpy(), z["class_mat"], atol=1e-7)
+
+
+def test_ggcn_layer_oracle_against_the_reference_made_fixtures():
+    """tests/golden/ggcn_sp_*.npz hold inputs and the outputs of the REFERENCE's GGCNlayer_SP
+    (models.py:1453-1553, run verbatim by pin_reference.py: all core torch): the oracle's
+    restatement gives the same forward and gradients to rounding (bit-equal forward where the
+    fixture was made; torch's threaded CPU sparse products are host- and run-dependent in the last bits)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "ggcn_sp_*.npz")))
+    assert len(paths) >= 3
+    for path in paths:
+        z = np.load(path)
+        n, f, c = (int(v) for v in z["n"])
+        kw = dict(zip(("use_degree", "use_sign", "use_decay"), (bool(v) for v in z["flags"])))
+        adj = torch.sparse_coo_tensor(torch.from_numpy(z["adj_indices"]), torch.from_numpy(z["adj_values"]), (n, n)).coalesce()
+        assert np.array_equal(O.ggcn_degree_precompute(adj)._values().numpy(), z["degree_values"])
+        dp = torch.sparse_coo_tensor(adj._indices(), torch.from_numpy(z["degree_values"]), (n, n)).coalesce()
+        layer = O.GGCNlayer_SP(f, c, "cpu", **kw)
+        layer.load_state_dict({k[6:].replace("fcn_", "fcn."): torch.from_numpy(z[k]) for k in z.files
+                               if k.startswith("param_")})
+        h = torch.from_numpy(z["h"]).requires_grad_(True)
+        out = layer(h, adj, dp)
+        # (bit for bit on the machine that made the fixture - pin_reference.py asserts that; another
+        # host CPU blocks torch's GEMM and sparse products differently)
+        np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=0, atol=2e-6 * np.abs(z["out"]).max())
+        (out * torch.from_numpy(z["gout"])).sum().backward()
+        np.testing.assert_allclose(h.grad.numpy(), z["grad_h"], rtol=0, atol=2e-6 * np.abs(z["grad_h"]).max())
+        for k, p in layer.named_parameters():
+            want = z["grad_" + k.replace(".", "_")]
+            np.testing.assert_allclose(p.grad.numpy(), want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1.0))
