@@ -217,22 +217,25 @@ def sn_edge_list(edge_index: Tensor, num_nodes: int, add_loops: bool,
 
 
 def propagate_mean(x: Tensor, norm: Tensor, ei: Tensor, top_k: Optional[int],
-                   thr: float, use_loop: bool = False):
+                   thr: float, use_loop: bool = False, smax=None, smean=None):
     """PyG ``propagate`` + ``message`` + mean ``aggregate`` for the three convs
     (models.py:132+139-158, :239+244-263, :326+331-334; Appendix A-3/A-4).
 
     ``top_k=None`` is SNConv (every edge weighted by its cosine).  Returns
     (out [N,C], s [E'], weight [E'], per-round index list or None).
+    ``smax`` / ``smean``: the REAL ``torch_scatter.scatter_max(src, index)`` /
+    ``scatter(msg, index, dim_size)`` where that package imports (bench.py's literal-reference
+    CPU leg, tests/third_party_cases.py) instead of the restatements above.
     """
     N = x.size(0)
     s = edge_cosine(norm, ei)
     if top_k is None:
         weight, rounds = s, None
     else:
-        weight, rounds = topk_threshold_weights(s, ei[1], top_k, thr, use_loop)
+        weight, rounds = topk_threshold_weights(s, ei[1], top_k, thr, use_loop, smax)
     x_j = x.index_select(0, ei[0])
     msg = weight.view(-1, 1) * x_j
-    out = scatter_mean(msg, ei[1], N)
+    out = scatter_mean(msg, ei[1], N) if smean is None else smean(msg, ei[1], N)
     return out, s, weight, rounds
 
 
@@ -609,7 +612,7 @@ class GGCNlayer_SP(nn.Module):
 
 def aggregate_reference(h: Tensor, edge_index: Tensor, *, add_loops: bool = True,
                         remove_loops: bool = False, top_k: Optional[int] = None,
-                        thr: float = 0.0, use_loop: bool = False):
+                        thr: float = 0.0, use_loop: bool = False, smax=None, smean=None):
     """The fused operator's contract, computed the reference's way.
 
     h: [N, C] fp32 (the output of ``self.lin``).  Returns a dict with
@@ -623,7 +626,7 @@ def aggregate_reference(h: Tensor, edge_index: Tensor, *, add_loops: bool = True
     N = h.size(0)
     ei = sn_edge_list(edge_index, N, add_loops, remove_loops)
     norm = F.normalize(h, p=2., dim=-1)
-    out, s, weight, rounds = propagate_mean(h, norm, ei, top_k, thr, use_loop)
+    out, s, weight, rounds = propagate_mean(h, norm, ei, top_k, thr, use_loop, smax, smean)
     res = dict(out=out, ei=ei, s=s, weight=weight)
     if top_k is not None:
         res["sel_src"], res["sel_pos"] = selected_sources(rounds, ei, N, top_k)

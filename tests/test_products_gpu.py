@@ -110,3 +110,87 @@ def test_plus_plus_layer_at_products_size(cuda):
         assert (got - dw).abs().max() <= 1e-4 * dw.abs().max() + 1e-9, int(i)
     # lin.weight's gradient exists and is finite (its value is checked at test size elsewhere)
     assert bool(torch.isfinite(conv.lin.weight.grad).all()) and float(conv.lin.weight.grad.abs().max()) > 0
+
+
+def test_products_eight_way_split_equals_the_whole(cuda):
+    """BASELINE config 5's PARTITION at full size on one GPU: the products-sized graph cut into
+    the 8 node ranges the 8 ranks would own (``sngnn_graph_create_partition``; all-gather form of the
+    exchange, which on one GPU needs no collective - the full feature table is simply there), the
+    ++ layer's forward and backward run range by range with ``w`` sharded by node range (a rank's
+    adjacency branch gathers W^T rows through the partition of the FLIPPED edge list, as
+    sngnn_amd/conv.py does under a partition).  The ranges' outputs, concatenated, are the whole
+    graph's output - bit for bit for the aggregation - and the ranges' partial gradients, summed
+    (what the reduce-scatter does), are the whole graph's gradients.  models/models.py:116-137;
+    SURVEY.md 8e.  Also: edges per rank and time per rank for even and edge-balanced bounds."""
+    import time
+
+    from sngnn_amd import ops
+    from sngnn_amd.dist import Partition
+    from sngnn_amd.graph import Graph
+    from tests.helpers import REPORT_LINES
+    W, C = 8, 48
+    ei = _products_like_graph(cuda)
+    g = torch.Generator(device=cuda).manual_seed(21)
+    h = torch.randn(N, C, generator=g, device=cuda)
+    h[:, 47] = 0.0                                          # 47 classes padded to 16-byte rows
+    wt = torch.randn(N, C, generator=g, device=cuda) * 0.01  # W^T of Linear(num_nodes, C)
+    bias = torch.randn(C, generator=g, device=cuda) * 0.01
+    beta = torch.full((1,), BETA, device=cuda)
+    gout = torch.randn(N, C, generator=g, device=cuda) * 1e-3
+
+    def layer(graph_t, graph_adj, rows, whole):
+        """forward + backward of the ++ layer on the target rows ``rows`` = (begin, end)."""
+        hg, wg, bg, be = (t.clone().requires_grad_(True) for t in (h, wt, bias, beta))
+        out1 = ops.aggregate(hg, graph_t, K, THR)
+        out0 = ops.adj_linear(wg.t(), bg, graph_t) if whole else ops.gather_sum(wg, bg, graph_adj)
+        out = ops.blend(out0, out1, be)
+        out.backward(gout[rows[0]:rows[1]])
+        return out.detach(), out1.detach(), out0.detach(), hg.grad, wg.grad, bg.grad, be.grad
+
+    gw = Graph(ei, N, True, True)
+    whole = layer(gw, None, (0, N), True)
+    e_total = gw.num_edges
+    del gw
+    ei_f = ei.flip(0).contiguous()
+    deg_in = torch.bincount(ei[1][ei[0] != ei[1]], minlength=N)
+    report = {}
+    for name, bounds in (("even", Partition.even_bounds(N, W)),
+                         ("edge_balanced", Partition.edge_balanced_bounds(deg_in, W))):
+        assert bounds[0] == 0 and bounds[-1] == N and len(bounds) == W + 1
+        outs, out1s, out0s = [], [], []
+        dh = torch.zeros_like(h)
+        dw = torch.zeros_like(wt)
+        db = torch.zeros_like(bias)
+        dbeta = torch.zeros_like(beta)
+        edges, ms = [], []
+        for r in range(W):
+            rows = (bounds[r], bounds[r + 1])
+            gt = Graph(ei, N, True, True, row_range=rows)
+            gf = Graph(ei_f, N, True, True, row_range=rows)
+            assert gt.num_nodes == rows[1] - rows[0] and gt.num_total_nodes == N
+            edges.append(gt.num_edges)
+            res = layer(gt, gf, rows, False)               # (also the warm-up of the timing below)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            layer(gt, gf, rows, False)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            outs.append(res[0]); out1s.append(res[1]); out0s.append(res[2])
+            dh += res[3]; dw += res[4]; db += res[5]; dbeta += res[6]
+            del gt, gf, res
+        assert sum(edges) == e_total
+        assert torch.equal(torch.cat(out1s), whole[1]), f"{name}: aggregation of the ranges != whole graph"
+        out0 = torch.cat(out0s)
+        assert float((out0 - whole[2]).abs().max()) <= 1e-6 * float(whole[2].abs().max())
+        assert float((torch.cat(outs) - whole[0]).abs().max()) <= 1e-6 * float(whole[0].abs().max())
+        for got, want, what in ((dh, whole[3], "grad_h"), (dw, whole[4], "grad_w"), (db, whole[5], "grad_w_bias"),
+                                (dbeta, whole[6], "grad_beta")):
+            sc = float(want.abs().max())
+            tol = 2e-6 * sc if want.numel() > C else 2e-4 * sc      # (the two scalars-ish: signed sums over 117 M terms)
+            assert float((got - want).abs().max()) <= tol, (name, what, float((got - want).abs().max()), sc)
+        report[name] = (edges, ms)
+        REPORT_LINES.append(f"config 5, 8-way {name} split on one GPU: edges per rank max / mean = "
+                            f"{max(edges) / (sum(edges) / W):.3f}; ++ layer forward + backward per rank "
+                            f"[ms] = {', '.join(f'{t:.2f}' for t in ms)} (max {max(ms):.2f})")
+    # the edge-balanced bounds are what they say
+    assert max(report["edge_balanced"][0]) <= 1.02 * sum(report["edge_balanced"][0]) / W

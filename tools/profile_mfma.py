@@ -41,7 +41,7 @@ for name, n, f in (("chameleon", 2277, 2325), ("cora", 2708, 1433), ("actor", 76
           f"nominal {fl / t / 1e12:6.1f} TFLOP/s on 2 N^2 F = {fl / 1e9:.1f} GF;  "
           f"done {fl / 2 / t / 1e12:6.1f} TFLOP/s = {fl / 2 / t / FP32_MFMA_PEAK:5.1%} of the fp32 MFMA peak", flush=True)
 
-for n, f, k in ((20000, 128, 16), (169343, 128, 16)):
+for n, f, k in ((2277, 2325, 10), (7600, 932, 10), (20000, 128, 16), (169343, 128, 16)):
     x = torch.randn(n, f, generator=g, device=dev)
     t = timed(lambda: toolbox.knn_graph(x, k), reps=3 if n > 50000 else REPS)
     fl = 2.0 * n * n * f
