@@ -69,7 +69,9 @@ static int g_role_mask = 7;
 static int g_table_mode = 0;
 extern "C" int sngnn_tuning_set(int which, int value)
 {
-    SN_REQUIRE(which == 0 || (which >= 2 && which <= 5), SNGNN_EINVAL, "unknown tuning knob");
+    SN_REQUIRE(which == 0 || (which >= 2 && which <= 7), SNGNN_EINVAL, "unknown tuning knob");
+    if (which == 7) return sngnn::set_cosine_split(value);
+    if (which == 6) return sngnn::set_knn_route(value);
     if (which == 5) return sngnn::set_lin_mode(value);
     if (which == 3) return sngnn::set_bwd_mode(value);
     if (which == 4) return sngnn::set_bwd_roles(value);

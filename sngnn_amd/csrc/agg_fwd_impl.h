@@ -248,57 +248,7 @@ template <int G> __device__ __forceinline__ unsigned long long fwd_group_bits(un
 // ---------------------------------------------------------------------------
 constexpr int CAND_MAX_K = 32;   // split rows: chunk-local candidates are kept for k <= this
 
-// NK keys per lane (64 NK slots).  The search runs over the SCORE word first (32-bit compares) and
-// stops as soon as a prefix separates exactly k keys from the rest - for unrelated scores that is
-// the first bit in which the k-th and the (k+1)-th differ, ~15 of the 32 + lowbits steps of a full
-// search; the position bits are searched only when equal scores straddle the cut.  The kept set
-// is the full search's, bit for bit.
-template <int NK>
-__device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)[NK], int k, int lowbits,
-                                                 bool (&kept)[NK])
-{
-    int cnt = 0;
-#pragma unroll
-    for (int q = 0; q < NK; ++q) cnt += __popcll(__ballot(key[q] != 0ull));
-    if (cnt <= k) {                                           // everything that passed thr fits
-#pragma unroll
-        for (int q = 0; q < NK; ++q) kept[q] = key[q] != 0ull;
-        return;
-    }
-    unsigned hi[NK];
-#pragma unroll
-    for (int q = 0; q < NK; ++q) hi[q] = (unsigned)(key[q] >> 32);
-    unsigned Th = 0;
-    for (int b = 31; b >= 0; --b) {
-        const unsigned cand = Th | (1u << b);
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(hi[q] >= cand));
-        if (c >= k) {
-            Th = cand;
-            if (c == k) {                                     // (wave-uniform) no further bit changes the set
-#pragma unroll
-                for (int q = 0; q < NK; ++q) kept[q] = hi[q] >= Th;
-                return;
-            }
-        }
-    }
-    // equal scores on both sides of the cut: the edge position decides
-    unsigned long long T = ((unsigned long long)Th << 32) | (0xFFFFFFFFull & ~((1ull << lowbits) - 1ull));
-    for (int b = lowbits - 1; b >= 0; --b) {
-        const unsigned long long cand = T | (1ull << b);
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(key[q] >= cand));
-        if (c >= k) {
-            T = cand;
-            if (c == k) break;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NK; ++q) kept[q] = key[q] >= T;      // T > 0 here, so empty slots (key 0) stay out
-}
-
+// (wave_topk_keys_n: device_utils.h)
 __device__ __forceinline__ void wave_topk_keys(unsigned long long key0, unsigned long long key1,
                                                int k, int lowbits, bool &kept0, bool &kept1)
 {

@@ -41,6 +41,8 @@ int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, f
 int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knobs 3, 4)
 int set_bwd_roles(int v);
 int set_lin_mode(int v);       // linear.hip (knob 5)
+int set_knn_route(int v);      // knn.hip (knob 6)
+int set_cosine_split(int v);   // toolbox.hip (knob 7)
 bool fp32_mfma_only();         // knob 5 == 1: the fp32 contractions stay on fp32 MFMAs
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

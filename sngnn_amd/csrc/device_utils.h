@@ -85,6 +85,63 @@ __device__ __forceinline__ unsigned long long sel_key(float s, unsigned idx)
     return ((unsigned long long)f2key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
 
+// ---------------------------------------------------------------------------
+// Wave-level top-k of selection keys (sel_key above; 0 = no key), NK per lane: bitwise search for
+// a threshold that leaves exactly the k largest.  Keys are unique, so "the k largest" is well
+// defined.  lowbits = bits of the largest index (the low word of a key is 0xFFFFFFFF - index, so
+// its upper 32 - lowbits bits are all ones and need no search).
+// ---------------------------------------------------------------------------
+// NK keys per lane (64 NK slots).  The search runs over the SCORE word first (32-bit compares) and
+// stops as soon as a prefix separates exactly k keys from the rest - for unrelated scores that is
+// the first bit in which the k-th and the (k+1)-th differ, ~15 of the 32 + lowbits steps of a full
+// search; the position bits are searched only when equal scores straddle the cut.  The kept set
+// is the full search's, bit for bit.
+template <int NK>
+__device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)[NK], int k, int lowbits,
+                                                 bool (&kept)[NK])
+{
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < NK; ++q) cnt += __popcll(__ballot(key[q] != 0ull));
+    if (cnt <= k) {                                           // everything that passed thr fits
+#pragma unroll
+        for (int q = 0; q < NK; ++q) kept[q] = key[q] != 0ull;
+        return;
+    }
+    unsigned hi[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) hi[q] = (unsigned)(key[q] >> 32);
+    unsigned Th = 0;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned cand = Th | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(hi[q] >= cand));
+        if (c >= k) {
+            Th = cand;
+            if (c == k) {                                     // (wave-uniform) no further bit changes the set
+#pragma unroll
+                for (int q = 0; q < NK; ++q) kept[q] = hi[q] >= Th;
+                return;
+            }
+        }
+    }
+    // equal scores on both sides of the cut: the edge position decides
+    unsigned long long T = ((unsigned long long)Th << 32) | (0xFFFFFFFFull & ~((1ull << lowbits) - 1ull));
+    for (int b = lowbits - 1; b >= 0; --b) {
+        const unsigned long long cand = T | (1ull << b);
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) c += __popcll(__ballot(key[q] >= cand));
+        if (c >= k) {
+            T = cand;
+            if (c == k) break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NK; ++q) kept[q] = key[q] >= T;      // T > 0 here, so empty slots (key 0) stay out
+}
+
 // ---- fp32 operands for the bf16 matrix cores --------------------------------------------------
 // A float is the EXACT sum of three bf16 values (truncate to the top 16 bits, subtract, repeat:
 // 8 + 8 + 8 significant bits; every step exact), and a product of two bf16 values is exact in

@@ -414,6 +414,109 @@ __global__ __launch_bounds__(256) void k_knn_merge(const unsigned long long *__r
     }
 }
 
+// ---------------------------------------------------------------------------
+// Small graphs: materialise + select.  When S fits comfortably (N <= KNN_DENSE_MAX_N) and the
+// features are wide (the register-operand path above is for F <= 128), the dense cosine kernel
+// (toolbox.hip: upper triangle on the matrix cores, mirrored) followed by this row selection beats
+// the fused scan, whose both-panels-through-LDS path pays eight barriers per tile: Chameleon
+// (2 277 x 2 325) and Actor (7 600 x 932) - BASELINE configs 2 and 3 - are this case.
+// One wave per row of S: 256 entries per step (16 bytes per lane), an entry enters the selection
+// only when its key beats the row's current k-th key; survivors are parked behind the list in
+// LDS and merged when the buffer is full (the aggregation's early-exit k-th-key search).
+// Same keys, same order and padding as the fused kernel.
+// ---------------------------------------------------------------------------
+constexpr int64_t KNN_DENSE_MAX_N = 16384;
+
+__global__ __launch_bounds__(256) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int exclude_self,
+                                                  int lowbits, int32_t *__restrict__ out_idx,
+                                                  float *__restrict__ out_sim)
+{
+    __shared__ unsigned long long s_key[4][128];          // [0, k): the list (0 = empty); [k, k + pend): parked
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= N) return;                                   // wave-uniform
+    unsigned long long *keys = s_key[wave];
+    keys[lane] = 0ull;
+    keys[lane + 64] = 0ull;
+    const int cap = 128 - k;
+    int pend = 0;
+    unsigned long long T = 0ull;                          // the list's k-th key (0: not full yet)
+    auto merge = [&]() {
+        wave_lds_sync();
+        const unsigned long long key[2] = {keys[lane], keys[lane + 64]};
+        bool kept[2];
+        wave_topk_keys_n<2>(key, k, lowbits, kept);
+        const unsigned long long m0 = __ballot(kept[0]), m1 = __ballot(kept[1]);
+        const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+        // the new threshold: the smallest kept key once the list is full
+        unsigned long long mn = ~0ull;
+        if (kept[0]) mn = key[0];
+        if (kept[1] && key[1] < mn) mn = key[1];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = __shfl_xor(mn, m, 64);
+            mn = o < mn ? o : mn;
+        }
+        wave_lds_sync();                                  // every lane has read the old contents
+        keys[lane] = 0ull;
+        keys[lane + 64] = 0ull;
+        wave_lds_sync();
+        if (kept[0]) keys[prefix_popc(m0)] = key[0];
+        if (kept[1]) keys[n0 + prefix_popc(m1)] = key[1];
+        wave_lds_sync();
+        T = ns >= k ? mn : 0ull;
+        pend = 0;
+    };
+    const float *row = S + i * N;
+    const bool vec = (N % 4 == 0) && ((uintptr_t)S % 16 == 0);
+    for (int64_t base = 0; base < N; base += 256) {
+        const int64_t c0 = base + lane * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && c0 + 3 < N) {
+            const float4 t = *reinterpret_cast<const float4 *>(row + c0);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < N) v[u] = row[c0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = c0 + u;
+            const bool valid = c < N && !(exclude_self && c == i);
+            const unsigned long long key = valid ? sel_key(v[u] + 0.0f, (unsigned)c) : 0ull;
+            const bool pass = key > T;                    // (an invalid slot's key 0 never passes)
+            unsigned long long m = __ballot(pass);
+            if (m == 0ull) continue;                      // wave-uniform: the common case after the first steps
+            if (pend + __popcll(m) > cap) merge();        // (at most 64 new ones, cap >= 96)
+            const bool still = pass && key > T;           // the merge may have raised the threshold
+            m = __ballot(still);
+            if (still) keys[k + pend + prefix_popc(m)] = key;
+            pend += __popcll(m);
+        }
+    }
+    if (pend > 0) merge();
+    wave_lds_sync();
+    if (lane < k) {
+        const unsigned long long kq = keys[lane];
+        int rk = 0, n = 0;
+        for (int q = 0; q < k; ++q) {
+            const unsigned long long o = keys[q];
+            rk += o > kq;
+            n += o != 0ull;
+        }
+        if (kq != 0ull) {
+            const unsigned u = (unsigned)(kq >> 32);
+            out_idx[i * k + rk] = (int32_t)(0xFFFFFFFFu - (unsigned)kq);
+            out_sim[i * k + rk] = __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+        }
+        if (lane >= n) {               // fewer than k eligible nodes: pad
+            out_idx[i * k + lane] = -1;
+            out_sim[i * k + lane] = 0.f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_knn_inv_norm(const float *__restrict__ x, int64_t N, int64_t F,
                                                       float *__restrict__ inv)
 {
@@ -431,6 +534,10 @@ __global__ __launch_bounds__(256) void k_knn_inv_norm(const float *__restrict__ 
 }  // namespace sngnn
 
 using namespace sngnn;
+
+// 0 = by shape (default), 1 = the fused scan always, 2 = materialise + select always (measurement: sngnn_tuning_set(6, v))
+static int g_knn_route = 0;
+namespace sngnn { int set_knn_route(int v) { if (v < 0 || v > 2) return SNGNN_EINVAL; g_knn_route = v; return SNGNN_OK; } }
 
 // column splits: enough workgroups to fill the chip when there are few row blocks
 static int knn_splits(int64_t N)
@@ -455,6 +562,22 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     if (N == 0) return SNGNN_OK;
     SN_REQUIRE(x && nbr_idx && nbr_sim && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
+    const bool narrow = (uintptr_t)x % 16 == 0 && (F == 128 || F == 96 || F == 64 || F == 32);   // register-operand path
+    if (g_knn_route == 2 || (g_knn_route == 0 && !narrow && N <= KNN_DENSE_MAX_N && N >= 2)) {
+        // materialise + select (see k_row_topk); S lives in a stream-ordered allocation
+        SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "the dense route is for small graphs");
+        void *S = nullptr;
+        SN_REQUIRE(hipMallocAsync(&S, (size_t)N * N * 4, st) == hipSuccess, SNGNN_ENOMEM, "out of device memory");
+        int rc = sngnn_cosine_dense(x, N, F, (float *)S, stream);
+        if (rc == SNGNN_OK) {
+            int lowbits = 1;
+            while (((int64_t)1 << lowbits) < N && lowbits < 31) ++lowbits;
+            k_row_topk<<<(unsigned)((N + 3) / 4), 256, 0, st>>>((const float *)S, N, k, exclude_self, lowbits, nbr_idx, nbr_sim);
+            if (hipGetLastError() != hipSuccess) rc = SNGNN_EHIP;
+        }
+        (void)hipFreeAsync(S, st);
+        return rc;
+    }
     float *inv = (float *)workspace;
     unsigned long long *part = (unsigned long long *)((char *)workspace + (N + 63) / 64 * 256);
     const int ns = knn_splits(N);

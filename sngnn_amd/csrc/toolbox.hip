@@ -502,6 +502,10 @@ __global__ void k_check_labels(const int32_t *y, int64_t n, int n_classes, int *
 
 using namespace sngnn;
 
+// sngnn_tuning_set(7, ks): force the contraction split of the dense cosine (0 = by shape)
+static int g_cosine_split = 0;
+namespace sngnn { int set_cosine_split(int v) { if (v < 0 || v > 16) return SNGNN_EINVAL; g_cosine_split = v; return SNGNN_OK; } }
+
 extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S, void *stream)
 {
     SN_REQUIRE(N >= 0 && F >= 1, SNGNN_EINVAL, "bad shape");
@@ -527,6 +531,10 @@ extern "C" int sngnn_cosine_dense(const float *x, int64_t N, int64_t F, float *S
     // split); the partial tiles are added in split order by k_cosine_reduce (deterministic)
     int ks = 1;
     if (tiles <= 96) ks = (int)std::min<int64_t>(std::min<int64_t>(8, (512 + tiles - 1) / tiles), std::max<int64_t>(1, ld / (2 * TB_K)));
+    // fewer tiles than CUs with a long contraction (Chameleon: 171 tiles, F = 2 325): two halves per tile
+    // put a second workgroup on most CUs - 0.203 -> 0.176 ms (three or four splits: the reduce pass eats it)
+    else if (tiles < 220 && ld >= 16 * TB_K) ks = 2;
+    if (g_cosine_split > 0) ks = (int)std::min<int64_t>(g_cosine_split, std::max<int64_t>(1, ld / (2 * TB_K)));    // (measurement)
     const int64_t k_per = ((ld + ks - 1) / ks + TB_K - 1) / TB_K * TB_K;
     ks = (int)((ld + k_per - 1) / k_per);
     AsyncBuf part(st);

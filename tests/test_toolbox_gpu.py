@@ -150,18 +150,26 @@ def test_signed_edge_attention_ggcn(cuda):
 @pytest.mark.parametrize("n,f,k,excl", [(300, 16, 5, True), (1000, 64, 16, True), (777, 33, 32, False),
                                         (130, 7, 10, True), (5, 8, 8, True), (1, 4, 3, True),
                                         (2500, 128, 16, True), (900, 96, 7, True), (640, 64, 31, False),
-                                        (513, 32, 1, True)])
-def test_knn_graph_matches_dense_topk(cuda, n, f, k, excl):
-    """Fused MFMA cosine + per-row top-k against the materialised similarity (fp64): every
-    returned neighbour's cosine is right, the list is ordered, and nothing clearly better
-    was left out (pairs closer than 2e-6 may swap)."""
+                                        (513, 32, 1, True), (2277, 200, 10, True), (1030, 51, 32, True)])
+@pytest.mark.parametrize("route", [0, 1, 2])
+def test_knn_graph_matches_dense_topk(cuda, n, f, k, excl, route):
+    """The kNN builder against the materialised similarity (fp64): every returned neighbour's
+    cosine is right, the list is ordered, and nothing clearly better was left out (pairs closer
+    than 2e-6 may swap).  route (sngnn_tuning_set(6, .)): 0 = by shape (default), 1 = the fused
+    MFMA scan with its per-row top-k epilogue, 2 = dense cosine kernel + row selection (what
+    small graphs with wide features take by default)."""
+    from sngnn_amd import _lib
     from sngnn_amd import toolbox as T
     gen = torch.Generator().manual_seed(n + k)
     x = torch.randn(n, f, generator=gen)
     if n > 12:
         x[7] = x[3]                       # exact duplicates: tie broken by node id
         x[11] = 0.0                       # a zero row: cosine 0 with everything
-    idx, sim = T.knn_graph(x.to(cuda), k, exclude_self=excl)
+    try:
+        _lib.load().sngnn_tuning_set(6, route)
+        idx, sim = T.knn_graph(x.to(cuda), k, exclude_self=excl)
+    finally:
+        _lib.load().sngnn_tuning_set(6, 0)
     idx, sim = idx.cpu(), sim.cpu()
     xn = torch.nn.functional.normalize(x.double(), dim=1)
     S = xn @ xn.t()

@@ -45,5 +45,12 @@ for name, n, f in shapes:
     nb = (n + 127) // 128
     done = 2.0 * f * 128 * 128 * (nb * (nb + 1) // 2)
     diff = (toolbox.cosine_similarity_dense_small(x) - lib(x)).abs().max().item()
-    print(f"{name:10s} {n:6d} x {f:5d}    {ours:9.3f} ms  {done / ours / 1e9 / PEAK * 100:11.1f} %  "
-          f"{ref:11.3f} ms  {2.0 * n * n * f / ref / 1e9 / PEAK * 100:6.1f} %  {diff:.1e}", flush=True)
+    line = (f"{name:10s} {n:6d} x {f:5d}    {ours:9.3f} ms  {done / ours / 1e9 / PEAK * 100:11.1f} %  "
+            f"{ref:11.3f} ms  {2.0 * n * n * f / ref / 1e9 / PEAK * 100:6.1f} %  {diff:.1e}")
+    if os.environ.get("KS"):          # sweep of the contraction split (sngnn_tuning_set(7, ks)): "ks:ms" pairs
+        from sngnn_amd import _lib
+        for ks in (int(v) for v in os.environ["KS"].split(",")):
+            _lib.load().sngnn_tuning_set(7, ks)
+            line += f"  ks{ks}:{timed(lambda: toolbox.cosine_similarity_dense_small(x)):.3f}"
+        _lib.load().sngnn_tuning_set(7, 0)
+    print(line, flush=True)

@@ -23,11 +23,19 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-for n, f, k in ((2277, 2325, 10), (7600, 932, 10), (20000, 128, 16), (169343, 128, 16)):
+from sngnn_amd import _lib  # noqa: E402
+lib = _lib.load()
+for n, f, k in ((2277, 2325, 10), (7600, 932, 10), (2708, 1433, 10), (12000, 500, 16), (20000, 128, 16), (169343, 128, 16)):
     x = torch.randn(n, f, device=dev)
     t = timed(lambda: T.knn_graph(x, k), reps=3 if n > 50000 else 10)
     flop = 2.0 * n * n * f
-    line = f"N={n:7d} F={f:5d} k={k:2d}: fused {t:9.2f} ms  ({flop / t / 1e9:6.1f} TFLOP/s effective)"
+    line = f"N={n:7d} F={f:5d} k={k:2d}: builder (route by shape) {t:9.2f} ms  ({flop / t / 1e9:6.1f} TFLOP/s effective)"
+    if n <= 16384:
+        lib.sngnn_tuning_set(6, 1)
+        line += f"   fused scan {timed(lambda: T.knn_graph(x, k), reps=5):9.2f} ms"
+        lib.sngnn_tuning_set(6, 2)
+        line += f"   dense cosine + row selection {timed(lambda: T.knn_graph(x, k), reps=5):9.2f} ms"
+        lib.sngnn_tuning_set(6, 0)
     if n <= 20000:
         def dense():
             s = T.cosine_similarity_dense_small(x)

@@ -34,7 +34,9 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         if any(w in k for w in KEEP):
-            dur[(k, r.get("Grid_Size", "?"))].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9)
+            grid = str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])) if "Grid_Size_X" in r \
+                else r.get("Grid_Size", "?")
+            dur[(k, grid)].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9)
 print("\n== MFMA utilisation (busy cycles of the matrix pipes / SIMD cycles of the dispatch) ==")
 print(f"{'kernel':64s} {'grid':>10s} {'avg_us':>9s} {'MFMA busy':>13s} {'GUI_ACTIVE/8':>13s} {'util':>7s} {'util@2.4GHz':>11s} {'MOPS_BF16':>13s} {'MOPS_F32':>12s}")
 for key in sorted(acc):
