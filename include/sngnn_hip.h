@@ -186,6 +186,36 @@ int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const flo
                                const void *filt, int C, int top_k, float thr, float *out,
                                float *wsel, float *inv_norm, int32_t *sel_src, float *sel_w,
                                void *workspace, void *stream);
+
+/*
+ * The forward with a hidden layer's store epilogue.  Replaces, on top of sngnn_agg_forward /
+ * sngnn_agg_forward_prepared: the elementwise passes the reference runs between two conv layers
+ * (models.py:204-209 / :79-84 / :296-301): `out + self.bias` (:135-136, 240-241, 327-328),
+ * `F.relu(x, inplace=True)` and, in training, `self.dropout(x)` - applied to each finished mean row
+ * on its way out instead of three more passes over [N, C]:
+ *     out[i, c] = keep[i, c] ? max(mean[i, c] + bias[c], 0) * keep_scale : 0
+ * bias NULL: none; relu 0: none; keep NULL and seed NULL: no dropout (evaluation, or p == 0).  keep
+ * is the caller's own Bernoulli(1 - p) draw, uint8 [N, C]; or seed (a device counter) lets the
+ * kernel draw it; keep_scale = 1 / (1 - p) either way.  C % 4 == 0.  The mask the backward
+ * needs is out > 0 (times keep_scale): nothing else has to be saved (sngnn_linear_forward_masked).
+ * (No batch norm in between: models.py:207-208's bn stays a layer of its own.)
+ */
+typedef struct sngnn_epilogue {
+    const float *bias;
+    const unsigned char *keep;
+    float keep_scale;
+    int relu;
+    const void *seed;       /* dev uint64 [1] or NULL (with keep == NULL): draw the keep mask in the kernel, */
+    float p;                /* keep[i, c] = u(seed, i * C + c) >= p, u a counter-based uniform: the same     */
+                            /* seed gives the same mask; the caller advances the seed between forwards       */
+} sngnn_epilogue_t;
+int sngnn_agg_forward_epilogue(const sngnn_graph_t *g, const float *h, int C, int top_k, float thr,
+                               const sngnn_epilogue_t *epi, float *out, float *wsel, float *inv_norm,
+                               void *workspace, void *stream);
+int sngnn_agg_forward_prepared_epilogue(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                        const void *filt, int C, int top_k, float thr,
+                                        const sngnn_epilogue_t *epi, float *out, float *wsel,
+                                        float *inv_norm, void *workspace, void *stream);
 int sngnn_filter_enable(int mode);
 /* whether sngnn_agg_forward would use filter rows for this call (a caller that prepares the
  * rows itself writes them only then) */
@@ -413,6 +443,18 @@ int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *
  */
 int sngnn_linear_forward(const float *x, const float *weight, const float *bias,
                          int64_t N, int F, int C, float *h, void *stream);
+/*
+ * h = act > 0 ? (x W^T + b) * act_scale : 0, act dev f32 [N, C]: the input gradient g W of a layer
+ * (x = g, weight = W^T) whose input `act` was the epilogue'd output of the layer before
+ * (sngnn_agg_forward_epilogue): autograd's threshold_backward and dropout backward
+ * (models.py:206-209) folded into the store.  Any F, C <= 64.
+ */
+int sngnn_linear_forward_masked(const float *x, const float *weight, const float *bias, int64_t N,
+                                int F, int C, const float *act, float act_scale, float *h, void *stream);
+/* The same mask as a pass of its own (for a consumer that did not fold it into its store):
+ * grad_pre[q] = act[q] > 0 ? grad[q] * scale : 0 over n = N * C elements (may alias grad). */
+int sngnn_epilogue_backward(const float *grad, const float *act, float scale, int64_t n, float *grad_pre,
+                            void *stream);
 /*
  * Replaces: self.lin followed by F.normalize (models.py:237-238, :121-122, :324-325 - adjacent
  * lines of every conv forward): h as above AND, from the same launch's epilogue, the unit rows

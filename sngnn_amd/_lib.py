@@ -42,6 +42,9 @@ SIGNATURES = {
     "sngnn_normalize_rows_filter": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_agg_forward_prepared": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp]),
+    "sngnn_agg_forward_epilogue": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_agg_forward_prepared_epilogue": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
+                                                   _vp]),
     "sngnn_filter_enable": (_i32, [_i32]),
     "sngnn_filter_wanted": (_i32, [_vp, _i32, _i32, _f32]),
     "sngnn_agg_forward_rows": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -70,6 +73,8 @@ SIGNATURES = {
     "sngnn_head_nll": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "sngnn_head_nll2": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "sngnn_linear_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sngnn_linear_forward_masked": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _f32, _vp, _vp]),
+    "sngnn_epilogue_backward": (_i32, [_vp, _vp, _f32, _i64, _vp, _vp]),
     "sngnn_linear_normalized_supported": (_i32, [_i64, _i32, _i32]),
     "sngnn_linear_forward_normalized": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_linear_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32]),
@@ -80,6 +85,14 @@ SIGNATURES = {
     "sngnn_segment_mean": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "sngnn_sparse_pair_dot": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
 }
+
+
+
+class Epilogue(C.Structure):
+    """``sngnn_epilogue_t`` (include/sngnn_hip.h)."""
+    _fields_ = [("bias", C.c_void_p), ("keep", C.c_void_p), ("keep_scale", C.c_float), ("relu", C.c_int),
+                ("seed", C.c_void_p), ("p", C.c_float)]
+
 
 _lib = None
 

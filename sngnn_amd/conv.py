@@ -71,7 +71,7 @@ def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remov
     return shard.graph, shard
 
 
-def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None):
+def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None, act_in=None):
     """``h = lin(x)`` with the channel count rounded up to a multiple of 4 by zero
     weights (returns h, the true width and the rank's feature table or None).  Rows of 4k
     floats are 16-byte aligned, so the kernels read them with 16-byte lane loads (2.5x faster
@@ -86,10 +86,11 @@ def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32):
             return lin(x), c, None
         # ``unit`` (single GPU): F.normalize of h from the same launch, for the aggregation that follows
-        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None, unit if shard is None else None), c, None
+        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None, unit if shard is None else None,
+                                 act_in if shard is None else None), c, None
     table = sn_dist.new_table(shard.plan, pad or c, x)
     head = table[:shard.plan.n_local]
-    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head), None), c, table
+    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head), None, None), c, table
 
 
 def _unit_for(lin: nn.Linear, graph, top_k, thr) -> "ops.UnitRows":
@@ -105,6 +106,15 @@ def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
     still an autograd node whose backward zero-fills a [N, C] tensor and copies the gradient
     into it (two passes over 27-43 MB per layer at arxiv size for nothing)."""
     return out if out.size(1) == c else out[:, :c]
+
+
+def _fuse_epilogue(epilogue, h: torch.Tensor, c: int, shard) -> bool:
+    """Whether this layer's output takes the fused store epilogue (ops.HiddenEpilogue): one GPU,
+    no channel padding (the bias and the keep mask are [.., C] of the layer's own width)."""
+    ok = epilogue is not None and shard is None and h.is_cuda and h.size(1) == c and c % 4 == 0
+    if epilogue is not None:
+        epilogue.applied = ok
+    return ok
 
 
 def _aggregate(h: torch.Tensor, graph, shard, top_k, thr: float, table=None, unit=None) -> torch.Tensor:
@@ -138,10 +148,15 @@ class SNConv(nn.Module):
         if self.bias is not None:        # PyG inits.zeros(None) is a no-op
             self.bias.data.fill_(0)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, epilogue=None, act_in=None):
+        """``epilogue`` / ``act_in`` (both optional, the model wrappers' business): fuse the relu +
+        dropout that follow this layer into its stores / tell ``lin`` that ``x`` is such an output
+        (ops.HiddenEpilogue).  ``epilogue.applied`` says whether the layer did."""
         graph, shard = _graph_for(x, edge_index, True, False)
         # (no selection: the aggregation scores straight from h - no unit rows wanted from lin)
-        h, c, table = _lin_aligned(x, self.lin, shard)
+        h, c, table = _lin_aligned(x, self.lin, shard, None, act_in)
+        if _fuse_epilogue(epilogue, h, c, shard):
+            return ops.aggregate(h, graph, None, 0.0, None, epilogue, self.bias)
         out = _true_width(_aggregate(h, graph, shard, None, 0.0, table), c)
         if self.bias is not None:
             out = out + self.bias
@@ -197,10 +212,13 @@ class SNConv_plus(nn.Module):
         if self.bias is not None:
             self.bias.data.fill_(0)
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, epilogue=None, act_in=None):
+        """``epilogue`` / ``act_in``: see SNConv.forward."""
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         unit = _unit_for(self.lin, graph, self.top_k, self.thr)
-        h, c, table = _lin_aligned(x, self.lin, shard, unit)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        if _fuse_epilogue(epilogue, h, c, shard):
+            return ops.aggregate(h, graph, int(self.top_k), float(self.thr), unit, epilogue, self.bias)
         out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)
         if self.bias is not None:
             out = out + self.bias
@@ -353,7 +371,11 @@ class SNConv_plus_plus(nn.Module):
             self._src_min_cache = hit
         return hit[1]
 
-    def forward(self, x, edge_index):
+    def forward(self, x, edge_index, epilogue=None, act_in=None):
+        """``act_in``: see SNConv.forward.  ``epilogue`` is not taken here (the blend is the last
+        kernel of this layer): ``epilogue.applied`` stays False and the wrapper runs relu / dropout."""
+        if epilogue is not None:
+            epilogue.applied = False
         part = sn_dist.current_partition()
         if part is None and x.size(0) != self.num_nodes:
             raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
@@ -362,7 +384,7 @@ class SNConv_plus_plus(nn.Module):
             raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         unit = _unit_for(self.lin, graph, self.top_k, self.thr)
-        h, c, table = _lin_aligned(x, self.lin, shard, unit)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:

@@ -153,7 +153,7 @@ extern "C" int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *
 static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const float *n, const float *nrm,
                               const void *filt, int C, int top_k, float thr, float *out, float *wsel, float *inv_norm,
                               int32_t *sel_src, float *sel_w, void *scratch, hipEvent_t *ev, hipStream_t st,
-                              const uint8_t *row_flag = nullptr, int row_want = 0)
+                              const uint8_t *row_flag = nullptr, int row_want = 0, const sngnn_epilogue_t *epi = nullptr)
 {
     if (top_k > (1 << 20)) top_k = 1 << 20;     // more than any row can use
 
@@ -174,6 +174,14 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.delta = (float)(4 * C + 32) * 5.9604644775390625e-8f;
     a.role_mask = g_role_mask;
     a.row_flag = row_flag; a.row_want = row_want;
+    a.epi_flags = 0; a.epi_bias = nullptr; a.epi_keep = nullptr; a.epi_seed = nullptr; a.epi_p = 0.f; a.epi_scale = 1.0f;
+    if (epi) {
+        a.epi_bias = epi->bias; a.epi_keep = epi->keep;
+        a.epi_seed = (const unsigned long long *)epi->seed; a.epi_p = epi->p;
+        const bool drops = epi->keep != nullptr || epi->seed != nullptr;
+        a.epi_scale = drops ? epi->keep_scale : 1.0f;
+        a.epi_flags = (epi->relu ? 1 : 0) | (epi->bias ? 2 : 0) | (epi->keep ? 4 : (epi->seed ? 8 : 0));
+    }
     // row order: calls that stream the small rows (deg <= SMALL_T <= top_k, or no top_k) take the
     // bucket order, calls that rank inside them the exact degree order (graph.hip 5b)
     const bool stream_small = top_k < 0 || top_k >= SMALL_T;
@@ -203,6 +211,10 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
                                   : (top_k < 0 ? g->rows_gt((int64_t)16 * CHUNK) : 0);
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
+    if (a.epi_flags != 0) {
+        SN_REQUIRE(cfg.vec == 4, SNGNN_EINVAL, "the store epilogue needs C % 4 == 0 (16-byte rows)");
+        return launch_agg_fwd_epi_v4(cfg, a, max_split, ev, st);
+    }
     switch (cfg.vec) {
     case 1: return launch_agg_fwd_v1(cfg, a, max_split, ev, st);
     case 2: return launch_agg_fwd_v2(cfg, a, max_split, ev, st);
@@ -243,9 +255,9 @@ static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
     return g_filter_mode == 2 || thr >= 0.25f || top_k <= 8;
 }
 
-extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
-                                 float thr, float *out, float *wsel, float *inv_norm,
-                                 int32_t *sel_src, float *sel_w, void *workspace, void *stream)
+static int agg_forward_impl(const sngnn_graph_t *g, const float *h, int C, int top_k,
+                            float thr, float *out, float *wsel, float *inv_norm,
+                            int32_t *sel_src, float *sel_w, void *workspace, void *stream, const sngnn_epilogue_t *epi)
 {
     RowCfg cfg;
     if (int rc = check_forward_args(g, h, C, top_k, out, sel_src, sel_w, cfg)) return rc;
@@ -260,7 +272,7 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
             SN_HIP(hipEventRecord(ev0[0], st));
         }
         return forward_normalized(g, cfg, h, nullptr, nullptr, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w,
-                                  scratch0, ev0 ? ev0 + 1 : nullptr, st);
+                                  scratch0, ev0 ? ev0 + 1 : nullptr, st, nullptr, 0, epi);
     }
     // table mode (sngnn_tuning_set(2, 1)): the normalisation pass first.
     // workspace: unit rows [Ntot, C] | norms [Ntot] | fp16 filter rows | scratch of the split rows
@@ -273,13 +285,37 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     for (int rep = 0; rep < (ev ? g_prof_reps : 1); ++rep)
         if (int rc = normalize_dispatch(cfg, h, g->Ntot, C, n, nrm, filt, st)) return rc;
     return forward_normalized(g, cfg, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
-                              ev ? ev + 1 : nullptr, st);
+                              ev ? ev + 1 : nullptr, st, nullptr, 0, epi);
 }
 
-extern "C" int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const float *nrm,
-                                          const void *filt, int C, int top_k, float thr, float *out, float *wsel,
-                                          float *inv_norm, int32_t *sel_src, float *sel_w, void *workspace,
-                                          void *stream)
+extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, int top_k,
+                                 float thr, float *out, float *wsel, float *inv_norm,
+                                 int32_t *sel_src, float *sel_w, void *workspace, void *stream)
+{
+    return agg_forward_impl(g, h, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, workspace, stream, nullptr);
+}
+
+static int check_epilogue(const sngnn_epilogue_t *epi)
+{
+    SN_REQUIRE(epi != nullptr, SNGNN_EINVAL, "epilogue is NULL");
+    SN_REQUIRE((epi->keep == nullptr && epi->seed == nullptr) || (epi->keep_scale > 0.f && epi->keep_scale < 1e30f),
+               SNGNN_EINVAL, "keep_scale must be a positive finite number (1 / (1 - p))");
+    SN_REQUIRE(epi->seed == nullptr || (epi->p >= 0.f && epi->p < 1.f), SNGNN_EINVAL, "p must be in [0, 1)");
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_agg_forward_epilogue(const sngnn_graph_t *g, const float *h, int C, int top_k, float thr,
+                                          const sngnn_epilogue_t *epi, float *out, float *wsel, float *inv_norm,
+                                          void *workspace, void *stream)
+{
+    if (int rc = check_epilogue(epi)) return rc;
+    return agg_forward_impl(g, h, C, top_k, thr, out, wsel, inv_norm, nullptr, nullptr, workspace, stream, epi);
+}
+
+static int agg_forward_prepared_impl(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                     const void *filt, int C, int top_k, float thr, float *out, float *wsel,
+                                     float *inv_norm, int32_t *sel_src, float *sel_w, void *workspace,
+                                     void *stream, const sngnn_epilogue_t *epi)
 {
     RowCfg cfg;
     if (int rc = check_forward_args(g, n, C, top_k, out, sel_src, sel_w, cfg)) return rc;
@@ -305,7 +341,26 @@ extern "C" int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n
         }
     }
     return forward_normalized(g, cfg, n, nrm, f, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, scratch,
-                              ev ? ev + 1 : nullptr, st);
+                              ev ? ev + 1 : nullptr, st, nullptr, 0, epi);
+}
+
+extern "C" int sngnn_agg_forward_prepared(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                          const void *filt, int C, int top_k, float thr, float *out, float *wsel,
+                                          float *inv_norm, int32_t *sel_src, float *sel_w, void *workspace,
+                                          void *stream)
+{
+    return agg_forward_prepared_impl(g, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, workspace,
+                                     stream, nullptr);
+}
+
+extern "C" int sngnn_agg_forward_prepared_epilogue(const sngnn_graph_t *g, const float *n, const float *nrm,
+                                                   const void *filt, int C, int top_k, float thr,
+                                                   const sngnn_epilogue_t *epi, float *out, float *wsel,
+                                                   float *inv_norm, void *workspace, void *stream)
+{
+    if (int rc = check_epilogue(epi)) return rc;
+    return agg_forward_prepared_impl(g, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, nullptr, nullptr, workspace,
+                                     stream, epi);
 }
 
 extern "C" int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *nrm, const void *filt,

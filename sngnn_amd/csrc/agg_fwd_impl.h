@@ -81,7 +81,57 @@ struct FwdArgs {
     const uint8_t *row_flag;
     int row_want;
     __device__ __forceinline__ bool skip_row(int i) const { return row_flag != nullptr && row_flag[i] != row_want; }
+    // store epilogue of a hidden layer (models.py:204-209: conv -> [+ bias] -> relu_ -> dropout), applied to
+    // the finished mean row on its way out: out = keep ? max(mean + bias, 0) * scale : 0.
+    // epi_flags: bit 0 relu, bit 1 bias, bit 2 keep mask; 0 = none (sngnn_agg_forward_epilogue).
+    // epi_flags: bit 0 relu, bit 1 bias, bit 2 keep mask given, bit 3 keep mask drawn here; 0 = none.
+    int epi_flags;
+    const float *epi_bias;          // [C]
+    const uint8_t *epi_keep;        // [N, C] 1 = kept (the caller's own Bernoulli(1 - p) draw), or
+    const unsigned long long *epi_seed;   // dev [1]: the mask is drawn here, keep = u(seed, i C + c) >= p
+    float epi_p;
+    float epi_scale;                // 1 / (1 - p) when something is dropped, else 1
+    // counter-based uniform in [0, 1): two rounds of a 32-bit avalanche hash over (seed, element index) -
+    // the same element of the same call gets the same draw in every kernel that asks (main, finalize)
+    static __device__ __forceinline__ unsigned mix32(unsigned x)
+    {
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        return x;
+    }
+    __device__ __forceinline__ bool drawn_keep(int i, int c) const
+    {
+        const unsigned long long s = *epi_seed, idx = (unsigned long long)i * (unsigned)C + (unsigned)c;
+        // (the seed is hashed first: consecutive seeds must not give masks that are each other's
+        // pairwise swaps, which idx ^ seed alone would)
+        const unsigned k1 = mix32((unsigned)s * 0x9E3779B9u + (unsigned)(s >> 32)), k2 = mix32(k1 ^ 0x85EBCA6Bu);
+        unsigned hsh = mix32((unsigned)idx + k1);
+        hsh = mix32((hsh ^ k2) + 0x9E3779B9u * (unsigned)(idx >> 32));
+        return (float)(hsh >> 8) * 5.9604644775390625e-8f >= epi_p;
+    }
+    __device__ __forceinline__ float epilogue(float v, int i, int c) const
+    {
+        if (epi_flags & 2) v += epi_bias[c];
+        if (epi_flags & 1) v = fmaxf(v, 0.f);
+        if (epi_flags & 4) v = epi_keep[(size_t)i * C + c] ? v * epi_scale : 0.f;
+        if (epi_flags & 8) v = drawn_keep(i, c) ? v * epi_scale : 0.f;
+        return v;
+    }
 };
+
+// the same on a row held by a lane group (channels beyond C: untouched, never stored)
+template <int VEC, int G, int R>
+__device__ __forceinline__ void row_epilogue(const FwdArgs &a, Row<VEC, G, R> &acc, int i, int lg)
+{
+    if (a.epi_flags == 0) return;                         // (uniform)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int c0 = (r * G + lg) * VEC;
+        if (c0 < a.C) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc.x[r][v] = a.epilogue(acc.x[r][v], i, c0 + v);
+        }
+    }
+}
 
 #ifndef SNGNN_FWD_WAVES
 #define SNGNN_FWD_WAVES 6
@@ -295,7 +345,7 @@ __device__ __forceinline__ WaveSel wave_select(const float *sc, int n, int base,
 // ---------------------------------------------------------------------------
 // One set of 64/G small rows (one per lane group) whose column ids are already in
 // LDS (s_col[gid][t]).  d = this group's row descriptor (deg 0 for a padding slot).
-template <int VEC, int G, int R, bool OTF>
+template <int VEC, int G, int R, bool OTF, bool EPI>
 __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, bool valid,
                                                int *lds_wave, const int *s_col_set)
 {
@@ -440,6 +490,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
     }
     if (valid) {
         acc.div((float)max(deg, 1));
+        if constexpr (EPI) row_epilogue<VEC, G, R>(a, acc, i, lg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
 }
@@ -450,7 +501,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 // current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool OTF>
+template <int VEC, int G, int R, bool OTF, bool EPI>
 __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
@@ -503,7 +554,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
         if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull)
-            small_rows_set<VEC, G, R, OTF>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+            small_rows_set<VEC, G, R, OTF, EPI>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
         store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
@@ -727,7 +778,7 @@ __device__ __forceinline__ WaveSel banded_select(const FwdArgs &a, const Row<VEC
 // ---------------------------------------------------------------------------
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool FILT, bool OTF>
+template <int VEC, int G, int R, bool FILT, bool OTF, bool EPI>
 __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -828,6 +879,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     acc.reduce_across_groups();
     if (gid == 0) {
         acc.div((float)deg);
+        if constexpr (EPI) row_epilogue<VEC, G, R>(a, acc, i, lg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
     // (stored at the END of the row: a store up front would pin the scoring pass's first
@@ -911,7 +963,10 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // Persistent waves: wave w of the grid takes work items w, w + n_waves, ... of the
 // list [split-row tasks | wave rows | small-row sets], each class in order of
 // descending degree, so every wave gets a similar mix and the grid drains evenly.
-template <int VEC, int G, int R, bool FILT, bool OTF>
+// EPI: the hidden-layer store epilogue (FwdArgs::epilogue) compiled into the row stores - its own
+// instantiation, so the plain forward keeps its register allocation (a runtime flag cost the
+// filter variant two spilled registers and 2 us)
+template <int VEC, int G, int R, bool FILT, bool OTF, bool EPI = false>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
     static_assert(!(FILT && OTF), "the filter belongs to the table mode");
@@ -925,11 +980,11 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
         if (a.role_mask & 1) role_task<VEC, G, R, FILT, OTF>(a, a.task_order[it], lw);
     it -= a.n_tasks;
     for (; it < n_wave_rows; it += nw)
-        if (a.role_mask & 2) role_wave<VEC, G, R, FILT, OTF>(a, it, lw);
+        if (a.role_mask & 2) role_wave<VEC, G, R, FILT, OTF, EPI>(a, it, lw);
     it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    if (a.role_mask & 4) role_small<VEC, G, R, OTF>(a, it, nw, nsets, lw);
+    if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -987,7 +1042,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
         for (int c = tid; c < a.C; c += FIN_BLOCK) {
             float s = 0.f;
             for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-            a.out[(size_t)i * a.C + c] = s / (float)deg;
+            a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
         return;
     }
@@ -1074,14 +1129,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
         for (int ch = tid; ch < a.C; ch += FIN_BLOCK) {
             float s = 0.f;
             for (int w = 0; w < NW; ++w) s += s_part[(size_t)w * a.C + ch];
-            a.out[(size_t)i * a.C + ch] = s / (float)deg;
+            a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
         }
     } else {
         // emit on a streaming row: the sum itself still comes from the partials
         for (int ch = tid; ch < a.C; ch += FIN_BLOCK) {
             float s = 0.f;
             for (int t = t0; t < t1; ++t) s += a.partial[(size_t)t * a.C + ch];
-            a.out[(size_t)i * a.C + ch] = s / (float)deg;
+            a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
         }
     }
 }
@@ -1135,7 +1190,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         for (int c = tid; c < a.C; c += FINC_BLOCK) {
             float s = 0.f;
             for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + c];
-            a.out[(size_t)i * a.C + c] = s / (float)deg;
+            a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
         if (emit) {
             // selection of a streaming split row: every edge >= thr, ranked.  Rare
@@ -1233,7 +1288,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     for (int ch = tid; ch < a.C; ch += FINC_BLOCK) {
         float s = 0.f;
         for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
-        a.out[(size_t)i * a.C + ch] = s / (float)deg;
+        a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
     }
 }
 
@@ -1270,7 +1325,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += v[u];
             for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-            a.out[(size_t)i * a.C + c] = s / (float)deg;
+            a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
         return;
     }
@@ -1320,6 +1375,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     }
     acc.reduce_across_groups();
     acc.div((float)deg);
+    row_epilogue<VEC, G, R>(a, acc, i, lg);
     if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
 }
 
@@ -1418,8 +1474,8 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 // between its two events, so the event pair's own cost is spread over reps launches
 extern int g_prof_reps;
 
-template <int VEC, int G, int R>
-int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+template <int VEC, int G, int R, bool EPI>
+int launch_agg_fwd_impl(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
     const int reps = ev ? std::max(g_prof_reps, 1) : 1;
     constexpr int RPW = 64 / G;
@@ -1430,12 +1486,12 @@ int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStrea
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     for (int rep = 0; rep < reps && grid > 0; ++rep) {
         if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
-            k_agg_fwd<VEC, G, R, false, true><<<grid, BLOCK, 0, st>>>(a);
+            k_agg_fwd<VEC, G, R, false, true, EPI><<<grid, BLOCK, 0, st>>>(a);
         } else if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
-            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false><<<grid, BLOCK, 0, st>>>(a);
-            else k_agg_fwd<VEC, G, R, false, false><<<grid, BLOCK, 0, st>>>(a);
+            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false, EPI><<<grid, BLOCK, 0, st>>>(a);
+            else k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
         } else {
-            k_agg_fwd<VEC, G, R, false, false><<<grid, BLOCK, 0, st>>>(a);
+            k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
         }
     }
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
@@ -1449,7 +1505,20 @@ int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStrea
     return SNGNN_OK;
 }
 
+template <int VEC, int G, int R>
+int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+{
+    return launch_agg_fwd_impl<VEC, G, R, false>(a, max_split_deg, ev, st);
+}
+template <int VEC, int G, int R>
+int launch_agg_fwd_epi(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+{
+    return launch_agg_fwd_impl<VEC, G, R, true>(a, max_split_deg, ev, st);
+}
+
 // one translation unit per VEC instantiates these
+int launch_agg_fwd_epi_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
+                          hipStream_t st);      // (the store epilogue: 16-byte rows only)
 int launch_agg_fwd_v1(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,
                       hipStream_t st);
 int launch_agg_fwd_v2(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,

@@ -111,3 +111,38 @@ extern "C" int sngnn_blend_backward(const float *grad_out, const float *out0, co
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Backward of a hidden layer's store epilogue (sngnn_agg_forward_epilogue) when the consumer of
+// the activated tensor did not fold it into its own store (sngnn_linear_forward_masked):
+// g_pre = act > 0 ? g * scale : 0 - autograd's threshold_backward and dropout backward
+// (models.py:206-209) in one pass.
+// ---------------------------------------------------------------------------
+namespace sngnn {
+__global__ __launch_bounds__(256) void k_mask_grad(const float *__restrict__ g, const float *__restrict__ act, float scale,
+                                                   int64_t n4, int64_t n, float *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 d = reinterpret_cast<const float4 *>(g)[i], a = reinterpret_cast<const float4 *>(act)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(a.x > 0.f ? d.x * scale : 0.f, a.y > 0.f ? d.y * scale : 0.f,
+                                                          a.z > 0.f ? d.z * scale : 0.f, a.w > 0.f ? d.w * scale : 0.f);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        out[i] = act[i] > 0.f ? g[i] * scale : 0.f;
+}
+}  // namespace sngnn
+
+extern "C" int sngnn_epilogue_backward(const float *grad, const float *act, float scale, int64_t n, float *grad_pre,
+                                       void *stream)
+{
+    SN_REQUIRE(n >= 0, SNGNN_EINVAL, "negative size");
+    if (n == 0) return SNGNN_OK;
+    SN_REQUIRE(grad && act && grad_pre, SNGNN_EINVAL, "NULL argument");
+    const bool al = ((uintptr_t)grad % 16 == 0) && ((uintptr_t)act % 16 == 0) && ((uintptr_t)grad_pre % 16 == 0);
+    const int64_t n4 = al ? n / 4 : 0;
+    const int grid = (int)std::min<int64_t>((std::max<int64_t>(n4, 1) + 255) / 256, 2048);
+    sngnn::k_mask_grad<<<grid, 256, 0, (hipStream_t)stream>>>(grad, act, scale, n4, n, grad_pre);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}

@@ -29,10 +29,15 @@ __device__ __forceinline__ void wave_barrier_lds()
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int LF_M = 128, LF_K = 32, LF_LD = LF_K + 1;
 
-template <int NT>      // NT 32-column tiles of the output (C <= 32 NT)
+// act != NULL (sngnn_linear_forward_masked): the result leaves through the mask of an activated
+// tensor of its own shape, h = act > 0 ? (x W^T + b) * act_scale : 0 - the input gradient of a
+// layer whose input was relu (+ inverted dropout) of something: the two elementwise backward
+// passes of models.py:206-209 folded into the store that produces their operand.
+template <int NT, bool MASK = false>      // NT 32-column tiles of the output (C <= 32 NT)
 __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ b, int64_t N, int F, int C,
-                                                    float *__restrict__ h)
+                                                    float *__restrict__ h, const float *__restrict__ act = nullptr,
+                                                    float act_scale = 1.0f)
 {
     __shared__ float sx[LF_M * LF_LD];
     __shared__ float sw[NT * 32 * LF_LD];
@@ -44,6 +49,19 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // MASK: the mask values of this lane's outputs, requested before anything else (unconditional,
+    // clamped addresses): they travel while the panels stream.  (Loaded in the epilogue they were a
+    // burst behind the last multiply of every workgroup at once: 55.6 us against 32.9 us unmasked.)
+    float av[MASK ? NT : 1][16];
+    if constexpr (MASK) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t rr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                av[t][r] = act[min(rr, N - 1) * C + min(t * 32 + (lane & 31), C - 1)];
+            }
+    }
     const int sc = tid & 31, sr = tid >> 5;             // staging: column sc of rows sr + 8 u
     float rx[LF_M / 8], rw[NT * 4];
     auto fetch = [&](int k0) {
@@ -87,7 +105,9 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float *__restrict__ x,
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t rr = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (rr < N && c < C) h[rr * C + c] = acc[t][r] + bias;
+            float v = acc[t][r] + bias;
+            if constexpr (MASK) v = av[t][r] > 0.f ? v * act_scale : 0.f;
+            if (rr < N && c < C) h[rr * C + c] = v;
         }
     }
 }
@@ -727,6 +747,21 @@ extern "C" int sngnn_linear_forward(const float *x, const float *weight, const f
     const unsigned grid = (unsigned)((N + LF_M - 1) / LF_M);
     if (C <= 32) k_linear_fwd<1><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h);
     else k_linear_fwd<2><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_linear_forward_masked(const float *x, const float *weight, const float *bias, int64_t N,
+                                           int F, int C, const float *act, float act_scale, float *h, void *stream)
+{
+    SN_REQUIRE(N >= 0 && F >= 1 && C >= 1, SNGNN_EINVAL, "bad shape");
+    SN_REQUIRE(C <= 64, SNGNN_EINVAL, "sngnn_linear_forward_masked handles C <= 64");
+    if (N == 0) return SNGNN_OK;
+    SN_REQUIRE(x && weight && h && act, SNGNN_EINVAL, "NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((N + LF_M - 1) / LF_M);
+    if (C <= 32) k_linear_fwd<1, true><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h, act, act_scale);
+    else k_linear_fwd<2, true><<<grid, 256, 0, st>>>(x, weight, bias, N, F, C, h, act, act_scale);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }

@@ -4,12 +4,20 @@ signatures, ``state_dict`` keys and ``forward(data)`` contract, so the model
 construction at train.py:305-315 works unchanged."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import dist as sn_dist
+from . import ops
 from .conv import AGNNConv, SNConv, SNConv_plus, SNConv_plus_plus
+
+
+# A/B switch of the fused hidden-layer epilogue (_Stack.forward_logits; tests flip it, SNGNN_FUSE_HIDDEN=0
+# starts a process with it off)
+FUSE_HIDDEN = os.environ.get("SNGNN_FUSE_HIDDEN", "1") != "0"
 
 
 class _Stack(nn.Module):
@@ -24,18 +32,50 @@ class _Stack(nn.Module):
         """Everything before the final ``log_softmax`` (lets a trainer fuse the
         classification head, sngnn_amd/train.py:GraphedEpoch)."""
         x, edge_index = data.x, data.edge_index
+        # relu + dropout between two conv layers as the store epilogue of the aggregation that
+        # produces their operand, and backward as the store epilogue of the next ``lin``'s input
+        # gradient (ops.HiddenEpilogue) - without batch norm in between, on one GPU, for the layers
+        # that take it (SNConv, SNConv_plus); everything else runs the reference's op sequence
+        fusable = (FUSE_HIDDEN and not self.bn and sn_dist.current_partition() is None and x.is_cuda
+                   and isinstance(self.lins[0], (SNConv, SNConv_plus, SNConv_plus_plus)))
+        act = None
+        seeds = self._dropout_seeds(x.device) if (fusable and len(self.lins) > 1 and self.training
+                                                   and self.dropout.p > 0.0) else None
         for i, lin in enumerate(self.lins[:-1]):
-            x = lin(x, edge_index)
+            if fusable:
+                epi = ops.HiddenEpilogue(True, self.dropout.p, self.training, None if seeds is None else seeds[i:i + 1])
+                x = lin(x, edge_index, epi, act)
+                if epi.applied:
+                    act = epi
+                    continue
+                act = None
+            else:
+                x = lin(x, edge_index)
             x = F.relu(x, inplace=True)
             if self.bn:
                 part = sn_dist.current_partition()
                 # batch statistics over every rank's rows, as the single-process batch has them
                 x = self.bns[i](x) if part is None else sn_dist.sync_batch_norm(self.bns[i], x, part)
             x = self.dropout(x)
+        if fusable and act is not None:
+            return self.lins[-1](x, edge_index, None, act)
         return self.lins[-1](x, edge_index)
 
     def forward(self, data):
         return F.log_softmax(self.forward_logits(data), dim=1)
+
+    def _dropout_seeds(self, device):
+        """One counter per hidden layer for the in-kernel dropout draw (ops.HiddenEpilogue): started
+        from torch's CPU generator (so ``torch.manual_seed`` makes a run reproducible) and advanced on
+        the device once per training forward - inside a captured epoch too, where every replay must
+        drop differently."""
+        s = getattr(self, "_drop_seed", None)
+        if s is None or s.device != device or s.numel() != len(self.lins) - 1:
+            s = torch.randint(0, 2 ** 62, (len(self.lins) - 1,), dtype=torch.int64).to(device)
+            self._drop_seed = s
+        else:
+            s.add_(1)
+        return s
 
     def _build(self, conv, in_channels, hidden_channels, out_channels, num_layers):
         self.lins = nn.ModuleList()

@@ -181,14 +181,51 @@ def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
     return grad_h
 
 
+class HiddenEpilogue:
+    """What follows a hidden conv layer in the reference's wrappers (models.py:204-209, 79-84,
+    296-301) - the conv's bias add, ``F.relu(x, inplace=True)`` and ``self.dropout(x)`` - as the
+    aggregation's STORE epilogue (``sngnn_agg_forward_epilogue``) instead of three more passes over
+    [N, C], and, backward, as the epilogue of the store that produces the gradient of the
+    activated tensor (``sngnn_linear_forward_masked``: the next layer's ``lin`` input gradient)
+    instead of threshold_backward + the dropout backward.
+
+    ``p`` / ``training``: the wrapper's Dropout.  ``applied``: set by the conv layer when its shape
+    took the fused store (the caller falls back to the plain elementwise ops otherwise).
+    ``premasked``: set by the consumer's backward when it has already applied the mask to the
+    gradient it returns for the activated tensor - the contract between ``_Linear.backward`` and
+    ``_Aggregate.backward``, valid because the wrapper hands the activated tensor to exactly one
+    consumer (the next conv's ``lin``; models.py:205 -> :237)."""
+
+    def __init__(self, relu: bool = True, p: float = 0.0, training: bool = False, seed: Optional[torch.Tensor] = None):
+        """``seed``: int64 [1] device tensor - the dropout mask is then drawn inside the kernel from
+        (seed, element index) by a counter-based hash: no mask tensor, no extra launch; the owner
+        advances the seed between forwards (models._Stack does, on the device: graph-capture
+        safe).  Without it the mask is torch's own Bernoulli draw, handed to the kernel."""
+        self.relu, self.p, self.training = bool(relu), float(p), bool(training)
+        self.seed = seed
+        self.applied = False
+        self.premasked = False
+        self.scale = 1.0
+
+    @property
+    def drops(self) -> bool:
+        return self.training and self.p > 0.0
+
+
 class _Aggregate(torch.autograd.Function):
     """autograd seam of the fused aggregation.  The output is freshly allocated
-    and not saved, so the models' in-place ReLU on it is safe (models.py:81,206,298)."""
+    and not saved, so the models' in-place ReLU on it is safe (models.py:81,206,298).
+    With ``epi`` (a HiddenEpilogue) the stored rows are already bias-added / rectified /
+    dropped out; the output is then saved, as the mask its own backward needs."""
 
     @staticmethod
-    def forward(ctx, h, graph, top_k, thr, unit=None):
+    def forward(ctx, h, graph, top_k, thr, unit=None, epi=None, bias=None):
         need_grad = ctx.needs_input_grad[0]
-        if unit is not None and unit.n is not None:
+        ctx.epi = epi
+        if epi is not None:
+            out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, epi, bias)
+            ctx.bias_grad = bias is not None and ctx.needs_input_grad[6]
+        elif unit is not None and unit.n is not None:
             # the producer of h (``lin``'s epilogue) already wrote F.normalize(h): no pass over h
             out, wsel = _forward_prepared(graph, unit, top_k, thr, need_grad)
         else:
@@ -196,14 +233,33 @@ class _Aggregate(torch.autograd.Function):
                                                    save_for_backward=need_grad)
         if need_grad:
             ctx.graph, ctx.top_k = graph, top_k
-            ctx.save_for_backward(h, wsel)
+            if epi is not None:
+                ctx.save_for_backward(h, wsel, out)
+            else:
+                ctx.save_for_backward(h, wsel)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        h, wsel = ctx.saved_tensors
+        epi = ctx.epi
+        grad_bias = None
+        if epi is None:
+            h, wsel = ctx.saved_tensors
+        else:
+            h, wsel, out = ctx.saved_tensors
+            if epi.premasked:          # the consumer's store already applied relu' and the dropout mask
+                epi.premasked = False
+            else:
+                g = grad_out.contiguous()
+                grad_out = torch.empty_like(g)
+                with torch.cuda.device(g.device):
+                    rc = _lib.load().sngnn_epilogue_backward(g.data_ptr(), out.data_ptr(), float(epi.scale), g.numel(),
+                                                             grad_out.data_ptr(), _stream(g.device))
+                _lib.check(rc, "sngnn_epilogue_backward")
+            if ctx.bias_grad:
+                grad_bias = grad_out.sum(dim=0)
         grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
-        return grad_h, None, None, None, None
+        return grad_h, None, None, None, None, None, grad_bias
 
 
 class UnitRows:
@@ -236,12 +292,58 @@ def _forward_prepared(graph: Graph, unit: "UnitRows", top_k, thr, need_grad):
     return out, wsel
 
 
+def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: "HiddenEpilogue", bias):
+    """``sngnn_agg_forward_epilogue`` / ``_prepared_epilogue``: the forward whose stores apply
+    bias + relu + dropout.  Draws the keep mask (the caller's Bernoulli(1 - p), torch's generator:
+    graph-capture safe) when the epilogue drops."""
+    lib = _lib.load()
+    h = _check_rows(h, graph.num_total_nodes, "h")
+    n, c = graph.num_nodes, h.size(1)
+    k = -1 if top_k is None else int(top_k)
+    out = torch.empty((n, c), dtype=torch.float32, device=h.device)
+    wsel = inv = keep = None
+    if need_grad:
+        wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=h.device)
+        inv = torch.empty(n, dtype=torch.float32, device=h.device)
+    epi.scale = 1.0
+    seed = None
+    if epi.drops:
+        epi.scale = 1.0 / (1.0 - epi.p)
+        if epi.seed is not None:
+            if epi.seed.dtype != torch.int64 or epi.seed.numel() != 1 or epi.seed.device != h.device:
+                raise ValueError("seed must be an int64 tensor of one element on h's device")
+            seed = epi.seed
+        else:
+            keep = torch.empty((n, c), dtype=torch.uint8, device=h.device).bernoulli_(1.0 - epi.p)
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != c or bias.device != h.device:
+            raise ValueError("bias must be a float32 tensor of C elements on h's device")
+        bias = bias.detach().contiguous()
+    st = _lib.Epilogue(_lib.ptr(bias), _lib.ptr(keep), float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p))
+    ws = graph.workspace(c)
+    import ctypes
+    with torch.cuda.device(h.device):
+        if unit is not None and unit.n is not None:
+            rc = lib.sngnn_agg_forward_prepared_epilogue(graph.handle, unit.n.data_ptr(), unit.nrm.data_ptr(),
+                                                         _lib.ptr(unit.filt), c, k, float(thr), ctypes.byref(st),
+                                                         out.data_ptr(), _lib.ptr(wsel), _lib.ptr(inv), ws.data_ptr(),
+                                                         _stream(h.device))
+        else:
+            rc = lib.sngnn_agg_forward_epilogue(graph.handle, h.data_ptr(), c, k, float(thr), ctypes.byref(st),
+                                                out.data_ptr(), _lib.ptr(wsel), _lib.ptr(inv), ws.data_ptr(),
+                                                _stream(h.device))
+    _lib.check(rc, "sngnn_agg_forward_epilogue")
+    return out, wsel
+
+
 def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float,
-              unit: Optional["UnitRows"] = None) -> torch.Tensor:
+              unit: Optional["UnitRows"] = None, epilogue: Optional["HiddenEpilogue"] = None,
+              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Differentiable fused aggregation: [N_total, C] -> [N, C] (N_total == N unless
     ``graph`` is a node-range partition).  ``unit``: F.normalize(h) as left by ``lin``'s
-    epilogue (``UnitRows``) - the normalisation pass is skipped then."""
-    return _Aggregate.apply(h, graph, top_k, thr, unit)
+    epilogue (``UnitRows``) - the normalisation pass is skipped then.  ``epilogue`` (+ ``bias``):
+    the hidden layer's bias / relu / dropout applied by the forward's stores (``HiddenEpilogue``)."""
+    return _Aggregate.apply(h, graph, top_k, thr, unit, epilogue, bias if epilogue is not None else None)
 
 
 def attention_forward(graph: Graph, h: torch.Tensor, save_for_backward: bool = True):
@@ -522,7 +624,7 @@ class _Linear(torch.autograd.Function):
     handles poorly), grad_x through rocBLAS only when x needs it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad_to=None, out=None, unit=None):
+    def forward(ctx, x, weight, bias, pad_to=None, out=None, unit=None, act=None):
         """``pad_to``: produce [N, pad_to] with zero channels behind the layer's own (16-byte
         rows for the aggregation kernels).  The padded weight / bias live in two persistent
         buffers attached to the weight and are refreshed by two small copies - no
@@ -530,8 +632,12 @@ class _Linear(torch.autograd.Function):
         ``out``: ``OutBuffer`` around a contiguous [N, C] tensor to write into (the head of a rank's
         [own | halo] feature table, sngnn_amd/dist.py) - that tensor is returned as the result.
         ``unit``: a ``UnitRows`` to fill with F.normalize of the result from the same launch
-        (models.py:237-238 are adjacent lines); left empty when the shape takes the BLAS."""
+        (models.py:237-238 are adjacent lines); left empty when the shape takes the BLAS.
+        ``act``: the ``HiddenEpilogue`` whose activated output ``x`` is (the wrapper hands that
+        tensor to this layer only): the backward then applies relu' and the dropout mask inside
+        the kernel that writes grad_x (``sngnn_linear_forward_masked``) and tells the epilogue so."""
         ctx.save_for_backward(x, weight)
+        ctx.act = act if (act is not None and act.applied) else None
         ctx.has_bias = bias is not None
         n, f = x.shape
         c = weight.size(0)
@@ -591,14 +697,26 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             n, fin = g.size(0), weight.size(1)
+            act = ctx.act
             if g.is_cuda and g.size(1) == ctx.c and ctx.c <= 128 and fin <= 64 and n >= 4096:
                 # grad_x = g W is the same narrow streaming product as the forward, with W^T as the
                 # weight: 35 us against rocBLAS' 55 us at 169 343 x 40 -> 64 (gpurun_out/gx_cmp.log)
                 wt = weight.t().contiguous()
                 gx = torch.empty((n, fin), dtype=torch.float32, device=g.device)
+                # x is an activated tensor (relu + dropout of the layer before): their backward is the
+                # store epilogue of this product where the panel kernel runs it anyway (ctx.c not a
+                # row-tile width); the row-tile widths keep their faster kernel and leave the mask
+                # to the producer's backward
+                masked = act is not None and ctx.c not in (16, 32, 64, 128) and x.is_contiguous()
                 with torch.cuda.device(g.device):
-                    rc = _lib.load().sngnn_linear_forward(g.data_ptr(), wt.data_ptr(), None, n, ctx.c, fin,
-                                                          gx.data_ptr(), _stream(g.device))
+                    if masked:
+                        rc = _lib.load().sngnn_linear_forward_masked(g.data_ptr(), wt.data_ptr(), None, n, ctx.c, fin,
+                                                                     x.data_ptr(), float(act.scale), gx.data_ptr(),
+                                                                     _stream(g.device))
+                        act.premasked = True
+                    else:
+                        rc = _lib.load().sngnn_linear_forward(g.data_ptr(), wt.data_ptr(), None, n, ctx.c, fin,
+                                                              gx.data_ptr(), _stream(g.device))
                 _lib.check(rc, "sngnn_linear_forward (input gradient)")
             else:
                 gx = g[:, :ctx.c].mm(weight)         # (the padded channels carry no gradient)
@@ -616,14 +734,14 @@ class _Linear(torch.autograd.Function):
             _lib.check(rc, "sngnn_linear_wgrad")
             gw = gw[:ctx.c]
             gb = None if gb is None else gb[:ctx.c]
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
     """Apply ``lin`` with the hand-written weight gradient (fp32 GPU tensors), or
     plain ``lin(x)`` for anything else."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32:
-        return _Linear.apply(x, lin.weight, lin.bias, None, None, None)
+        return _Linear.apply(x, lin.weight, lin.bias, None, None, None, None)
     return lin(x)
 
 

@@ -298,3 +298,105 @@ def test_real_actor_published_hyperparameters(cuda):
     for k, v in model.state_dict().items():
         w = z["final." + k]
         assert np.abs(v.cpu().numpy() - w).max() <= 1e-3, k
+
+
+@pytest.mark.parametrize("kind,args", [
+    ("SNGNN_Plus", dict(hidden=64, layers=2, top_k=1, thr=0.0, rem=1, classes=40)),      # the training scripts' shape
+    ("SNGNN_Plus", dict(hidden=32, layers=3, top_k=16, thr=0.2, rem=0, classes=7)),      # 32 -> 32: row-tile gx, mask left to the producer
+    ("SNGNN", dict(hidden=24, layers=2, classes=5)),                                     # conv bias in the epilogue, no selection
+    ("SNGNN_Plus_Plus", dict(hidden=32, layers=2, top_k=4, thr=0.0, rem=1, classes=6)),  # blend last: wrapper falls back
+])
+def test_fused_hidden_epilogue_equals_the_op_sequence(cuda, kind, args):
+    """models.py:204-209's relu_ + dropout between two conv layers as the aggregation's store
+    epilogue / the next lin's input-gradient epilogue (ops.HiddenEpilogue) against the plain op
+    sequence (models.FUSE_HIDDEN = False): same log-probs and same parameter gradients BIT FOR BIT
+    without dropout (evaluation and training with p = 0); with dropout the fused forward is the op
+    sequence under the mask it drew (checked through the gradients of a replay with that mask)."""
+    import sngnn_amd
+    from sngnn_amd import models as M
+    from sngnn_amd import synth
+    n, f = 6000, 48
+    d = synth.make_dataset("actor", with_features=False)
+    ei = d.edge_index[:, (d.edge_index[0] < n) & (d.edge_index[1] < n)].to(cuda)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, f, generator=gen).to(cuda)
+    y = torch.randint(0, args["classes"], (n,), generator=gen).to(cuda)
+    data = sngnn_amd.Data(x=x, edge_index=ei, y=y)
+
+    def make():
+        torch.manual_seed(11)
+        if kind == "SNGNN":
+            m = sngnn_amd.SNGNN(f, args["hidden"], args["classes"], args["layers"])
+        elif kind == "SNGNN_Plus":
+            m = sngnn_amd.SNGNN_Plus(f, args["hidden"], args["classes"], n, args["layers"], args["top_k"], args["thr"],
+                                     args["rem"], 0.0)
+        else:
+            m = sngnn_amd.SNGNN_Plus_Plus(f, args["hidden"], args["classes"], n, args["layers"], args["top_k"],
+                                          args["thr"], 0.3, args["rem"], 0.0)
+        m = m.to(cuda)
+        with torch.no_grad():
+            for c in m.lins:
+                if getattr(c, "bias", None) is not None:
+                    c.bias.uniform_(-0.1, 0.1)          # a conv bias that matters
+        return m
+
+    def run(fuse, train, p):
+        M.FUSE_HIDDEN = fuse
+        try:
+            m = make()
+            m.dropout.p = p
+            m.train(train)
+            out = m(data)
+            grads = None
+            if train:
+                torch.nn.functional.nll_loss(out, y).backward()
+                grads = {k: v.grad.clone() for k, v in m.named_parameters()}
+            return out.detach(), grads
+        finally:
+            M.FUSE_HIDDEN = True
+
+    for train in (False, True):
+        a, ga = run(True, train, 0.0)
+        b, gb = run(False, train, 0.0)
+        assert torch.equal(a, b), (kind, train)
+        if train:
+            for k in ga:
+                assert torch.equal(ga[k], gb[k]), (kind, k, float((ga[k] - gb[k]).abs().max()))
+    # with dropout: finite, and about half of the hidden activations dropped
+    out, grads = run(True, True, 0.5)
+    assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(g).all()) for g in grads.values())
+
+
+def test_hidden_epilogue_operator_with_dropout_matches_autograd_of_its_own_mask(cuda):
+    """ops.aggregate(..., epilogue, bias) in training mode with p = 0.4: the stored rows are
+    where(keep, relu(mean + bias) / (1 - p), 0) for SOME keep mask with about 60 % ones, and the
+    gradients of h and bias are autograd's through that very expression (mask read back from the
+    output)."""
+    from sngnn_amd import ops
+    from sngnn_amd.graph import Graph
+    from tests.helpers import random_graph
+    n, c, k, thr, p = 5000, 32, 4, 0.0, 0.4
+    ei = random_graph(n, 40000, seed=9, hubs=((3, 700), (4, 200))).to(cuda)
+    g = Graph(ei, n, True, True)
+    gen = torch.Generator().manual_seed(2)
+    h = torch.randn(n, c, generator=gen).to(cuda).requires_grad_(True)
+    bias = (torch.randn(c, generator=gen) * 0.2).to(cuda).requires_grad_(True)
+    gout = torch.randn(n, c, generator=gen).to(cuda)
+    epi = ops.HiddenEpilogue(True, p, True)
+    epi.applied = True
+    x1 = ops.aggregate(h, g, k, thr, None, epi, bias)
+    x1.backward(gout)
+    gh, gb = h.grad.clone(), bias.grad.clone()
+    h.grad = bias.grad = None
+    y = ops.aggregate(h, g, k, thr) + bias                     # the plain path, differentiable
+    pos = y.detach() > 0
+    kept = x1.detach() != 0
+    assert bool((kept <= pos).all())                            # nothing kept that relu removed
+    frac = float(kept.sum()) / float(pos.sum())
+    assert 0.57 < frac < 0.63, frac
+    scale = 1.0 / (1.0 - p)
+    want = torch.where(kept, torch.relu(y) * scale, torch.zeros_like(y))
+    assert torch.equal(x1.detach(), want.detach())
+    want.backward(gout)
+    assert float((gh - h.grad).abs().max()) <= 1e-6 * float(h.grad.abs().max())
+    assert float((gb - bias.grad).abs().max()) <= 1e-5 * float(bias.grad.abs().max())

@@ -37,7 +37,7 @@ for F, C in ((128, 40), (128, 32), (32, 40), (64, 64), (16, 7)):
         if C % 4 == 0:       # the same launch with the F.normalize epilogue (unit rows + norms [+ filter rows])
             def lin_norm(filt):
                 u = ops.UnitRows(filt)
-                ops._Linear.apply(x, lin.weight, lin.bias, None, None, u)
+                ops._Linear.apply(x, lin.weight, lin.bias, None, None, u, None)
                 return u
             t_n = timed(lambda: lin_norm(False))
             t_nf = timed(lambda: lin_norm(True)) if C > 32 else float("nan")

@@ -17,5 +17,5 @@ with torch.no_grad():
     for _ in range(200):
         ops.linear(x, lin)
     for _ in range(200):
-        ops._Linear.apply(x, lin.weight, lin.bias, None, None, ops.UnitRows(False))
+        ops._Linear.apply(x, lin.weight, lin.bias, None, None, ops.UnitRows(False), None)
 torch.cuda.synchronize()
