@@ -94,3 +94,9 @@ def test_config3_actor_sngnn_plus_plus_full_size(cuda, layers):
     differ, rows = _check(cuda, "SNGNN_Plus_Plus", (f, 32, 5, n, layers, 10, 0.9, 0.0, 1, 0.0), data,
                           f"actor SNGNN_Plus_Plus {layers}-layer", train_modes=(True, False))
     assert differ <= max(2, rows // 500)
+    # the same model where the selection and BOTH branches matter: thr 0.0 keeps up to 10 edges a row
+    # (at thr 0.9 the bag-of-words rows keep ~400 of 29 940 edges) and init_beta 0.3 blends the
+    # adjacency branch in, so every parameter of both branches gets a gradient
+    differ, rows = _check(cuda, "SNGNN_Plus_Plus", (f, 32, 5, n, layers, 10, 0.0, 0.3, 1, 0.0), data,
+                          f"actor SNGNN_Plus_Plus {layers}-layer thr=0 beta=0.3", train_modes=(True, False))
+    assert differ <= (max(2, rows // 500) if layers == 1 else rows // 50)

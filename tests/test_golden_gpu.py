@@ -110,10 +110,10 @@ def test_linearity_in_the_message_values(cuda):
 
 
 def test_alternating_inputs_on_one_graph_never_see_stale_candidates(cuda):
-    """The split-row finalize runs inside the main kernel on keys handed over
-    between waves (possibly on different XCDs).  Stale keys from the previous launch
-    would be invisible with identical inputs, so alternate two inputs on the same
-    graph, L1/L2-warm, and check every launch."""
+    """The split rows' tasks hand their candidate keys to the finalize launch through the
+    graph's workspace (written by waves on any XCD, read by the next kernel).  Stale keys from
+    the previous call would be invisible with identical inputs, so alternate two inputs on the
+    same graph, L1/L2-warm, and check every call."""
     from oracle import c_oracle as CO
     from sngnn_amd import ops
     from sngnn_amd.graph import Graph
