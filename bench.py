@@ -521,12 +521,20 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
     launch stream around batches of 10 back-to-back backward calls, nothing subtracted."""
     _, wsel, *_ = ops.aggregate_forward(graph, h, top_k, thr, save_for_backward=True)
     n_sel = int((wsel > -3.0).sum())
+    # one backward call as the autograd function makes it: from the kept bits its training forward wrote
+    # itself where the library offers that (no packing launch), else from the per-edge weights
+    bits = ops.kept_bits_supported(graph, top_k, c)
+    if bits:
+        _, kb = ops._forward_epilogue(graph, h, None, top_k, thr, True, None, None, True)
+        call = lambda: ops.aggregate_backward_bits(graph, h, gout, kb, top_k)      # noqa: E731
+    else:
+        call = lambda: ops.aggregate_backward(graph, h, gout, wsel, top_k)        # noqa: E731
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     bw = []
     for _ in range(8):
         ev[0].record()
         for _ in range(10):
-            ops.aggregate_backward(graph, h, gout, wsel, top_k)
+            call()
         ev[1].record()
         ev[1].synchronize()
         bw.append(ev[0].elapsed_time(ev[1]) / 10)
@@ -538,7 +546,8 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
             traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("arxiv_k16_bwd")
     except Exception:
         traffic = None
-    return {"bound": "hbm", "kernels": ("k_pack_kept + k_bwd_w (node-centric: one backward call as the autograd function makes it, "
+    return {"bound": "hbm", "kernels": ("k_bwd_w (node-centric, one launch: the kept bits come from the training forward itself)" if bits else
+                        "k_pack_kept + k_bwd_w (node-centric: one backward call as the autograd function makes it, "
                         "with the forward's top_k)" if 2 * graph.num_fused_nodes >= graph.num_nodes else
                         "k_clear_words + k_bwd_t + k_bwd_t_fin + k_bwd_s (the two passes: fewer than half of this graph's "
                         "nodes are small both as target and as source)"),

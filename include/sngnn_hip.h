@@ -208,6 +208,11 @@ typedef struct sngnn_epilogue {
     const void *seed;       /* dev uint64 [1] or NULL (with keep == NULL): draw the keep mask in the kernel, */
     float p;                /* keep[i, c] = u(seed, i * C + c) >= p, u a counter-based uniform: the same     */
                             /* seed gives the same mask; the caller advances the seed between forwards       */
+    void *kept_bits;        /* dev, sngnn_graph_kept_bits_bytes(g) bytes, or NULL: training calls - the      */
+                            /* forward writes WHICH edges it kept as packed bits (its own layout) for        */
+                            /* sngnn_agg_backward_bits, instead of wsel + a packing launch in the backward;  */
+                            /* only where sngnn_agg_kept_bits_supported(g, top_k); an all-zero struct with   */
+                            /* this field set is a plain forward that saves the bits                         */
 } sngnn_epilogue_t;
 int sngnn_agg_forward_epilogue(const sngnn_graph_t *g, const float *h, int C, int top_k, float thr,
                                const sngnn_epilogue_t *epi, float *out, float *wsel, float *inv_norm,
@@ -280,6 +285,15 @@ int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
 int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, int C,
                             const float *grad_out, const float *wsel, int top_k, float *grad_h,
                             void *workspace, void *stream);
+/* The same from the kept bits a forward wrote itself (sngnn_epilogue_t.kept_bits): no packing
+ * launch in front.  sngnn_agg_kept_bits_supported: whole graph, 1 <= top_k <= 16, a graph on which
+ * the backward is the node-centric one (most nodes small as target and as source) and whose
+ * biggest row's candidates fit the finalize at this C.  The gradient
+ * equals sngnn_agg_backward_topk's on the same forward, bit for bit. */
+int sngnn_agg_kept_bits_supported(const sngnn_graph_t *g, int C, int top_k);
+int64_t sngnn_graph_kept_bits_bytes(const sngnn_graph_t *g);
+int sngnn_agg_backward_bits(const sngnn_graph_t *g, const float *h, int C, const float *grad_out,
+                            const void *kept_bits, int top_k, float *grad_h, void *workspace, void *stream);
 
 /*
  * Cosine-attention mode of the same gather skeleton.

@@ -54,6 +54,9 @@ SIGNATURES = {
                                             _vp]),
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_agg_backward_topk": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_agg_kept_bits_supported": (_i32, [_vp, _i32, _i32]),
+    "sngnn_graph_kept_bits_bytes": (_i64, [_vp]),
+    "sngnn_agg_backward_bits": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_attn_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_signed_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -91,7 +94,7 @@ SIGNATURES = {
 class Epilogue(C.Structure):
     """``sngnn_epilogue_t`` (include/sngnn_hip.h)."""
     _fields_ = [("bias", C.c_void_p), ("keep", C.c_void_p), ("keep_scale", C.c_float), ("relu", C.c_int),
-                ("seed", C.c_void_p), ("p", C.c_float)]
+                ("seed", C.c_void_p), ("p", C.c_float), ("kept_bits", C.c_void_p)]
 
 
 _lib = None

@@ -17,14 +17,46 @@ extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
     return sngnn_agg_backward_topk(g, h, C, grad_out, wsel, -1, grad_h, workspace, stream);
 }
 
+// whether a forward with this top_k can write the kept bits itself AND the backward that would read
+// them is the hinted node-centric one (agg_fwd.hip asks the same question)
+static bool node_centric(const sngnn_graph_t *g)
+{
+    const bool mostly_fused = (int64_t)g->n_fused * 2 >= g->N;
+    return g_bwd_mode == 2 || (g_bwd_mode == 0 && mostly_fused);
+}
+bool sngnn::kept_bits_path(const sngnn_graph_t *g, int top_k)
+{
+    return g != nullptr && g->csc_bit != nullptr && g->N == g->Ntot && top_k >= 1 && top_k <= SMALL_T && node_centric(g) &&
+           !fwd_scores_on_the_fly_forced();       // (the forward writes the bits in table mode only)
+}
+
+static int backward_impl(const sngnn_graph_t *g, const float *h, int C, const float *grad_out, const float *wsel,
+                         const unsigned *kbits, int top_k, float *grad_h, void *workspace, void *stream);
+
 extern "C" int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, int C,
                                        const float *grad_out, const float *wsel, int top_k,
                                        float *grad_h, void *workspace, void *stream)
 {
+    SN_REQUIRE(g == nullptr || wsel != nullptr || g->Ep == 0, SNGNN_EINVAL, "wsel is NULL");
+    return backward_impl(g, h, C, grad_out, wsel, nullptr, top_k, grad_h, workspace, stream);
+}
+
+extern "C" int sngnn_agg_backward_bits(const sngnn_graph_t *g, const float *h, int C, const float *grad_out,
+                                       const void *kept_bits, int top_k, float *grad_h, void *workspace,
+                                       void *stream)
+{
+    SN_REQUIRE(g != nullptr && kept_bits != nullptr, SNGNN_EINVAL, "graph / kept_bits is NULL");
+    SN_REQUIRE(kept_bits_path(g, top_k), SNGNN_EINVAL,
+               "no kept-bit path for this graph / top_k (sngnn_agg_kept_bits_supported)");
+    return backward_impl(g, h, C, grad_out, nullptr, (const unsigned *)kept_bits, top_k, grad_h, workspace, stream);
+}
+
+static int backward_impl(const sngnn_graph_t *g, const float *h, int C, const float *grad_out, const float *wsel,
+                         const unsigned *kbits, int top_k, float *grad_h, void *workspace, void *stream)
+{
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
     if (g->Ntot == 0) return SNGNN_OK;
     SN_REQUIRE(h && grad_h && workspace && (grad_out || g->N == 0), SNGNN_EINVAL, "NULL argument");
-    SN_REQUIRE(wsel != nullptr || g->Ep == 0, SNGNN_EINVAL, "wsel is NULL");
     RowCfg cfg;
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
                "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
@@ -62,12 +94,12 @@ extern "C" int sngnn_agg_backward_topk(const sngnn_graph_t *g, const float *h, i
     // would be a wave-per-node item, one node per wave with a longer dependent chain than either
     // pass has: 4.9 ms against the two passes' 4.2 ms at products size.  So: node-centric when at
     // least half of the owned nodes are fused.
-    const bool mostly_fused = (int64_t)g->n_fused * 2 >= g->N;
-    a.mode = (g_bwd_mode == 2 || (g_bwd_mode == 0 && mostly_fused)) ? 0 : 1;   // (2: node-centric whatever the graph - measurement)
+    a.mode = node_centric(g) ? 0 : 1;   // (knob 3 = 2: node-centric whatever the graph - measurement)
     a.top_k = top_k;
     a.role_mask = g_bwd_roles;
     a.fdesc = g->fdesc; a.trest = g->trest;
     a.n_fused = g->n_fused; a.n_trest = g->n_trest;
+    a.kbits = kbits; a.csc_bit = g->csc_bit; a.kb_wbase = (int)g->kb_wbase; a.kb_tbase = (int)g->kb_tbase;
     a.s_small_end = a.mode == 0 ? g->srcs_gt(SMALL_T - 1) : (int)g->Ntot;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {

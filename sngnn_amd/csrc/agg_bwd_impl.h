@@ -63,7 +63,14 @@ struct BwdArgs {
     int role_mask;                // measurement aid (sngnn_tuning_set knob 4): bit 0 wave-per-node items, bit 1 fused items
     int top_k;                    // the forward's top_k when the caller gave it (at most that many kept in-edges
                                   // per row), else <= 0
+    // kept bits written by the forward itself (common.h "kbits" layout; agg_fwd_impl.h): no k_pack_kept
+    // launch.  Small rows: halfword at the row id; wave rows / tasks: 128-bit blocks; out-edges by csc_bit.
+    const unsigned *kbits;
+    const int32_t *csc_bit;
+    int kb_wbase, kb_tbase;
 };
+
+__device__ __forceinline__ bool kbit(const BwdArgs &a, int b) { return (a.kbits[b >> 5] >> (b & 31)) & 1u; }
 
 __device__ __forceinline__ bool is_kept(float w) { return w > -3.0f; }
 
@@ -100,6 +107,13 @@ __device__ __forceinline__ void t_edge_row(const Row<VEC, G, R> &x, const Row<VE
 
 // node-centric mode: kept bit of CSR edge e (the mask is 145 KB at arxiv size: cache resident)
 __device__ __forceinline__ bool kept_csr(const BwdArgs &a, int e) { return (a.kmask[e >> 5] >> (e & 31)) & 1u; }
+
+// kept bit of the out-edge at CSC position q: KB = the forward-written layout, else k_pack_kept's CSR-order mask
+template <bool KB> __device__ __forceinline__ bool kept_out(const BwdArgs &a, int q)
+{
+    if constexpr (KB) return kbit(a, a.csc_bit[q]);
+    else return kept_csr(a, a.csc_eid[q]);
+}
 
 __device__ __forceinline__ void set_kept_bit(const BwdArgs &a, int cp)
 {
@@ -389,7 +403,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
             const int q = qs + t;
             it = a.csc_dst[q];
             if constexpr (REC) rec = a.wd[q];
-            else if constexpr (CSRM) kept = kept_csr(a, a.csc_eid[q]);
+            else if constexpr (CSRM) kept = a.kbits ? kbit(a, a.csc_bit[q]) : kept_csr(a, a.csc_eid[q]);
             else kept = (a.kmask[q >> 5] >> (q & 31)) & 1u;
         }
         // (REC: every out-edge carries a record - softmax terms in the attention mode, signed
@@ -443,7 +457,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
 // ascending, T then S), so the result equals theirs bit for bit.
 // The kept bits come from k_pack_kept's mask in CSR order (below): in-edges by position, out-edges
 // through csc_eid.
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool KB = false>
 __device__ __forceinline__ void f_role_node(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -463,15 +477,19 @@ __device__ __forceinline__ void f_role_node(const BwdArgs &a, int blk, int *lds_
     fin.hv.load(a.h + (size_t)v * a.C, a.C, lg);
     fin.own = true;
     int nk = 0, nko = 0;
+    unsigned hw = 0u;                                        // KB: the row's own 16 kept bits, one 2-byte load
+    if constexpr (KB) hw = reinterpret_cast<const unsigned short *>(a.kbits)[vl];
     for (int t0 = 0; t0 < max(deg, od); t0 += G) {           // (one trip for G >= 16)
         const int t = t0 + lg;
-        const bool kept_i = t < deg && kept_csr(a, rs + t);
+        bool kept_i;
+        if constexpr (KB) kept_i = t < deg && ((hw >> t) & 1u);
+        else kept_i = t < deg && kept_csr(a, rs + t);
         const int j = t < deg ? a.col[rs + t] : 0;
         bool kept_o = false;
         int it = 0;
         if (t < od) {
             it = a.csc_dst[qs + t];
-            kept_o = kept_csr(a, a.csc_eid[qs + t]);         // index -> bit: the one chained load of the item
+            kept_o = kept_out<KB>(a, qs + t);                // index -> bit: the one chained load of the item
         }
         const unsigned long long gi = group_bits<G>(__ballot(kept_i), gid);
         const unsigned long long go = group_bits<G>(__ballot(kept_o), gid);
@@ -539,7 +557,7 @@ __device__ __forceinline__ int wave_prefix_incl(int v)
 // so pass S has nothing left but split sources and, under a partition, the halo's sources.
 // Robust against a wrong hint: a list that would overflow is flushed (gathered and
 // accumulated) first - slower, still correct and deterministic.
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool KB = false>
 __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -567,7 +585,7 @@ __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_
     auto flush = [&]() {
         wave_lds_sync();
         if (!have_ids) {
-            for (int t = lane; t < n; t += 64) elist[t] = a.col[elist[t]];
+            for (int t = lane; t < n; t += 64) elist[t] = a.col[(KB ? rs : 0) + elist[t]];   // (KB: the list holds row-local indices)
             wave_lds_sync();
         }
         for (int q0 = 0; q0 < n; q0 += 2 * NG) {
@@ -597,15 +615,34 @@ __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_
     if (deg <= WAVE_T) {
         // a row one wave covers lane by edge: bits and source ids in one round trip (the word scan
         // below needs a second one for the ids of the edges it found)
+        // KB: a wave row's 128 bits sit at its slot, a small target's 16 at its row id
+        const int bitbase = !KB ? 0 : (slot < a.n_med_end ? 32 * (a.kb_wbase + 4 * (slot - a.n_split)) : 16 * vl);
         for (int base = 0; base < deg; base += 64) {
             const int t = base + lane;
-            const bool kept = t < deg && kept_csr(a, rs + t);
+            bool kept;
+            if constexpr (KB) kept = t < deg && kbit(a, bitbase + t);
+            else kept = t < deg && kept_csr(a, rs + t);
             const int j = t < deg ? a.col[rs + t] : 0;
             const unsigned long long m = __ballot(kept);
             if (kept) elist[n + prefix_popc(m)] = j;
             n += __popcll(m);
         }
         have_ids = true;
+    } else if constexpr (KB) {
+        // a split row's bits: 128 per task from its first task's block on (bits beyond the row are zero)
+        const unsigned *rowbits = a.kbits + a.kb_tbase + 4 * a.split_task0[slot];
+        const int nwords = 4 * (a.split_task0[slot + 1] - a.split_task0[slot]);
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            const int wi = w0 + lane;
+            const unsigned word = wi < nwords ? rowbits[wi] : 0u;
+            const int total = wave_sum_i(__popc(word));
+            if (total <= WAVE_T) append(word, wi, total);
+            else
+                for (int sb = 0; sb < 16; ++sb) {
+                    const unsigned ws = (lane >> 2) == sb ? word : 0u;
+                    append(ws, wi, wave_sum_i(__popc(ws)));
+                }
+        }
     } else {
         for (int w0 = rs >> 5; w0 * 32 < e_end; w0 += 64) {
             const int wi = w0 + lane;
@@ -628,7 +665,7 @@ __device__ __forceinline__ void w_role_node(const BwdArgs &a, int blk, int *lds_
         for (int base = 0; base < od; base += 64) {
             const int t = base + lane;
             const int it = t < od ? a.csc_dst[qs + t] : 0;
-            const bool kept = t < od && kept_csr(a, a.csc_eid[qs + t]);
+            const bool kept = t < od && kept_out<KB>(a, qs + t);
             const unsigned long long m = __ballot(kept);
             if (kept) s_i[nso + prefix_popc(m)] = it;
             nso += __popcll(m);
@@ -691,7 +728,7 @@ static __global__ __launch_bounds__(256) void k_pack_kept(const float *__restric
 #define SNGNN_BWDF_ATTR __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 1, 8)))
 // selective calls: every owned node in one launch - a wave per node that is not fused (heavy rows
 // first), then the fused nodes
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool KB = false>
 __global__ __launch_bounds__(BLOCK) SNGNN_BWDF_ATTR void k_bwd_w(const BwdArgs a)
 {
     __shared__ __align__(16) int lds[WAVES][2 * WAVE_T];
@@ -703,8 +740,8 @@ __global__ __launch_bounds__(BLOCK) SNGNN_BWDF_ATTR void k_bwd_w(const BwdArgs a
     // memory system (62 -> 5x us).
     const int stride = a.nbB;
     const int cw = min(a.nbA, (b + stride - 1) / stride);          // wave-per-node workgroups before b
-    if (b % stride == 0 && b / stride < a.nbA) { if (a.role_mask & 1) w_role_node<VEC, G, R>(a, b / stride, lw); }
-    else if (a.role_mask & 2) f_role_node<VEC, G, R>(a, b - cw, lw);
+    if (b % stride == 0 && b / stride < a.nbA) { if (a.role_mask & 1) w_role_node<VEC, G, R, KB>(a, b / stride, lw); }
+    else if (a.role_mask & 2) f_role_node<VEC, G, R, KB>(a, b - cw, lw);
 }
 
 // pass T of the targets that are not fused (split-row tasks, wave rows, small targets with a
@@ -760,7 +797,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
             if (t < e1) rec = a.wd[q];
             kept = t < e1;
         } else if constexpr (CSRM) {
-            kept = t < e1 && kept_csr(a, a.csc_eid[q]);
+            kept = t < e1 && (a.kbits ? kbit(a, a.csc_bit[q]) : kept_csr(a, a.csc_eid[q]));
         } else {
             kept = t < e1 && ((a.kmask[q >> 5] >> (q & 31)) & 1u);
         }
@@ -861,15 +898,22 @@ template <int VEC, int G, int R> int launch_agg_bwd(const BwdArgs &a0, hipStream
     BwdArgs a = a0;
     if (a.mode == 0) {
         // node-centric: kept bits packed from the forward's weights, then ...
-        if (a.kmask_words > 0)
+        if (a.kmask_words > 0 && a.kbits == nullptr)
             k_pack_kept<<<ceil_div(a.Ep, 256 * WAVES), 256, 0, st>>>(a.wsel, a.Ep, (unsigned long long *)a.kmask);
+        if (a.kbits != nullptr && !(a.top_k >= 1 && a.top_k <= WAVE_T && a.N == a.Ntot)) {
+            set_error("internal: the kept-bit backward is the hinted node-centric one");
+            return SNGNN_EINVAL;
+        }
         if (a.top_k >= 1 && a.top_k <= WAVE_T && a.N == a.Ntot) {
             // ... selective call on a whole graph: every node in one launch; pass S is left with
             // the split sources' tasks
             a.nbA = ceil_div(a.n_med_end + a.n_trest, WAVES);
             const int nbF = ceil_div(a.n_fused, (int64_t)WAVES * RPW);
             a.nbB = std::max(1, (a.nbA + nbF) / std::max(a.nbA, 1));          // k_bwd_w: spacing of the wave-per-node workgroups
-            if (a.nbA + nbF > 0) k_bwd_w<VEC, G, R><<<a.nbA + nbF, BLOCK, 0, st>>>(a);
+            if (a.nbA + nbF > 0) {
+                if (a.kbits) k_bwd_w<VEC, G, R, true><<<a.nbA + nbF, BLOCK, 0, st>>>(a);
+                else k_bwd_w<VEC, G, R, false><<<a.nbA + nbF, BLOCK, 0, st>>>(a);
+            }
             if (a.n_stasks > 0) {
                 a.nbA = ceil_div(a.n_stasks, WAVES);
                 a.nbB = 0;

@@ -67,6 +67,7 @@ static int g_role_mask = 7;
 // exact re-scoring of the candidates, 72.2 against 73.5 us at top_k 16 / thr 0), 1 = table
 // always, 2 = on the fly always (same selections, bit for bit)
 static int g_table_mode = 0;
+bool sngnn::fwd_scores_on_the_fly_forced() { return g_table_mode == 2; }
 extern "C" int sngnn_tuning_set(int which, int value)
 {
     SN_REQUIRE(which == 0 || (which >= 2 && which <= 7), SNGNN_EINVAL, "unknown tuning knob");
@@ -175,6 +176,12 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.role_mask = g_role_mask;
     a.row_flag = row_flag; a.row_want = row_want;
     a.epi_flags = 0; a.epi_bias = nullptr; a.epi_keep = nullptr; a.epi_seed = nullptr; a.epi_p = 0.f; a.epi_scale = 1.0f;
+    a.kbits = nullptr; a.kb_wbase = (int)g->kb_wbase; a.kb_tbase = (int)g->kb_tbase;
+    if (epi && epi->kept_bits) {
+        SN_REQUIRE(sngnn::kept_bits_path(g, top_k) && row_flag == nullptr && nrm != nullptr, SNGNN_EINVAL,
+                   "no kept-bit path for this graph / top_k (sngnn_agg_kept_bits_supported)");
+        a.kbits = (unsigned *)epi->kept_bits;
+    }
     if (epi) {
         a.epi_bias = epi->bias; a.epi_keep = epi->keep;
         a.epi_seed = (const unsigned long long *)epi->seed; a.epi_p = epi->p;
@@ -205,6 +212,8 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.cand_src = a.cand_key ? (int32_t *)(a.cand_key + (size_t)g->n_tasks * CAND_MAX_K) : nullptr;
     const int max_split = g->n_split ? g->rdeg[0] : 0;
     a.use_cand = fwd_use_candidates(a.k, C, max_split) ? 1 : 0;
+    SN_REQUIRE(a.kbits == nullptr || a.use_cand, SNGNN_EINVAL,
+               "no kept-bit path: this graph's biggest row takes the scratch-score finalize");
     // split rows whose (tasks * top_k) candidates exceed one 128-key wave selection
     // (no selection: split rows with more than 16 partial rows to add)
     a.n_split_gt_wave = top_k > 0 ? g->rows_gt((int64_t)(128 / std::min(top_k, 128)) * CHUNK)
@@ -380,6 +389,13 @@ extern "C" int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, co
     // (the caller decides whether filter rows exist - sngnn_filter_wanted - and passes them or NULL)
     return forward_normalized(g, cfg, n, nrm, filt, C, top_k, thr, out, wsel, inv_norm, nullptr, nullptr, scratch,
                               nullptr, (hipStream_t)stream, row_flag, row_want);
+}
+
+// (the forward side of the question: split rows must take the candidate finalize, whose winners set their bits)
+extern "C" int sngnn_agg_kept_bits_supported(const sngnn_graph_t *g, int C, int top_k)
+{
+    if (!sngnn::kept_bits_path(g, top_k)) return 0;
+    return fwd_use_candidates(top_k, C, g->n_split ? g->rdeg[0] : 0) ? 1 : 0;
 }
 
 extern "C" int sngnn_filter_wanted(const sngnn_graph_t *g, int C, int top_k, float thr)

@@ -84,6 +84,14 @@ struct FwdArgs {
     // store epilogue of a hidden layer (models.py:204-209: conv -> [+ bias] -> relu_ -> dropout), applied to
     // the finished mean row on its way out: out = keep ? max(mean + bias, 0) * scale : 0.
     // epi_flags: bit 0 relu, bit 1 bias, bit 2 keep mask; 0 = none (sngnn_agg_forward_epilogue).
+    // Kept bits written by the forward itself (training calls; common.h "kbits" layout; nullptr = off, the
+    // per-edge weights wsel are written instead): a small row stores its 16 bits as one halfword
+    // at its row id, a wave row its 128 bits at its slot, a split-row task zeroes its 128 bits and
+    // the finalize sets the winners' - plain stores of whole units each row owns: no atomics between
+    // rows, no clearing pass, and the backward needs no k_pack_kept launch.  Host guarantees
+    // 0 <= top_k <= SMALL_T (wave rows and tasks always rank) and the candidate finalize.
+    unsigned *kbits;
+    int kb_wbase, kb_tbase;
     // epi_flags: bit 0 relu, bit 1 bias, bit 2 keep mask given, bit 3 keep mask drawn here; 0 = none.
     int epi_flags;
     const float *epi_bias;          // [C]
@@ -375,6 +383,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 
     RowT acc;
     acc.zero();
+    unsigned kb = 0u;                 // the row's kept bits (a.kbits)
     for (int t0 = 0; t0 < dmax; t0 += U) {
         RowT x[U];
         float nj[U];
@@ -409,6 +418,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
                     const bool sel = (a.k < 0) || (s >= a.thr);
                     if (sel) acc.axpy(s * nj[u], x[u]);
                     if (a.wsel && lg == 0) a.wsel[rs + t0 + u] = sel ? s : SNGNN_UNSELECTED;
+                    if constexpr (!OTF) kb |= sel ? (1u << (t0 + u)) : 0u;     // (group-uniform; table mode only)
                 }
             }
         }
@@ -466,6 +476,9 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
             const bool sel = rk < a.k && se >= a.thr;
             s_w[e] = sel ? se : SNGNN_UNSELECTED;
             if (rank && a.wsel) a.wsel[rs + e] = sel ? se : SNGNN_UNSELECTED;
+            // (lane lg == 0 runs every iteration any lane of its group runs: it ends with all the bits)
+            if constexpr (!OTF)
+                if (rank && a.kbits) kb |= (unsigned)fwd_group_bits<G>(__ballot(sel), gid) << (e - lg);
             if (emit && sel) {
                 a.sel_src[(size_t)i * a.k + rk] = s_col[e];
                 a.sel_w[(size_t)i * a.k + rk] = se;
@@ -488,6 +501,8 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
         }
         wave_lds_sync();       // s_sc / s_w are reused by the next set
     }
+    if constexpr (!OTF)
+        if (a.kbits && valid && lg == 0) reinterpret_cast<unsigned short *>(a.kbits)[i] = (unsigned short)kb;
     if (valid) {
         acc.div((float)max(deg, 1));
         if constexpr (EPI) row_epilogue<VEC, G, R>(a, acc, i, lg);
@@ -840,6 +855,9 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
             if (i0 < deg) a.wsel[rs + i0] = ws.kept0 ? s_sc[i0] : SNGNN_UNSELECTED;
             if (i1 < deg) a.wsel[rs + i1] = ws.kept1 ? s_sc[i1] : SNGNN_UNSELECTED;
         }
+        if constexpr (!OTF)
+            if (a.kbits && lane < 4)          // the row's 128 kept bits at its slot
+                a.kbits[a.kb_wbase + 4 * item + lane] = (unsigned)((lane < 2 ? m0 : m1) >> (32 * (lane & 1)));
         wave_lds_sync();
         if (emit) {
             // rank of a kept edge = number of keys above it
@@ -953,6 +971,8 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             if (lane < e1 - e0) w[lane] = SNGNN_UNSELECTED;
             if (lane + 64 < e1 - e0) w[lane + 64] = SNGNN_UNSELECTED;
         }
+        if constexpr (!OTF)
+            if (a.kbits && lane < 4) a.kbits[a.kb_tbase + 4 * tq + lane] = 0u;      // the finalize sets the winners' bits
     } else if (!rank) {
         acc.reduce_across_groups();
         if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
@@ -1275,6 +1295,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         const unsigned long long kq = win[q];
         const float sq = key_score(kq);
         if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
+        if (a.kbits) atomicOr(a.kbits + a.kb_tbase + 4 * t0 + (key_index(kq) >> 5), 1u << (key_index(kq) & 31));
         if (emit) {
             int rk = 0;
             for (int r = 0; r < nsel; ++r) rk += win[r] > kq;
@@ -1366,6 +1387,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
         const unsigned long long kq = s_key_w[lane];
         const float sq = key_score(kq);
         if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
+        if (a.kbits) atomicOr(a.kbits + a.kb_tbase + 4 * t0 + (key_index(kq) >> 5), 1u << (key_index(kq) & 31));
         if (emit) {
             int rk = 0;
             for (int r = 0; r < nsel; ++r) rk += s_key_w[r] > kq;

@@ -70,6 +70,7 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     a.nbA = a.nbB = a.nbC = 0;
     a.mode = 1; a.top_k = -1; a.role_mask = 3; a.s_small_end = (int)g->Ntot; a.Ep = g->Ep;
     a.fdesc = nullptr; a.trest = nullptr; a.n_fused = a.n_trest = 0;
+    a.kbits = nullptr; a.csc_bit = nullptr; a.kb_wbase = a.kb_tbase = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg.vec) {
     case 1: return launch_attn_bwd_v1(cfg, a, st);

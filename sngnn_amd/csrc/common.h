@@ -38,6 +38,8 @@ int wgrad_mfma_partials(int64_t N, int C, int F);
 int launch_wgrad_mfma(const float *g, const float *x, int64_t N, int C, int F, float *part, float *part_b,
                       hipStream_t st);
 
+bool kept_bits_path(const sngnn_graph_t *g, int top_k);
+bool fwd_scores_on_the_fly_forced();          // agg_fwd.hip (knob 2 == 2)     // agg_bwd.hip: forward-written kept bits usable
 int set_bwd_mode(int v);      // agg_bwd.hip (sngnn_tuning_set knobs 3, 4)
 int set_bwd_roles(int v);
 int set_lin_mode(int v);       // linear.hip (knob 5)
@@ -118,6 +120,12 @@ struct sngnn_graph {
     float *inv_deg = nullptr;  // [N] 1 / max(in-degree, 1) by row (backward pass S)
     // backward, node-centric path: the small sources of sdesc / sperm are ordered [not fused |
     // fused], natural order inside each; fused = owned, in-degree and out-degree <= SMALL_T
+    // kept-bit layout the forward can write without atomics ("kbits": agg_fwd_impl.h, agg_bwd_impl.h):
+    //   words [0, kb_wbase): one HALFWORD per row id (bit t = edge t of a small row);
+    //   [kb_wbase, kb_tbase): 4 words per wave row, by slot;  [kb_tbase, kb_words): 4 words per split-row task.
+    // csc_bit[q] = the bit index of CSC entry q's edge in that layout (static); nullptr = layout unavailable
+    int32_t *csc_bit = nullptr;
+    int64_t kb_wbase = 0, kb_tbase = 0, kb_words = 0;
     int4 *fdesc = nullptr;     // [n_fused] {node, first in-edge, first CSC entry, in-degree | out-degree << 8}
     int4 *trest = nullptr;     // [n_trest] {row, first edge, in-degree, 0}: small targets with out-degree > SMALL_T
     int n_fused = 0, n_trest = 0;

@@ -193,6 +193,24 @@ __global__ void k_bucket_key(const int32_t *__restrict__ deg, int64_t N, int32_t
     if (i < N) key[i] = deg[i] > SMALL_T ? deg[i] : (deg[i] + 3) / 4 * 4;
 }
 
+// bit index of every CSC entry's edge in the forward-written kept-bit layout (common.h: kbits)
+__global__ void k_csc_bit(const int32_t *__restrict__ csc_eid, const int32_t *__restrict__ csc_dst,
+                          const int32_t *__restrict__ rowptr, const int32_t *__restrict__ rslot,
+                          const int32_t *__restrict__ split_task0, int64_t Ep, int n_split, int n_med_end,
+                          int64_t wbase, int64_t tbase, int32_t *__restrict__ csc_bit)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Ep) return;
+    const int i = csc_dst[q];
+    const int t = csc_eid[q] - rowptr[i];
+    const int slot = rslot[i];
+    int64_t b;
+    if (slot >= n_med_end) b = 16 * (int64_t)i + t;
+    else if (slot >= n_split) b = 32 * wbase + 128 * (int64_t)(slot - n_split) + t;
+    else b = 32 * tbase + 128 * (int64_t)split_task0[slot] + t;
+    csc_bit[q] = (int32_t)b;
+}
+
 __global__ void k_degree(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ deg)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,6 +500,23 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
     if ((rc = build_tasks(g->sdeg, g->n_ssplit, &g->stask_slot, &g->stask_chunk, &g->ssplit_task0,
                           nullptr, &g->n_stasks, nullptr)))
         return rc;
+    // 8. the kept-bit layout a training forward writes itself (common.h): geometry + the static bit
+    //    index of every CSC entry.  (Whole graphs only: the node-centric backward that reads it is.)
+    {
+        const int n_med_end = g->rows_gt(SMALL_T);
+        g->kb_wbase = ((N + 1) / 2 + 3) / 4 * 4;
+        g->kb_tbase = g->kb_wbase + 4 * (int64_t)(n_med_end - g->n_split);
+        g->kb_words = g->kb_tbase + 4 * (int64_t)g->n_tasks;
+        if (N == Ntot && Ep > 0 && g->kb_words * 32 < ((int64_t)1 << 31)) {
+            DevBuf rslot;
+            if (rslot.alloc((size_t)N * 4)) { set_error("out of device memory (graph build)"); return SNGNN_ENOMEM; }
+            if ((rc = dev_alloc(&g->csc_bit, Ep))) return rc;
+            k_invert<<<grid1(N), 256, 0, st>>>(g->rperm, rslot.as<int32_t>(), N);
+            k_csc_bit<<<grid1(Ep), 256, 0, st>>>(g->csc_eid, g->csc_dst, g->rowptr, rslot.as<int32_t>(), g->split_task0,
+                                                 Ep, g->n_split, n_med_end, g->kb_wbase, g->kb_tbase, g->csc_bit);
+            SN_HIP(hipStreamSynchronize(st));      // rslot goes out of scope
+        }
+    }
     SN_HIP(hipStreamSynchronize(st));
     return 0;
 }
@@ -534,12 +569,13 @@ void sngnn_graph_destroy(sngnn_graph_t *g)
     if (!g) return;
     void *ptrs[] = {g->rowptr, g->col, g->eid, g->cscptr, g->csc_eid, g->csc_dst, g->csc_pos, g->col_s, g->rperm_b, g->rdesc_b, g->col_s_b, g->rperm, g->fdesc, g->trest,
                     g->sperm, g->rdesc, g->sdesc, g->inv_deg, g->task_slot, g->task_chunk, g->split_soff, g->split_task0, g->task_order,
-                    g->stask_slot, g->stask_chunk, g->ssplit_task0};
+                    g->stask_slot, g->stask_chunk, g->ssplit_task0, g->csc_bit};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete g;
 }
 
 int64_t sngnn_graph_num_nodes(const sngnn_graph_t *g) { return g ? g->N : -1; }
+int64_t sngnn_graph_kept_bits_bytes(const sngnn_graph_t *g) { return (g && g->csc_bit) ? g->kb_words * 4 : 0; }
 int64_t sngnn_graph_num_total_nodes(const sngnn_graph_t *g) { return g ? g->Ntot : -1; }
 int64_t sngnn_graph_row_offset(const sngnn_graph_t *g) { return g ? g->row_off : -1; }
 int64_t sngnn_graph_num_edges(const sngnn_graph_t *g) { return g ? g->Ep : -1; }

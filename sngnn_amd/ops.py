@@ -181,6 +181,29 @@ def aggregate_backward(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor,
     return grad_h
 
 
+def kept_bits_supported(graph: Graph, top_k: Optional[int], channels: int = 64) -> bool:
+    """``sngnn_agg_kept_bits_supported``: whether a training forward on this graph with this top_k
+    (at this width) can hand its backward the kept edges as bits it packs itself."""
+    if top_k is None:
+        return False
+    return bool(_lib.load().sngnn_agg_kept_bits_supported(graph.handle, int(channels), int(top_k)))
+
+
+def aggregate_backward_bits(graph: Graph, h: torch.Tensor, grad_out: torch.Tensor, kept_bits: torch.Tensor,
+                            top_k: int) -> torch.Tensor:
+    """``sngnn_agg_backward_bits``: the backward from the kept bits the forward wrote."""
+    lib = _lib.load()
+    h = _check_rows(h, graph.num_total_nodes, "h")
+    grad_out = _check_rows(grad_out, graph.num_nodes, "grad_out")
+    c = h.size(1)
+    grad_h = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        rc = lib.sngnn_agg_backward_bits(graph.handle, h.data_ptr(), c, grad_out.data_ptr(), kept_bits.data_ptr(),
+                                         int(top_k), grad_h.data_ptr(), graph.workspace(c).data_ptr(), _stream(h.device))
+    _lib.check(rc, "sngnn_agg_backward_bits")
+    return grad_h
+
+
 class HiddenEpilogue:
     """What follows a hidden conv layer in the reference's wrappers (models.py:204-209, 79-84,
     296-301) - the conv's bias add, ``F.relu(x, inplace=True)`` and ``self.dropout(x)`` - as the
@@ -222,9 +245,12 @@ class _Aggregate(torch.autograd.Function):
     def forward(ctx, h, graph, top_k, thr, unit=None, epi=None, bias=None):
         need_grad = ctx.needs_input_grad[0]
         ctx.epi = epi
-        if epi is not None:
-            out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, epi, bias)
-            ctx.bias_grad = bias is not None and ctx.needs_input_grad[6]
+        # training calls: where the library can, the forward writes WHICH edges it kept as packed bits
+        # itself (sngnn_epilogue_t.kept_bits) - no per-edge weights, no packing launch in the backward
+        ctx.bits = need_grad and kept_bits_supported(graph, top_k, h.size(1))
+        if epi is not None or ctx.bits:
+            out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, epi, bias, ctx.bits)
+            ctx.bias_grad = epi is not None and bias is not None and ctx.needs_input_grad[6]
         elif unit is not None and unit.n is not None:
             # the producer of h (``lin``'s epilogue) already wrote F.normalize(h): no pass over h
             out, wsel = _forward_prepared(graph, unit, top_k, thr, need_grad)
@@ -258,7 +284,10 @@ class _Aggregate(torch.autograd.Function):
                 _lib.check(rc, "sngnn_epilogue_backward")
             if ctx.bias_grad:
                 grad_bias = grad_out.sum(dim=0)
-        grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
+        if ctx.bits:         # (``wsel`` holds the kept bits)
+            grad_h = aggregate_backward_bits(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
+        else:
+            grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
         return grad_h, None, None, None, None, None, grad_bias
 
 
@@ -292,19 +321,26 @@ def _forward_prepared(graph: Graph, unit: "UnitRows", top_k, thr, need_grad):
     return out, wsel
 
 
-def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: "HiddenEpilogue", bias):
+def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optional["HiddenEpilogue"], bias,
+                      bits: bool = False):
     """``sngnn_agg_forward_epilogue`` / ``_prepared_epilogue``: the forward whose stores apply
-    bias + relu + dropout.  Draws the keep mask (the caller's Bernoulli(1 - p), torch's generator:
-    graph-capture safe) when the epilogue drops."""
+    bias + relu + dropout (``epi``; draws the keep mask - the caller's Bernoulli(1 - p), torch's
+    generator: graph-capture safe - when the epilogue drops and has no seed) and / or that writes
+    the kept bits for its backward itself (``bits``: the second result is then that bit tensor
+    instead of the per-edge weights)."""
     lib = _lib.load()
     h = _check_rows(h, graph.num_total_nodes, "h")
     n, c = graph.num_nodes, h.size(1)
     k = -1 if top_k is None else int(top_k)
     out = torch.empty((n, c), dtype=torch.float32, device=h.device)
-    wsel = inv = keep = None
-    if need_grad:
+    wsel = inv = keep = kbits = None
+    if need_grad and bits:
+        kbits = torch.empty(max(int(lib.sngnn_graph_kept_bits_bytes(graph.handle)), 16), dtype=torch.uint8, device=h.device)
+    elif need_grad:
         wsel = torch.empty(graph.num_edges, dtype=torch.float32, device=h.device)
         inv = torch.empty(n, dtype=torch.float32, device=h.device)
+    if epi is None:
+        epi = HiddenEpilogue(False, 0.0, False)          # (a plain forward that saves the bits)
     epi.scale = 1.0
     seed = None
     if epi.drops:
@@ -319,7 +355,8 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: "Hidden
         if bias.dtype != torch.float32 or bias.numel() != c or bias.device != h.device:
             raise ValueError("bias must be a float32 tensor of C elements on h's device")
         bias = bias.detach().contiguous()
-    st = _lib.Epilogue(_lib.ptr(bias), _lib.ptr(keep), float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p))
+    st = _lib.Epilogue(_lib.ptr(bias), _lib.ptr(keep), float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p),
+                       _lib.ptr(kbits))
     ws = graph.workspace(c)
     import ctypes
     with torch.cuda.device(h.device):
@@ -333,7 +370,7 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: "Hidden
                                                 out.data_ptr(), _lib.ptr(wsel), _lib.ptr(inv), ws.data_ptr(),
                                                 _stream(h.device))
     _lib.check(rc, "sngnn_agg_forward_epilogue")
-    return out, wsel
+    return out, (kbits if kbits is not None else wsel)
 
 
 def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float,

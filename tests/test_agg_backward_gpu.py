@@ -254,3 +254,69 @@ def test_node_centric_backward_equals_the_two_passes(cuda, n, e, C, hubs, rem, k
         assert torch.equal(_backward_in_mode(lib, 2, gp, h, gout[lo:hi].contiguous(), wsel_p, k), two_p)
     finally:
         lib.sngnn_tuning_set(3, 0)
+
+
+@pytest.mark.parametrize("C,k,thr", [(40, 16, 0.0), (40, 1, 0.0), (32, 3, 0.2), (8, 2, -0.5), (64, 10, 0.9), (7, 16, 0.0),
+                                     (130, 5, 0.0), (48, 16, 0.3)])
+def test_kept_bits_written_by_the_forward_equal_the_packed_weights(cuda, C, k, thr):
+    """Training calls hand the backward WHICH edges were kept as bits the forward packs itself
+    (sngnn_epilogue_t.kept_bits: a halfword per small row, 128 bits per wave row / split-row task,
+    the finalize sets the winners') instead of per-edge weights + a packing launch: the gradient is
+    the weights path's BIT FOR BIT, on a graph with small rows of every degree, wave rows, split
+    rows (a 5 000-edge hub) and isolated nodes - and the bits say exactly what the weights say."""
+    from sngnn_amd import _lib, ops
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    n = 6000
+    hubs = ((5, 5000), (6, 1300), (7, 129), (8, 128), (9, 17), (10, 16))
+    ei = random_graph(n, 30000, seed=C + k, hubs=hubs).to(cuda)
+    ei = ei[:, ei[1] < n - 50]                                        # the last 50 nodes have no in-edge
+    g = Graph(ei, n, True, True)
+    assert g.num_fused_nodes * 2 >= n and ops.kept_bits_supported(g, k)
+    gen = torch.Generator().manual_seed(3)
+    h = torch.randn(n, C, generator=gen).to(cuda)
+    h[11] = h[12]                                                      # an exact tie somewhere
+    gout = torch.randn(n, C, generator=gen).to(cuda)
+    # the weights path, explicitly
+    out_w, wsel, *_ = ops.aggregate_forward(g, h, k, thr, save_for_backward=True)
+    grad_w = ops.aggregate_backward(g, h, gout, wsel, k)
+    # the autograd function: takes the bits path by itself
+    hg = h.clone().requires_grad_(True)
+    out_b = ops.aggregate(hg, g, k, thr)
+    out_b.backward(gout)
+    assert torch.equal(out_b.detach(), out_w)
+    assert torch.equal(hg.grad, grad_w)
+    # the bits themselves against the weights, edge by edge
+    out2, kb = ops._forward_epilogue(g, h, None, k, thr, True, None, None, True)
+    assert torch.equal(out2, out_w)
+    words = kb.view(torch.int32).cpu().numpy().view(np.uint32)
+    rowptr, rperm = g.array("rowptr").astype(np.int64), g.array("rperm").astype(np.int64)
+    deg = np.diff(rowptr)
+    kept = (wsel.cpu().numpy() > -3.0)
+    n_split, n_med_end = int((deg > 128).sum()), int((deg > 16).sum())
+    wbase = ((n + 1) // 2 + 3) // 4 * 4
+    tbase = wbase + 4 * (n_med_end - n_split)
+    task0 = np.concatenate([[0], np.cumsum((deg[rperm[:n_split]] + 127) // 128)])
+
+    def bit(b):
+        return (words[b >> 5] >> np.uint32(b & 31)) & np.uint32(1)
+    for slot in list(range(min(n_med_end + 40, n))) + list(range(n - 60, n)):
+        i = int(rperm[slot])
+        if slot >= n_med_end:
+            base = 16 * i
+        elif slot >= n_split:
+            base = 32 * wbase + 128 * (slot - n_split)
+        else:
+            base = 32 * tbase + 128 * int(task0[slot])
+        got = np.array([bit(base + t) for t in range(int(deg[i]))], dtype=bool)
+        assert np.array_equal(got, kept[rowptr[i]:rowptr[i + 1]]), (slot, i)
+    # knob 3 = 1 (two passes for every node) has no bits path: the function falls back to the weights
+    try:
+        lib.sngnn_tuning_set(3, 1)
+        assert not ops.kept_bits_supported(g, k)
+        hg2 = h.clone().requires_grad_(True)
+        ops.aggregate(hg2, g, k, thr).backward(gout)
+    finally:
+        lib.sngnn_tuning_set(3, 0)
+    assert float((hg2.grad - grad_w).abs().max()) <= 2e-6 * float(grad_w.abs().max())
+    assert not ops.kept_bits_supported(g, 17) and not ops.kept_bits_supported(g, None)

@@ -62,6 +62,30 @@ def main():
         print("with top_k, roles %d (1 wave-per-node items, 2 fused items): %.1f us/call" % (roles, float(np.mean(ts[2:]))))
     lib.sngnn_tuning_set(4, 3)
     lib.sngnn_tuning_set(3, 0)
+    if k > 0 and ops.kept_bits_supported(g, k, c):        # from the kept bits a training forward writes itself
+        _, kb = ops._forward_epilogue(g, h, None, k, thr, True, None, None, True)
+        ts = []
+        for _ in range(8):
+            ev[0].record()
+            for _ in range(10):
+                gb = ops.aggregate_backward_bits(g, h, gout, kb, k)
+            ev[1].record()
+            ev[1].synchronize()
+            ts.append(ev[0].elapsed_time(ev[1]) * 100)
+        print("from the forward's kept bits (no packing launch): %.1f us/call; equal to the weights path: %s"
+              % (float(np.mean(ts[2:])), bool(torch.equal(gb, res[("g", 2)]))))
+        # the training forward that writes them, against the one that writes per-edge weights
+        for name, fn in (("forward saving weights", lambda: ops.aggregate_forward(g, h, k, thr, save_for_backward=True)),
+                         ("forward saving bits   ", lambda: ops._forward_epilogue(g, h, None, k, thr, True, None, None, True))):
+            ts = []
+            for _ in range(8):
+                ev[0].record()
+                for _ in range(10):
+                    fn()
+                ev[1].record()
+                ev[1].synchronize()
+                ts.append(ev[0].elapsed_time(ev[1]) * 100)
+            print("%s: %.1f us/call" % (name, float(np.mean(ts[2:]))))
     print("two passes   us/call:", res[1])
     print("node-centric us/call:", res[0])
     print("with top_k   us/call:", res[2])
