@@ -415,17 +415,17 @@ __global__ __launch_bounds__(256) void k_knn_merge(const unsigned long long *__r
 }
 
 // ---------------------------------------------------------------------------
-// Small graphs: materialise + select.  When S fits comfortably (N <= KNN_DENSE_MAX_N) and the
-// features are wide (the register-operand path above is for F <= 128), the dense cosine kernel
-// (toolbox.hip: upper triangle on the matrix cores, mirrored) followed by this row selection beats
-// the fused scan, whose both-panels-through-LDS path pays eight barriers per tile: Chameleon
+// Small graphs: materialise + select.  When S fits comfortably (N <= KNN_DENSE_MAX_N) the dense cosine
+// kernel (toolbox.hip: upper triangle on the matrix cores, mirrored) followed by this row selection
+// beats the fused scan - whose both-panels-through-LDS path (wide features) pays eight barriers per
+// tile and whose column splits (few row blocks) each warm their lists up from empty: Chameleon
 // (2 277 x 2 325) and Actor (7 600 x 932) - BASELINE configs 2 and 3 - are this case.
 // One wave per row of S: 256 entries per step (16 bytes per lane), an entry enters the selection
 // only when its key beats the row's current k-th key; survivors are parked behind the list in
 // LDS and merged when the buffer is full (the aggregation's early-exit k-th-key search).
 // Same keys, same order and padding as the fused kernel.
 // ---------------------------------------------------------------------------
-constexpr int64_t KNN_DENSE_MAX_N = 16384;
+constexpr int64_t KNN_DENSE_MAX_N = 32768;       // S = 4.3 GB at most (a stream-ordered allocation)
 
 __global__ __launch_bounds__(256) void k_row_topk(const float *__restrict__ S, int64_t N, int k, int exclude_self,
                                                   int lowbits, int32_t *__restrict__ out_idx,
@@ -562,8 +562,9 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     if (N == 0) return SNGNN_OK;
     SN_REQUIRE(x && nbr_idx && nbr_sim && workspace, SNGNN_EINVAL, "NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    const bool narrow = (uintptr_t)x % 16 == 0 && (F == 128 || F == 96 || F == 64 || F == 32);   // register-operand path
-    if (g_knn_route == 2 || (g_knn_route == 0 && !narrow && N <= KNN_DENSE_MAX_N && N >= 2)) {
+    // (narrow features too: at 20 000 x 128 the fused scan's register-operand path takes 3.1 ms - few row
+    // blocks, lists warmed up per column split - against ~1.2 ms for S + selection)
+    if (g_knn_route == 2 || (g_knn_route == 0 && N <= KNN_DENSE_MAX_N && N >= 2)) {
         // materialise + select (see k_row_topk); S lives in a stream-ordered allocation
         SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "the dense route is for small graphs");
         void *S = nullptr;

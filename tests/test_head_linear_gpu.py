@@ -156,13 +156,17 @@ def test_model_path_uses_the_epilogue_and_matches_the_pass(cuda):
     torch.manual_seed(0)
     conv = sngnn_amd.SNConv_plus(f, c, n, top_k=8, thr=0.1).to(cuda)
     seen = {}
-    orig = ops._forward_prepared
+    orig, orig_e = ops._forward_prepared, ops._forward_epilogue
     ops._forward_prepared = lambda *a, **k: (seen.__setitem__("prepared", True), orig(*a, **k))[1]
+    # (a training call that saves the kept bits goes through _forward_epilogue: it takes the prepared
+    # entry point exactly when ``unit`` - its third argument - carries unit rows)
+    ops._forward_epilogue = lambda *a, **k: (seen.__setitem__("prepared", a[2] is not None and a[2].n is not None),
+                                             orig_e(*a, **k))[1]
     try:
         out = conv(x, ei)
         (out * gout).sum().backward()
     finally:
-        ops._forward_prepared = orig
+        ops._forward_prepared, ops._forward_epilogue = orig, orig_e
     assert seen.get("prepared"), "the conv did not take the unit rows from lin's epilogue"
     g1 = [p.grad.clone() for p in conv.parameters()]
     conv.zero_grad()
