@@ -361,6 +361,16 @@ int sngnn_blend_forward(const float *out0, const float *out1, const float *beta,
 int sngnn_blend_backward(const float *grad_out, const float *out0, const float *out1,
                          const float *beta, int64_t n, float *grad0, float *grad1,
                          float *grad_beta, void *workspace, void *stream);
+/* The blend with a hidden layer's relu + dropout behind it (models.py:81-84) in the same store:
+ * sngnn_epilogue_t with relu and / or a seeded dropout (bias, keep and kept_bits must be NULL;
+ * the keep draw is the aggregation epilogue's: seed, flat element index); and its backward from
+ * the activated output `act`: d = act > 0 ? grad_out * scale : 0, then as above. */
+int sngnn_blend_forward_epilogue(const float *out0, const float *out1, const float *beta, int64_t n,
+                                 const sngnn_epilogue_t *epi, float *out, void *stream);
+int sngnn_blend_backward_epilogue(const float *grad_out, const float *out0, const float *out1,
+                                  const float *beta, int64_t n, const float *act, float scale,
+                                  float *grad0, float *grad1, float *grad_beta, void *workspace,
+                                  void *stream);
 
 /*
  * The same two gather-sums on any graph, node-range partitions included (multi-GPU

@@ -64,6 +64,8 @@ SIGNATURES = {
     "sngnn_blend_workspace_bytes": (_i64, []),
     "sngnn_blend_forward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "sngnn_blend_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "sngnn_blend_forward_epilogue": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sngnn_blend_backward_epilogue": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_knn_workspace_bytes": (_i64, [_i64, _i32]),
     "sngnn_knn_graph": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -372,8 +372,8 @@ class SNConv_plus_plus(nn.Module):
         return hit[1]
 
     def forward(self, x, edge_index, epilogue=None, act_in=None):
-        """``act_in``: see SNConv.forward.  ``epilogue`` is not taken here (the blend is the last
-        kernel of this layer): ``epilogue.applied`` stays False and the wrapper runs relu / dropout."""
+        """``epilogue`` / ``act_in``: see SNConv.forward; here the BLEND is the layer's last kernel and
+        takes the epilogue (one GPU, no conv bias - i.e. no batch norm flag, models.py:52-53)."""
         if epilogue is not None:
             epilogue.applied = False
         part = sn_dist.current_partition()
@@ -411,6 +411,8 @@ class SNConv_plus_plus(nn.Module):
                                              row_range=(part.row_begin, part.row_end))
                 out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
         out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)
+        if epilogue is not None and part is None and self.bias is None:
+            return ops.blend(out_0, out_1, self.beta, epilogue)
         out = ops.blend(out_0, out_1, self.beta)
         if self.bias is not None:
             out = out + self.bias

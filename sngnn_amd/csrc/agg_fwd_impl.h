@@ -99,22 +99,9 @@ struct FwdArgs {
     const unsigned long long *epi_seed;   // dev [1]: the mask is drawn here, keep = u(seed, i C + c) >= p
     float epi_p;
     float epi_scale;                // 1 / (1 - p) when something is dropped, else 1
-    // counter-based uniform in [0, 1): two rounds of a 32-bit avalanche hash over (seed, element index) -
-    // the same element of the same call gets the same draw in every kernel that asks (main, finalize)
-    static __device__ __forceinline__ unsigned mix32(unsigned x)
+    __device__ __forceinline__ bool drawn_keep(int i, int c) const       // (device_utils.h: sn_dropout_keep)
     {
-        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-        return x;
-    }
-    __device__ __forceinline__ bool drawn_keep(int i, int c) const
-    {
-        const unsigned long long s = *epi_seed, idx = (unsigned long long)i * (unsigned)C + (unsigned)c;
-        // (the seed is hashed first: consecutive seeds must not give masks that are each other's
-        // pairwise swaps, which idx ^ seed alone would)
-        const unsigned k1 = mix32((unsigned)s * 0x9E3779B9u + (unsigned)(s >> 32)), k2 = mix32(k1 ^ 0x85EBCA6Bu);
-        unsigned hsh = mix32((unsigned)idx + k1);
-        hsh = mix32((hsh ^ k2) + 0x9E3779B9u * (unsigned)(idx >> 32));
-        return (float)(hsh >> 8) * 5.9604644775390625e-8f >= epi_p;
+        return sn_dropout_keep(*epi_seed, (unsigned long long)i * (unsigned)C + (unsigned)c, epi_p);
     }
     __device__ __forceinline__ float epilogue(float v, int i, int c) const
     {

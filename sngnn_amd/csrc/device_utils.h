@@ -142,6 +142,26 @@ __device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)
     for (int q = 0; q < NK; ++q) kept[q] = key[q] >= T;      // T > 0 here, so empty slots (key 0) stay out
 }
 
+// ---------------------------------------------------------------------------
+// Dropout drawn in the kernel: keep(seed, element index) = u >= p with u a counter-based uniform
+// in [0, 1) - two rounds of a 32-bit avalanche hash over the (hashed) seed and the flat element
+// index.  The same element of the same call gets the same draw in every kernel that asks (the
+// aggregation's main and finalize kernels, the blend); the seed is hashed first so that
+// consecutive seeds do not give masks that are each other's pairwise swaps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sn_mix32(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool sn_dropout_keep(unsigned long long seed, unsigned long long idx, float p)
+{
+    const unsigned k1 = sn_mix32((unsigned)seed * 0x9E3779B9u + (unsigned)(seed >> 32)), k2 = sn_mix32(k1 ^ 0x85EBCA6Bu);
+    unsigned hsh = sn_mix32((unsigned)idx + k1);
+    hsh = sn_mix32((hsh ^ k2) + 0x9E3779B9u * (unsigned)(idx >> 32));
+    return (float)(hsh >> 8) * 5.9604644775390625e-8f >= p;
+}
+
 // ---- fp32 operands for the bf16 matrix cores --------------------------------------------------
 // A float is the EXACT sum of three bf16 values (truncate to the top 16 bits, subtract, repeat:
 // 8 + 8 + 8 significant bits; every step exact), and a product of two bf16 values is exact in

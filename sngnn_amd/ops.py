@@ -783,42 +783,78 @@ def linear(x: torch.Tensor, lin: torch.nn.Linear) -> torch.Tensor:
 
 
 class _Blend(torch.autograd.Function):
-    """``beta * out_0 + (1 - beta) * out_1`` (models.py:134) in one pass each way."""
+    """``beta * out_0 + (1 - beta) * out_1`` (models.py:134) in one pass each way.  With ``epi`` (a
+    HiddenEpilogue: relu + seeded dropout, no bias) the hidden layer's activation behind the blend
+    (models.py:81-84) is applied in the same store, and undone in the same backward pass."""
 
     @staticmethod
-    def forward(ctx, out0, out1, beta):
+    def forward(ctx, out0, out1, beta, epi=None):
         lib = _lib.load()
         out = torch.empty_like(out0)
+        ctx.epi = epi
         with torch.cuda.device(out0.device):
-            rc = lib.sngnn_blend_forward(out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), out0.numel(),
-                                         out.data_ptr(), _stream(out0.device))
+            if epi is None:
+                rc = lib.sngnn_blend_forward(out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), out0.numel(),
+                                             out.data_ptr(), _stream(out0.device))
+            else:
+                import ctypes
+                epi.scale = 1.0 / (1.0 - epi.p) if epi.drops else 1.0
+                seed = epi.seed if epi.drops else None
+                st = _lib.Epilogue(None, None, float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p), None)
+                rc = lib.sngnn_blend_forward_epilogue(out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), out0.numel(),
+                                                      ctypes.byref(st), out.data_ptr(), _stream(out0.device))
         _lib.check(rc, "sngnn_blend_forward")
-        ctx.save_for_backward(out0, out1, beta)
+        if epi is None:
+            ctx.save_for_backward(out0, out1, beta)
+        else:
+            ctx.save_for_backward(out0, out1, beta, out)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        out0, out1, beta = ctx.saved_tensors
+        epi = ctx.epi
+        act = None
+        if epi is None:
+            out0, out1, beta = ctx.saved_tensors
+        else:
+            out0, out1, beta, out = ctx.saved_tensors
+            if epi.premasked:          # the consumer's store already applied relu' and the dropout mask
+                epi.premasked = False
+            else:
+                act = out
         lib = _lib.load()
         g = g.contiguous()
         g0, g1 = torch.empty_like(g), torch.empty_like(g)
         gbeta = torch.empty_like(beta)
         ws = _workspace("blend", lib.sngnn_blend_workspace_bytes(), g.device)
         with torch.cuda.device(g.device):
-            rc = lib.sngnn_blend_backward(g.data_ptr(), out0.data_ptr(), out1.data_ptr(), beta.data_ptr(),
-                                          g.numel(), g0.data_ptr(), g1.data_ptr(), gbeta.data_ptr(),
-                                          ws.data_ptr(), _stream(g.device))
+            if act is None:
+                rc = lib.sngnn_blend_backward(g.data_ptr(), out0.data_ptr(), out1.data_ptr(), beta.data_ptr(),
+                                              g.numel(), g0.data_ptr(), g1.data_ptr(), gbeta.data_ptr(),
+                                              ws.data_ptr(), _stream(g.device))
+            else:
+                rc = lib.sngnn_blend_backward_epilogue(g.data_ptr(), out0.data_ptr(), out1.data_ptr(), beta.data_ptr(),
+                                                       g.numel(), act.data_ptr(), float(epi.scale), g0.data_ptr(),
+                                                       g1.data_ptr(), gbeta.data_ptr(), ws.data_ptr(), _stream(g.device))
         _lib.check(rc, "sngnn_blend_backward")
-        return g0, g1, gbeta
+        return g0, g1, gbeta, None
 
 
-def blend(out0: torch.Tensor, out1: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+def blend(out0: torch.Tensor, out1: torch.Tensor, beta: torch.Tensor,
+          epilogue: Optional["HiddenEpilogue"] = None) -> torch.Tensor:
     """SNGNN++'s ``beta * out_0 + (1 - beta) * out_1``; fused for contiguous fp32 GPU tensors of
-    one shape with a one-element fp32 ``beta``, the plain expression otherwise."""
-    if (out0.is_cuda and out0.dtype == torch.float32 and out1.dtype == torch.float32 and out0.shape == out1.shape
-            and out0.is_contiguous() and out1.is_contiguous() and beta.numel() == 1
-            and beta.dtype == torch.float32 and beta.is_cuda):
-        return _Blend.apply(out0, out1, beta)
+    one shape with a one-element fp32 ``beta``, the plain expression otherwise.  ``epilogue``: the
+    hidden layer's relu + dropout behind it in the same pass (``epilogue.applied`` says whether the
+    fused kernel took it; needs a seed for the dropout)."""
+    fused = (out0.is_cuda and out0.dtype == torch.float32 and out1.dtype == torch.float32 and out0.shape == out1.shape
+             and out0.is_contiguous() and out1.is_contiguous() and beta.numel() == 1
+             and beta.dtype == torch.float32 and beta.is_cuda)
+    if epilogue is not None:
+        epilogue.applied = fused and (not epilogue.drops or epilogue.seed is not None)
+        if not epilogue.applied:
+            epilogue = None
+    if fused:
+        return _Blend.apply(out0, out1, beta, epilogue)
     return beta * out0 + (1 - beta) * out1
 
 

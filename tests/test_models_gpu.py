@@ -304,7 +304,8 @@ def test_real_actor_published_hyperparameters(cuda):
     ("SNGNN_Plus", dict(hidden=64, layers=2, top_k=1, thr=0.0, rem=1, classes=40)),      # the training scripts' shape
     ("SNGNN_Plus", dict(hidden=32, layers=3, top_k=16, thr=0.2, rem=0, classes=7)),      # 32 -> 32: row-tile gx, mask left to the producer
     ("SNGNN", dict(hidden=24, layers=2, classes=5)),                                     # conv bias in the epilogue, no selection
-    ("SNGNN_Plus_Plus", dict(hidden=32, layers=2, top_k=4, thr=0.0, rem=1, classes=6)),  # blend last: wrapper falls back
+    ("SNGNN_Plus_Plus", dict(hidden=32, layers=2, top_k=4, thr=0.0, rem=1, classes=6)),  # the blend takes the epilogue
+    ("SNGNN_Plus_Plus", dict(hidden=20, layers=3, top_k=16, thr=0.1, rem=0, classes=9)),
 ])
 def test_fused_hidden_epilogue_equals_the_op_sequence(cuda, kind, args):
     """models.py:204-209's relu_ + dropout between two conv layers as the aggregation's store
