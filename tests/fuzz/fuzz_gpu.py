@@ -147,6 +147,46 @@ while time.time() < t_end:
             # db is a signed sum over all rows: fp64 truth, tolerance from the terms' size
             ge = (bg.grad.cpu().double() - gout.double().sum(0)).abs()
             assert (ge <= 2e-6 * gout.double().abs().sum(0) + 1e-7).all(), f"adj db err {ge.max():.3e}"
+        # --- GGCN's sparse signed-attention layer (models.py:1453-1553) on a symmetric normalised adjacency
+        if n >= 3 and C <= 130 and n <= 400:
+            from sngnn_amd.ggcn import GGCNlayer_SP
+            a = torch.zeros(n, n)
+            if ei.numel():
+                a[ei[1], ei[0]] = 1.0
+            a = ((a + a.t()) > 0).float()
+            a.fill_diagonal_(1.0)
+            dgr = a.sum(1)
+            adj = (a / torch.sqrt(dgr[:, None] * dgr[None, :])).to_sparse().coalesce()
+            dp = O.ggcn_degree_precompute(adj)
+            fin = int(rng.integers(2, 24))
+            kw = dict(use_degree=bool(rng.integers(0, 2)), use_decay=bool(rng.integers(0, 2)))
+            torch.manual_seed(seed)
+            lr = O.GGCNlayer_SP(fin, C, "cpu", **kw)
+            with torch.no_grad():
+                lr.coeff.copy_(torch.randn(3, generator=gen))
+                if kw["use_degree"]:
+                    lr.deg_coeff.copy_(torch.tensor([0.6, 0.1]))
+            lg = GGCNlayer_SP(fin, C, dev, **kw)
+            lg.load_state_dict(lr.state_dict())
+            lg = lg.to(dev)
+            xin = torch.randn(n, fin, generator=gen)
+            xr, xg = xin.clone().requires_grad_(True), xin.to(dev).requires_grad_(True)
+            outr = lr(xr, adj, dp)
+            (outr * gout).sum().backward()
+            outg = lg(xg, adj.to(dev), dp.to(dev))
+            (outg * gout.to(dev)).sum().backward()
+            sc = float(outr.detach().abs().max()) + 1e-6
+            assert float((outg.detach().cpu() - outr.detach()).abs().max()) <= 2e-5 * sc, "ggcn out"
+            gs = float(xr.grad.abs().max()) + 1e-9
+            # (C == 1: every cosine is +-1 and d cos / d Wh is exactly 0 - what both sides compute there is
+            # rounding noise times 1 / |Wh|, as in the attention mode above)
+            assert C == 1 or float((xg.grad.cpu() - xr.grad).abs().max()) <= 5e-5 * gs, "ggcn grad_h"
+            for (kname, pg), (_, pr) in zip(lg.named_parameters(), lr.named_parameters()):
+                if C == 1:
+                    break
+                scp = max(float(pr.grad.abs().max()), 1e-6)
+                tol = 5e-5 * scp if pr.grad.numel() > 3 else 5e-5 * scp + 2e-5 * sc
+                assert float((pg.grad.cpu() - pr.grad).abs().max()) <= tol, f"ggcn grad {kname}"
     except Exception as ex:      # noqa: BLE001
         print("FAIL", tag, "->", repr(ex)[:500], flush=True)
         sys.exit(1)

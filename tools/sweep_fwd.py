@@ -34,6 +34,9 @@ if os.environ.get("FILTER") is not None:          # A/B of the fp16 filter (csrc
 if os.environ.get("ROLES") is not None:           # only some row classes of the main kernel (timing only)
     lib.sngnn_tuning_set(0, int(os.environ["ROLES"]))
     print("role mask", os.environ["ROLES"], "(1 tasks, 2 wave rows, 4 small rows)")
+if os.environ.get("TABLE") is not None:           # how sngnn_agg_forward scores: 0 auto, 1 unit-row table always, 2 on the fly always
+    lib.sngnn_tuning_set(2, int(os.environ["TABLE"]))
+    print("scoring mode", os.environ["TABLE"], "(0 auto, 1 table, 2 on the fly)")
 for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
     res, wall = [], []
     for rnd in range(int(os.environ.get("ROUNDS", 4))):
