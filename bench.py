@@ -471,6 +471,37 @@ def main():
             torch.cuda.synchronize()
             batches.append((time.perf_counter() - t0) / 10 * 1e3)
         result["fwd_bwd_ms"] = float(np.median(batches))
+        # the same pair replayed from a HIP graph: the eager figure above is bound by the HOST on most
+        # boxes (one autograd round trip costs ~200 us of Python / engine time against ~130 us of GPU
+        # work: tools/host_overhead.py), this one by the device
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    hg.grad = None
+                    ops.aggregate(hg, graph, args.top_k, args.thr).backward(gout)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            hg.grad = None
+            with torch.cuda.graph(cg, stream=side):
+                ops.aggregate(hg, graph, args.top_k, args.thr).backward(gout)
+            for _ in range(5):
+                cg.replay()
+            torch.cuda.synchronize()
+            batches = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    cg.replay()
+                torch.cuda.synchronize()
+                batches.append((time.perf_counter() - t0) / 20 * 1e3)
+            result["fwd_bwd_graphed_ms"] = float(np.median(batches))
+            del cg
+        except Exception as ex:      # noqa: BLE001  (a secondary figure: never fail the line for it)
+            result["fwd_bwd_graphed_ms"] = None
+            result["fwd_bwd_graphed_note"] = repr(ex)[:200]
         result["roofline_bwd"] = backward_roofline(ops, graph, h_local, gout, args.top_k, args.thr, e_prime, n, c)
         if not args.no_epoch:
             from sngnn_amd.train import epoch_time_ms
