@@ -154,37 +154,71 @@ __global__ __launch_bounds__(BLOCK) void k_attn_fwd(const AttnArgs a)
 }
 
 // split rows: l_i and the weighted sum over the row's tasks (fixed order), then the
-// row's exp(s_e) become alpha_e
-static __global__ __launch_bounds__(256) void k_attn_fin(const AttnArgs a)
+// row's exp(s_e) become alpha_e.  One 1024-thread workgroup per row; every step is wide - the
+// first version summed l with ONE thread (a hub's ~100 partials as a serial chain of loads) and
+// rewrote alpha one element per thread and trip: 34.5 us per forward at arxiv size (r04 epoch
+// profile), most of it the 13 k-edge hub's latency chain.
+constexpr int AFIN_BLOCK = 1024, AFIN_WAVES = AFIN_BLOCK / 64;
+
+// sum of v over the workgroup in a fixed order (lanes by shuffle, waves in wave order); every thread gets it
+__device__ __forceinline__ float afin_block_sum(float v, float *s_red)
 {
-    __shared__ float s[4][64];
-    __shared__ float s_l;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    __syncthreads();                                   // (s_red may still be read from the previous use)
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < AFIN_WAVES; ++w) tot += s_red[w];
+    return tot;
+}
+
+static __global__ __launch_bounds__(AFIN_BLOCK) void k_attn_fin(const AttnArgs a)
+{
+    __shared__ float s[AFIN_WAVES][64];
+    __shared__ float s_red[AFIN_WAVES];
     const int p = blockIdx.x;
     const int4 d = a.rdesc[p];
     const int i = d.x, rs = d.y, deg = d.z;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const size_t stride = (size_t)a.C + 4;
-    if (threadIdx.x == 0) {
-        float l = 0.f;
-        for (int t = t0; t < t1; ++t) l += a.partial[t * stride + a.C];
-        s_l = l;
-    }
-    __syncthreads();
-    const float l = s_l;
+    float lp = 0.f;
+    for (int t = t0 + (int)threadIdx.x; t < t1; t += AFIN_BLOCK) lp += a.partial[t * stride + a.C];
+    const float l = afin_block_sum(lp, s_red);
     for (int c0 = 0; c0 < a.C; c0 += 64) {
         const int c = c0 + cl;
         float v = 0.f;
         if (c < a.C)
-            for (int t = t0 + q; t < t1; t += 4) v += a.partial[t * stride + c];
+            for (int t = t0 + q; t < t1; t += AFIN_WAVES) v += a.partial[t * stride + c];
         s[q][cl] = v;
         __syncthreads();
-        if (q == 0 && c < a.C)
-            a.out[(size_t)i * a.C + c] = ((s[0][cl] + s[1][cl]) + (s[2][cl] + s[3][cl])) / l;
+        if (q == 0 && c < a.C) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < AFIN_WAVES; ++w) tot += s[w][cl];
+            a.out[(size_t)i * a.C + c] = tot / l;
+        }
         __syncthreads();
     }
-    if (a.alpha)
-        for (int t = threadIdx.x; t < deg; t += 256) a.alpha[rs + t] = a.alpha[rs + t] / l;
+    if (a.alpha) {
+        // eight elements per thread in flight (loads first, then the stores: the array aliases itself)
+        float *al = a.alpha + rs;
+        for (int base = 0; base < deg; base += 8 * AFIN_BLOCK) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = base + u * AFIN_BLOCK + (int)threadIdx.x;
+                v[u] = t < deg ? al[t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = base + u * AFIN_BLOCK + (int)threadIdx.x;
+                if (t < deg) al[t] = v[u] / l;
+            }
+        }
+    }
 }
 
 template <int VEC, int G, int R> int launch_attn_fwd(const AttnArgs &a0, hipStream_t st)
@@ -195,7 +229,7 @@ template <int VEC, int G, int R> int launch_attn_fwd(const AttnArgs &a0, hipStre
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
     const int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
     if (a.nbA + a.nbB + nbC > 0) k_attn_fwd<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
-    if (a.n_split > 0) k_attn_fin<<<a.n_split, 256, 0, st>>>(a);
+    if (a.n_split > 0) k_attn_fin<<<a.n_split, AFIN_BLOCK, 0, st>>>(a);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
@@ -336,29 +370,56 @@ __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t(const BwdArgs a)
     else attn_t_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
 }
 
-static __global__ __launch_bounds__(256) void k_attn_bwd_t_fin(const BwdArgs a)
+// Split rows after the tasks.  The first version was one 256-thread workgroup per row that summed
+// dot_i with ONE thread and rewrote the row's records one per thread and trip behind a
+// csc_pos -> record chain: 68 us per backward at arxiv size (r04 epoch profile), the 13 k-edge hub's
+// latency chain.  Now one launch, two roles, both task-wide: workgroups [0, n_split) sum the
+// partial rows of one split row into dnT; the others take one TASK per wave and turn its 128
+// records' raw t_e into ds_e.  Every wave derives dot_i itself from the row's task partials
+// (attn_row_dot: the same fixed order everywhere, so dnT and the records use the same bits).
+__device__ __forceinline__ float attn_row_dot(const BwdArgs &a, int t0, int t1, size_t stride)
 {
-    __shared__ float sA[4][64], sB[4][64];
-    __shared__ float s_dot;
+    float dp = 0.f;
+    for (int t = t0 + lane_id(); t < t1; t += 64) dp += a.partT[t * stride + 2 * a.C];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dp += __shfl_xor(dp, m, 64);
+    return dp;
+}
+
+static __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t_fin(const BwdArgs a)
+{
+    __shared__ float sA[WAVES][64], sB[WAVES][64];
+    const size_t stride = 2 * (size_t)a.C + 4;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= a.n_split) {
+        const int tq = ((int)blockIdx.x - a.n_split) * WAVES + q;
+        if (tq >= a.n_tasks) return;
+        const int p = a.task_slot[tq];
+        const int i = a.rperm[p];
+        const int rs = a.rowptr[i];
+        const int e0 = a.task_chunk[tq] * CHUNK;
+        const int n = min(a.rowptr[i + 1] - rs - e0, CHUNK);
+        const float dot = attn_row_dot(a, a.split_task0[p], a.split_task0[p + 1], stride);
+        int cp[CHUNK / 64];
+        float2 rec[CHUNK / 64];
+#pragma unroll
+        for (int u = 0; u < CHUNK / 64; ++u) cp[u] = cl + 64 * u < n ? a.csc_pos[rs + e0 + cl + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < CHUNK / 64; ++u) rec[u] = cp[u] >= 0 ? a.wd[cp[u]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < CHUNK / 64; ++u)
+            if (cp[u] >= 0) a.wd[cp[u]] = make_float2(rec[u].x, rec[u].x * (rec[u].y - dot));
+        return;
+    }
     const int p = blockIdx.x;
     const int i = a.rperm[p];
-    const int rs = a.rowptr[i];
-    const int deg = a.rowptr[i + 1] - rs;
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const size_t stride = 2 * (size_t)a.C + 4;
-    if (threadIdx.x == 0) {
-        float dsum = 0.f;
-        for (int t = t0; t < t1; ++t) dsum += a.partT[t * stride + 2 * a.C];
-        s_dot = dsum;
-    }
-    __syncthreads();
-    const float dot = s_dot;
+    const float dot = attn_row_dot(a, t0, t1, stride);
     for (int c0 = 0; c0 < a.C; c0 += 64) {
         const int c = c0 + cl;
         float va = 0.f, vb = 0.f;
         if (c < a.C)
-            for (int t = t0 + q; t < t1; t += 4) {
+            for (int t = t0 + q; t < t1; t += WAVES) {
                 va += a.partT[t * stride + c];
                 vb += a.partT[t * stride + a.C + c];
             }
@@ -366,17 +427,12 @@ static __global__ __launch_bounds__(256) void k_attn_bwd_t_fin(const BwdArgs a)
         sB[q][cl] = vb;
         __syncthreads();
         if (q == 0 && c < a.C) {
-            const float A = (sA[0][cl] + sA[1][cl]) + (sA[2][cl] + sA[3][cl]);
-            const float B = (sB[0][cl] + sB[1][cl]) + (sB[2][cl] + sB[3][cl]);
+            float A = 0.f, B = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) { A += sA[w][cl]; B += sB[w][cl]; }
             a.dnT[(size_t)i * a.C + c] = fmaf(-dot, B, A);
         }
         __syncthreads();
-    }
-    for (int t = threadIdx.x; t < deg; t += 256) {
-        const int cp = a.csc_pos[rs + t];
-        float2 rec = a.wd[cp];
-        rec.y = rec.x * (rec.y - dot);
-        a.wd[cp] = rec;
     }
 }
 
@@ -388,7 +444,7 @@ template <int VEC, int G, int R> int launch_attn_bwd(const BwdArgs &a0, hipStrea
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
     int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
     if (a.nbA + a.nbB + nbC > 0) k_attn_bwd_t<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
-    if (a.n_split > 0) k_attn_bwd_t_fin<<<a.n_split, 256, 0, st>>>(a);
+    if (a.n_split > 0) k_attn_bwd_t_fin<<<a.n_split + ceil_div(a.n_tasks, WAVES), BLOCK, 0, st>>>(a);
     // pass S: the aggregation's kernels (every edge kept, weight alpha_e, no mean division)
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);

@@ -23,6 +23,10 @@ CASES = [
     (300, 2000, 300, ((4, 200),)),
     (1500, 20000, 40, ((0, 1499), (1, 900), (2, 129), (3, 128), (4, 17), (5, 16))),
     (300, 2000, 512, ((4, 200),)),
+    # a 12 000-edge row: more than one trip of the split-row finalizes' batched rewrites (8 x 1024
+    # alpha values / 4 x 1024 records a trip), and > 1024 tasks' partials summed across the workgroup
+    (20000, 60000, 8, ((0, 12000), (1, 5000), (2, 4097))),
+    (140000, 200000, 3, ((7, 135000),)),
 ]
 
 
