@@ -362,7 +362,7 @@ class SNConv_plus_plus(nn.Module):
                     # ranks may hold different subsets of the edges: the shift is a property of the
                     # WHOLE list, so every rank must arrive at the same value (and raise together)
                     m = m.clone()
-                    if sn_dist._is_gloo(m, part.group):
+                    if sn_dist._host_staged(m, part.group):
                         m = m.cpu()
                     torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MIN, group=part.group)
                 m = int(m)

@@ -122,10 +122,14 @@ def current_partition() -> Optional[Partition]:
     return _current
 
 
-def _is_gloo(t: torch.Tensor, group=None) -> bool:
-    # gloo (CPU tests, and multi-rank rehearsals on a box with fewer GPUs than ranks) has neither
-    # reduce_scatter nor all_to_all: point-to-point / list all-gather forms instead
-    return (not t.is_cuda) or dist.get_backend(group) == "gloo"
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """Whether the collective on ``t`` has to go through host copies: gloo moves host memory only,
+    so a multi-rank REHEARSAL on a box with fewer GPUs than ranks (GPU tensors, gloo group) stages
+    its buffers.  The collectives themselves are the same calls on every backend - RCCL on GPU
+    tensors, gloo on CPU tensors (the world-2 CPU tests) and gloo on staged copies all run
+    ``all_to_all_single`` / ``all_gather_into_tensor`` / ``reduce_scatter_tensor``: the CPU tests
+    execute the branch the GPUs execute."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
 # ---------------------------------------------------------------------------
@@ -136,40 +140,20 @@ def _all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts
     """``send`` = [sum(send_counts), C] row blocks ordered by destination rank; returns the
     [sum(recv_counts), C] blocks ordered by source rank."""
     c = send.size(1)
-    recv = send.new_empty((int(sum(recv_counts)), c))
-    if not _is_gloo(send, part.group):
-        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(map(int, recv_counts)),
-                               input_split_sizes=list(map(int, send_counts)), group=part.group)
-        return recv
-    # gloo: point-to-point, staged through host memory for GPU tensors
-    dev = send.device
-    s_host = send.detach().cpu().contiguous() if send.is_cuda else send.contiguous()
-    r_host = torch.empty(recv.shape, dtype=recv.dtype) if send.is_cuda else recv
-    s_off = [0]
-    for n in send_counts:
-        s_off.append(s_off[-1] + int(n))
-    r_off = [0]
-    for n in recv_counts:
-        r_off.append(r_off[-1] + int(n))
-    r_host[r_off[part.rank]:r_off[part.rank + 1]] = s_host[s_off[part.rank]:s_off[part.rank + 1]]
-    ops = []
-    for p in range(part.world):
-        if p == part.rank:
-            continue
-        if send_counts[p]:
-            ops.append(dist.P2POp(dist.isend, s_host[s_off[p]:s_off[p + 1]], p, part.group))
-        if recv_counts[p]:
-            ops.append(dist.P2POp(dist.irecv, r_host[r_off[p]:r_off[p + 1]], p, part.group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    return r_host.to(dev) if send.is_cuda else r_host
+    staged = _host_staged(send, part.group)
+    s = send.detach().contiguous()
+    if staged:
+        s = s.cpu()
+    recv = s.new_empty((int(sum(recv_counts)), c))
+    dist.all_to_all_single(recv, s, output_split_sizes=list(map(int, recv_counts)),
+                           input_split_sizes=list(map(int, send_counts)), group=part.group)
+    return recv.to(send.device) if staged else recv
 
 
 def _exchange_counts(counts: torch.Tensor, part: Partition) -> torch.Tensor:
     """counts[p] = what I send to p  ->  what p sends to me (int64 [world])."""
     mine = counts.to(torch.int64)
-    if _is_gloo(mine, part.group):
+    if _host_staged(mine, part.group):
         mine = mine.cpu()
     gathered = [torch.empty_like(mine) for _ in range(part.world)]
     dist.all_gather(gathered, mine, group=part.group)
@@ -246,14 +230,13 @@ def start_halo_exchange(table: torch.Tensor, plan: HaloPlan) -> _Pending:
     """Send the own rows the peers asked for and receive this rank's halo rows STRAIGHT INTO
     ``table[n_local:]``; the own rows must already be in ``table[:n_local]``.  RCCL: one
     ``all_to_all_single`` issued asynchronously - kernels launched before ``wait()`` overlap it.
-    (gloo: the point-to-point form, complete on return.)"""
+    (GPU tensors on a gloo group - rehearsals - are staged through the host and complete on return.)"""
     part = plan.part
     own = table[:plan.n_local]
     send = own.index_select(0, plan.send_idx)
     halo = table[plan.n_local:]
-    if _is_gloo(table, part.group):
-        if plan.n_halo or send.size(0):
-            halo.copy_(_all_to_all_rows(send, plan.send_counts, plan.recv_counts, part))
+    if _host_staged(table, part.group):
+        halo.copy_(_all_to_all_rows(send, plan.send_counts, plan.recv_counts, part))
         return _Pending()
     work = dist.all_to_all_single(halo, send, output_split_sizes=plan.recv_counts,
                                   input_split_sizes=plan.send_counts, group=part.group, async_op=True)
@@ -380,28 +363,42 @@ class _AllGatherRows(torch.autograd.Function):
         ctx.part = part
         h_local = h_local.contiguous()
         sizes, c = part.sizes, h_local.size(1)
-        if _is_gloo(h_local, part.group) or len(set(sizes)) > 1:
-            # uneven shards (or gloo): pad to the largest shard, gather, drop the padding
+        staged = _host_staged(h_local, part.group)
+        src = h_local.cpu() if staged else h_local
+        if len(set(sizes)) > 1:
+            # uneven shards: pad to the largest shard, gather, drop the padding
             mx = max(sizes)
-            pad = h_local.new_zeros((mx, c))
-            pad[:part.n_local] = h_local
-            chunks = [torch.empty_like(pad) for _ in range(part.world)]
-            dist.all_gather(chunks, pad, group=part.group)
-            return torch.cat([ch[:n] for ch, n in zip(chunks, sizes)], dim=0)
-        full = h_local.new_empty((part.n_total, c))
-        dist.all_gather_into_tensor(full, h_local, group=part.group)
-        return full
+            pad = src.new_zeros((mx, c))
+            pad[:part.n_local] = src
+            packed = src.new_empty((part.world * mx, c))
+            dist.all_gather_into_tensor(packed, pad, group=part.group)
+            full = torch.cat([packed[r * mx:r * mx + n] for r, n in enumerate(sizes)], dim=0)
+        else:
+            full = src.new_empty((part.n_total, c))
+            dist.all_gather_into_tensor(full, src, group=part.group)
+        return full.to(h_local.device) if staged else full
 
     @staticmethod
     def backward(ctx, grad_full):
         part = ctx.part
-        grad_full = grad_full.contiguous()
-        if _is_gloo(grad_full, part.group) or len(set(part.sizes)) > 1:
-            dist.all_reduce(grad_full, group=part.group)
-            return grad_full[part.row_begin:part.row_end].clone(), None
-        out = grad_full.new_empty((part.n_local, grad_full.size(1)))
-        dist.reduce_scatter_tensor(out, grad_full, group=part.group)
-        return out, None
+        staged = _host_staged(grad_full, part.group)
+        g = grad_full.contiguous().cpu() if staged else grad_full.contiguous()
+        sizes, c = part.sizes, g.size(1)
+        if len(set(sizes)) > 1:
+            # uneven shards: every rank's block padded to the largest shard, then the same reduce-scatter
+            mx = max(sizes)
+            packed = g.new_zeros((part.world * mx, c))
+            off = 0
+            for r, n in enumerate(sizes):
+                packed[r * mx:r * mx + n] = g[off:off + n]
+                off += n
+            red = g.new_empty((mx, c))
+            dist.reduce_scatter_tensor(red, packed, group=part.group)
+            out = red[:part.n_local].clone()
+        else:
+            out = g.new_empty((part.n_local, c))
+            dist.reduce_scatter_tensor(out, g, group=part.group)
+        return (out.to(grad_full.device) if staged else out), None
 
 
 def all_gather_rows(h_local: torch.Tensor, part: Partition) -> torch.Tensor:

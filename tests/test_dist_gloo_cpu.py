@@ -93,10 +93,15 @@ def _worker(rank, world, port, bounds, C, k, thr, exchange, q):
     dist.destroy_process_group()
 
 
+# uneven ranges (61 nodes: nothing divides; the padded all-gather / reduce-scatter), even ranges (the
+# plain all_gather_into_tensor / reduce_scatter_tensor), three ranks of which one owns NO node
+# (zero-row blocks in every collective)
+@pytest.mark.parametrize("bounds", [(0, 37, 61), (0, 30, 60), (0, 25, 25, 61)], ids=["uneven", "even", "empty_rank"])
 @pytest.mark.parametrize("exchange", ["halo", "allgather"])
-def test_partitioned_aggregation_equals_single_process(exchange):
-    world, port = 2, _free_port()
-    bounds = (0, 37, 61)                        # uneven ranges, 61 nodes: nothing divides
+def test_partitioned_aggregation_equals_single_process(exchange, bounds):
+    """The collectives are the calls the GPUs make (all_to_all_single with split sizes,
+    all_gather_into_tensor, reduce_scatter_tensor): sngnn_amd/dist.py has one branch for every backend."""
+    world, port = len(bounds) - 1, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, bounds, 6, 3, 0.0, exchange, q))
@@ -107,7 +112,7 @@ def test_partitioned_aggregation_equals_single_process(exchange):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[:3] for r in res] == [(0, True, True), (1, True, True)]
+    assert [r[:3] for r in res] == [(r, True, True) for r in range(world)]
 
 
 def _bn_worker(rank, world, port, bounds, q):
