@@ -128,7 +128,19 @@ while time.time() < t_end:
         if C > 1:      # C == 1: d cos / d h is exactly 0; what is left is rounding noise / |h|
             sc = hr2.grad.abs().max().clamp_min(1e-20)
             ge = (ha.grad.cpu() - hr2.grad).abs().max()
-            assert ge <= 5e-5 * sc, f"attn grad err {ge:.3e} scale {sc:.3e}"
+            if not ge <= 5e-5 * sc:
+                # A zero row puts 1 / eps = 1e12 in front of a cancellation residue (seed 771212: h[0] = 0, its
+                # gradient 1.3e6 = 1e12 x a 1.3e-6 left over from terms four digits larger; against float64
+                # the fp32 oracle is 5e-5 of that scale away, these kernels 4e-4): that row's gradient is
+                # rounding noise times 1e12 on either side.  Judge every OTHER row, against float64.
+                h64 = h.double().clone().requires_grad_(True)
+                r64 = O.attention_reference(h64, ei)
+                (r64["out"] * gout.double()).sum().backward()
+                live = h.abs().sum(1) > 0
+                assert not bool(live.all()), f"attn grad err {ge:.3e} scale {sc:.3e}"
+                ge64 = (ha.grad.cpu().double() - h64.grad)[live].abs().max()
+                sc64 = h64.grad[live].abs().max().clamp_min(1e-20)
+                assert ge64 <= 5e-5 * sc64, f"attn grad err vs f64 {ge64:.3e} scale {sc64:.3e} (zero rows left out)"
         # --- SNGNN++ adjacency branch (models.py:124-130) on the same edge list
         eip = O.sn_edge_list(ei, n, True, rem)
         if eip.size(1) > 0 and C <= 64:
