@@ -213,7 +213,29 @@ typedef struct sngnn_epilogue {
                             /* sngnn_agg_backward_bits, instead of wsel + a packing launch in the backward;  */
                             /* only where sngnn_agg_kept_bits_supported(g, top_k); an all-zero struct with   */
                             /* this field set is a plain forward that saves the bits                         */
+    /* The classification head of the LAST layer inside the forward's own launches (round 4; NULL
+     * head_y = off): what the wrappers do to the last conv's output - log_softmax (models.py:86,211,
+     * 303) - and what the harness does to that - nll_loss on a mask and the accuracy count
+     * (train.py:81-84, 98-102, 112-116).  The rows go through it in the forward's SECOND launch: the
+     * split rows in their finalize, all others read back by extra workgroups of that launch, which is
+     * otherwise a latency chain on an idle chip - instead of two more launches behind it
+     * (sngnn_head_nll / _nll2, which compute the same per-row bits).  `bias` (the conv's) is added
+     * first; relu / keep / seed must be off.  Needs sngnn_agg_head_supported.                        */
+    const int64_t *head_y;          /* dev int64 [N] labels                                                      */
+    const unsigned char *head_sel;  /* dev u8 [N]: head_sets == 1: != 0 marks the split's rows; == 2: bit 0 = in */
+                                    /* split A, bit 1 = in split B (validation and test off ONE forward)          */
+    int head_sets;                  /* 1 or 2                                                                    */
+    int head_out_mode;              /* what `out` holds afterwards: 1 the logits (mean rows + bias), 2 d(mean    */
+                                    /* NLL of the split) / d logits, zero rows outside it (head_sets == 1):     */
+                                    /* the tensor the backward starts from                                     */
+    int64_t head_n_a, head_n_b;     /* rows in split A / B: the means' denominators                              */
+    float *head_metrics;            /* dev f32 [2 * head_sets]: (mean NLL, correct count) per split              */
+    void *head_workspace;           /* dev, sngnn_agg_head_workspace_bytes(g) bytes                              */
 } sngnn_epilogue_t;
+int64_t sngnn_agg_head_workspace_bytes(const sngnn_graph_t *g);
+/* 1 if a forward on this graph at this width / top_k can take the head epilogue (C % 4 == 0, C <= 64, the
+ * split rows on the candidate finalize), else 0 */
+int sngnn_agg_head_supported(const sngnn_graph_t *g, int C, int top_k);
 int sngnn_agg_forward_epilogue(const sngnn_graph_t *g, const float *h, int C, int top_k, float thr,
                                const sngnn_epilogue_t *epi, float *out, float *wsel, float *inv_norm,
                                void *workspace, void *stream);

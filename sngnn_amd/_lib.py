@@ -55,6 +55,8 @@ SIGNATURES = {
     "sngnn_agg_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_agg_backward_topk": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_agg_kept_bits_supported": (_i32, [_vp, _i32, _i32]),
+    "sngnn_agg_head_supported": (_i32, [_vp, _i32, _i32]),
+    "sngnn_agg_head_workspace_bytes": (_i64, [_vp]),
     "sngnn_graph_kept_bits_bytes": (_i64, [_vp]),
     "sngnn_agg_backward_bits": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_attn_forward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
@@ -96,7 +98,10 @@ SIGNATURES = {
 class Epilogue(C.Structure):
     """``sngnn_epilogue_t`` (include/sngnn_hip.h)."""
     _fields_ = [("bias", C.c_void_p), ("keep", C.c_void_p), ("keep_scale", C.c_float), ("relu", C.c_int),
-                ("seed", C.c_void_p), ("p", C.c_float), ("kept_bits", C.c_void_p)]
+                ("seed", C.c_void_p), ("p", C.c_float), ("kept_bits", C.c_void_p),
+                ("head_y", C.c_void_p), ("head_sel", C.c_void_p), ("head_sets", C.c_int), ("head_out_mode", C.c_int),
+                ("head_n_a", C.c_int64), ("head_n_b", C.c_int64), ("head_metrics", C.c_void_p),
+                ("head_workspace", C.c_void_p)]
 
 
 _lib = None

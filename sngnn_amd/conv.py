@@ -108,6 +108,17 @@ def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
     return out if out.size(1) == c else out[:, :c]
 
 
+def _fuse_head(head, graph, h: torch.Tensor, c: int, shard, top_k) -> bool:
+    """Whether this (last) layer's rows go through the classification head inside the aggregation's launches
+    (ops.HeadEpilogue): one GPU, unpadded rows of 16-byte vectors, at most 64 classes, a graph whose
+    split rows take the candidate finalize."""
+    ok = (head is not None and shard is None and h.is_cuda and h.size(1) == c and c % 4 == 0 and c <= 64
+          and ops.head_supported(graph, c, top_k))
+    if head is not None:
+        head.applied = ok
+    return ok
+
+
 def _fuse_epilogue(epilogue, h: torch.Tensor, c: int, shard) -> bool:
     """Whether this layer's output takes the fused store epilogue (ops.HiddenEpilogue): one GPU,
     no channel padding (the bias and the keep mask are [.., C] of the layer's own width)."""
@@ -148,13 +159,16 @@ class SNConv(nn.Module):
         if self.bias is not None:        # PyG inits.zeros(None) is a no-op
             self.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, epilogue=None, act_in=None):
+    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None):
         """``epilogue`` / ``act_in`` (both optional, the model wrappers' business): fuse the relu +
         dropout that follow this layer into its stores / tell ``lin`` that ``x`` is such an output
-        (ops.HiddenEpilogue).  ``epilogue.applied`` says whether the layer did."""
+        (ops.HiddenEpilogue).  ``epilogue.applied`` says whether the layer did.  ``head`` (the LAST
+        layer): the classification head inside the aggregation's launches (ops.HeadEpilogue; ``head.applied``)."""
         graph, shard = _graph_for(x, edge_index, True, False)
         # (no selection: the aggregation scores straight from h - no unit rows wanted from lin)
         h, c, table = _lin_aligned(x, self.lin, shard, None, act_in)
+        if _fuse_head(head, graph, h, c, shard, None):
+            return ops.aggregate(h, graph, None, 0.0, None, None, self.bias, head)
         if _fuse_epilogue(epilogue, h, c, shard):
             return ops.aggregate(h, graph, None, 0.0, None, epilogue, self.bias)
         out = _true_width(_aggregate(h, graph, shard, None, 0.0, table), c)
@@ -212,11 +226,13 @@ class SNConv_plus(nn.Module):
         if self.bias is not None:
             self.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, epilogue=None, act_in=None):
-        """``epilogue`` / ``act_in``: see SNConv.forward."""
+    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None):
+        """``epilogue`` / ``act_in`` / ``head``: see SNConv.forward."""
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         unit = _unit_for(self.lin, graph, self.top_k, self.thr)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        if _fuse_head(head, graph, h, c, shard, int(self.top_k)):
+            return ops.aggregate(h, graph, int(self.top_k), float(self.thr), unit, None, self.bias, head)
         if _fuse_epilogue(epilogue, h, c, shard):
             return ops.aggregate(h, graph, int(self.top_k), float(self.thr), unit, epilogue, self.bias)
         out = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)

@@ -176,11 +176,33 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.role_mask = g_role_mask;
     a.row_flag = row_flag; a.row_want = row_want;
     a.epi_flags = 0; a.epi_bias = nullptr; a.epi_keep = nullptr; a.epi_seed = nullptr; a.epi_p = 0.f; a.epi_scale = 1.0f;
+    a.head_y = nullptr; a.head_sel = nullptr; a.head_part = nullptr; a.head_flags = 0; a.head_nmain = 0;
+    a.head_scale = a.head_scale_b = 0.f; a.head_out = nullptr;
     a.kbits = nullptr; a.kb_wbase = (int)g->kb_wbase; a.kb_tbase = (int)g->kb_tbase;
     if (epi && epi->kept_bits) {
         SN_REQUIRE(sngnn::kept_bits_path(g, top_k) && row_flag == nullptr && nrm != nullptr, SNGNN_EINVAL,
                    "no kept-bit path for this graph / top_k (sngnn_agg_kept_bits_supported)");
         a.kbits = (unsigned *)epi->kept_bits;
+    }
+    const bool head = epi != nullptr && epi->head_y != nullptr;
+    if (head) {
+        SN_REQUIRE(cfg.vec == 4 && cfg.r == 1 && cfg.g <= 16, SNGNN_EINVAL,
+                   "the head epilogue needs C % 4 == 0 and C <= 64 (sngnn_agg_head_supported)");
+        SN_REQUIRE(epi->head_sel && epi->head_metrics && epi->head_workspace, SNGNN_EINVAL,
+                   "head_sel / head_metrics / head_workspace is NULL");
+        SN_REQUIRE(epi->head_sets == 1 || epi->head_sets == 2, SNGNN_EINVAL, "head_sets must be 1 or 2");
+        SN_REQUIRE((epi->head_out_mode == 1 || epi->head_out_mode == 2) && (epi->head_out_mode != 2 || epi->head_sets == 1),
+                   SNGNN_EINVAL, "head_out_mode: 1 logits, 2 gradient (one split only)");
+        SN_REQUIRE(out != nullptr, SNGNN_EINVAL, "out is NULL");
+        SN_REQUIRE(!epi->relu && epi->keep == nullptr && epi->seed == nullptr, SNGNN_EINVAL,
+                   "the head follows the LAST layer: no relu / dropout with it");
+        SN_REQUIRE(row_flag == nullptr && sel_src == nullptr, SNGNN_EINVAL,
+                   "the head epilogue covers all rows of a call and emits no selection lists");
+        a.head_y = epi->head_y; a.head_sel = epi->head_sel;
+        a.head_part = (float *)epi->head_workspace; a.head_out = epi->head_metrics;
+        a.head_flags = (epi->head_sets == 2 ? 1 : 0) | (epi->head_out_mode == 2 ? 2 : 0);
+        a.head_scale = 1.0f / (float)(epi->head_n_a > 0 ? epi->head_n_a : 1);
+        a.head_scale_b = 1.0f / (float)(epi->head_n_b > 0 ? epi->head_n_b : 1);
     }
     if (epi) {
         a.epi_bias = epi->bias; a.epi_keep = epi->keep;
@@ -220,6 +242,11 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
                                   : (top_k < 0 ? g->rows_gt((int64_t)16 * CHUNK) : 0);
     a.lowbits = 1;
     while ((1ll << a.lowbits) < g->max_in_deg && a.lowbits < 31) ++a.lowbits;
+    if (head) {
+        SN_REQUIRE(g->n_split == 0 || a.use_cand, SNGNN_EINVAL,
+                   "no head epilogue: this graph's biggest row takes the scratch-score finalize (sngnn_agg_head_supported)");
+        return launch_agg_fwd_v4(cfg, a, max_split, ev, st);      // (the plain kernels: the head rides in the second launch)
+    }
     if (a.epi_flags != 0) {
         SN_REQUIRE(cfg.vec == 4, SNGNN_EINVAL, "the store epilogue needs C % 4 == 0 (16-byte rows)");
         return launch_agg_fwd_epi_v4(cfg, a, max_split, ev, st);
@@ -270,6 +297,8 @@ static int agg_forward_impl(const sngnn_graph_t *g, const float *h, int C, int t
 {
     RowCfg cfg;
     if (int rc = check_forward_args(g, h, C, top_k, out, sel_src, sel_w, cfg)) return rc;
+    if (g->N == 0 && epi != nullptr && epi->head_y != nullptr && epi->head_metrics != nullptr)      // no row: zero metrics
+        return launch_head_reduce(nullptr, 0, 0.f, 0.f, epi->head_sets == 2 ? 2 : 1, 4, epi->head_metrics, (hipStream_t)stream);
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(workspace != nullptr, SNGNN_EINVAL, "workspace is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -304,6 +333,20 @@ extern "C" int sngnn_agg_forward(const sngnn_graph_t *g, const float *h, int C, 
     return agg_forward_impl(g, h, C, top_k, thr, out, wsel, inv_norm, sel_src, sel_w, workspace, stream, nullptr);
 }
 
+extern "C" int64_t sngnn_agg_head_workspace_bytes(const sngnn_graph_t *g)
+{
+    // one 16-byte entry per wave of the head role and per split row
+    return g ? ((int64_t)256 * 32 + g->n_split) * 16 + 256 : 0;
+}
+
+extern "C" int sngnn_agg_head_supported(const sngnn_graph_t *g, int C, int top_k)
+{
+    RowCfg cfg;
+    if (g == nullptr || !row_cfg(C, cfg) || cfg.vec != 4 || cfg.r != 1 || cfg.g > 16) return 0;
+    const int max_split = g->n_split ? g->rdeg[0] : 0;
+    return (g->n_split == 0 || fwd_use_candidates(top_k < 0 ? -1 : top_k, C, max_split)) ? 1 : 0;
+}
+
 static int check_epilogue(const sngnn_epilogue_t *epi)
 {
     SN_REQUIRE(epi != nullptr, SNGNN_EINVAL, "epilogue is NULL");
@@ -328,6 +371,8 @@ static int agg_forward_prepared_impl(const sngnn_graph_t *g, const float *n, con
 {
     RowCfg cfg;
     if (int rc = check_forward_args(g, n, C, top_k, out, sel_src, sel_w, cfg)) return rc;
+    if (g->N == 0 && epi != nullptr && epi->head_y != nullptr && epi->head_metrics != nullptr)
+        return launch_head_reduce(nullptr, 0, 0.f, 0.f, epi->head_sets == 2 ? 2 : 1, 4, epi->head_metrics, (hipStream_t)stream);
     if (g->N == 0) return SNGNN_OK;
     SN_REQUIRE(nrm != nullptr, SNGNN_EINVAL, "nrm is NULL");
     SN_REQUIRE(workspace != nullptr || (g->n_tasks == 0 && (filt != nullptr || !use_filter(g, C, top_k, thr))),

@@ -38,6 +38,7 @@
 #pragma once
 #include "agg_fwd_filter.h"
 #include "device_utils.h"
+#include "head_row.h"
 
 namespace sngnn {
 
@@ -99,6 +100,24 @@ struct FwdArgs {
     const unsigned long long *epi_seed;   // dev [1]: the mask is drawn here, keep = u(seed, i C + c) >= p
     float epi_p;
     float epi_scale;                // 1 / (1 - p) when something is dropped, else 1
+    // The classification head of the LAST layer inside the forward's second launch (head_row.h;
+    // sngnn_epilogue_t.head_*): the finished mean row (+ epi_bias) is the row of logits - its
+    // log-softmax NLL term and arg-max hit are added to an entry of head_part ([entries][4] floats:
+    // loss A, correct A, loss B, correct B) and, training, d loss / d logits replaces the row in `out`.
+    // Split rows go through it in their finalize, while they are in registers (entry head_nmain + p);
+    // all other rows are read back from `out` by extra workgroups of the SAME launch (head_rows_role;
+    // entry = their wave id): the finalize is a latency chain of a few hundred workgroups on an
+    // otherwise idle chip, the head a bandwidth-bound pass - one launch, the longer of the two.
+    // (In the main kernel's stores instead: its 80-register budget spilled 15-39 registers, at 96
+    // the kernel took 62 against 51 us - more than the head pass costs.)
+    // head_flags: bit 0 two splits (head_sel is a bit set), bit 1 out = the gradient, else out = the logits.
+    const int64_t *head_y;
+    const uint8_t *head_sel;
+    float *head_part;
+    int head_flags, head_nmain;
+    float head_scale;               // 1 / rows of split A (the gradient's factor, the mean's)
+    float head_scale_b;             // 1 / rows of split B
+    float *head_out;                // dev [2] or [4]: (mean NLL, correct count) per split, by launch_head_reduce
     __device__ __forceinline__ bool drawn_keep(int i, int c) const       // (device_utils.h: sn_dropout_keep)
     {
         return sn_dropout_keep(*epi_seed, (unsigned long long)i * (unsigned)C + (unsigned)c, epi_p);
@@ -126,6 +145,137 @@ __device__ __forceinline__ void row_epilogue(const FwdArgs &a, Row<VEC, G, R> &a
             for (int v = 0; v < VEC; ++v) acc.x[r][v] = a.epilogue(acc.x[r][v], i, c0 + v);
         }
     }
+}
+
+// what a wave has added up over its rows (lanes lg == 0 of every lane group hold terms)
+struct HeadAcc { float loss = 0.f, corr = 0.f, lossb = 0.f, corrb = 0.f; };
+
+// the finished mean row `acc` of target i, held by a G-lane group, goes through the head; yy / sv = the
+// row's label and split byte (loaded early by the caller: not a round trip at the end of the row)
+// (in_memory: `out` already holds the row as it is in acc - stored again only if the bias changes it)
+template <int VEC, int G, int R>
+__device__ __forceinline__ void head_store_row(const FwdArgs &a, const Row<VEC, G, R> &acc, int i, int lg, int yy,
+                                               unsigned sv, HeadAcc &ha, bool in_memory = false)
+{
+    if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+        const bool in = 4 * lg < a.C;
+        const int c0 = in ? 4 * lg : 0;
+        float4 t = make_float4(acc.x[0][0], acc.x[0][1], acc.x[0][2], acc.x[0][3]);
+        if (a.epi_flags & 2) {
+            const float4 b = *reinterpret_cast<const float4 *>(a.epi_bias + c0);
+            t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        }
+        float4 *o = reinterpret_cast<float4 *>(a.out + (size_t)i * a.C + c0);
+        const bool grad = (a.head_flags & 2) != 0;
+        if (sv == 0) {                                        // (group-uniform) the row is in no split
+            if (in && grad) *o = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (in && (!in_memory || (a.epi_flags & 2))) *o = t;
+            return;
+        }
+        if (in && !grad && (!in_memory || (a.epi_flags & 2))) *o = t;
+        const HeadRow hr = head_row<G>(t, in, c0, yy);
+        if (lg == 0) {
+            if (a.head_flags & 1) {
+                if (sv & 1) { ha.loss += hr.loss; ha.corr += hr.corr; }
+                if (sv & 2) { ha.lossb += hr.loss; ha.corrb += hr.corr; }
+            } else {
+                ha.loss += hr.loss;
+                ha.corr += hr.corr;
+            }
+        }
+        if (in && grad) *o = head_row_grad(hr, a.head_scale);
+    }
+}
+
+// one entry of head_part from a wave's accumulators (fixed order: a shuffle tree over the lanes)
+__device__ __forceinline__ void head_write_entry(const FwdArgs &a, int entry, const HeadAcc &ha)
+{
+    float v0 = ha.loss, v1 = ha.corr, v2 = ha.lossb, v3 = ha.corrb;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64);
+        v2 += __shfl_xor(v2, m, 64); v3 += __shfl_xor(v3, m, 64);
+    }
+    if (lane_id() == 0) *reinterpret_cast<float4 *>(a.head_part + 4 * (size_t)entry) = make_float4(v0, v1, v2, v3);
+}
+
+// Every row that is NOT a split row (in-degree <= WAVE_T), in natural order, read back from `out`: wave w of
+// nw walks 2 x 64 / G rows per step and returns what it has added up.
+template <int VEC, int G, int R>
+__device__ __forceinline__ HeadAcc head_rows_role(const FwdArgs &a, int w, int nw)
+{
+    HeadAcc ha;
+    if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+        constexpr int RPW = 64 / G, U = 2;
+        const int lane = lane_id();
+        const int gid = lane / G, lg = lane % G;
+        const int c0 = 4 * lg < a.C ? 4 * lg : 0;
+        for (int64_t base = (int64_t)w * (RPW * U); base < a.N; base += (int64_t)nw * (RPW * U)) {
+            Row<VEC, G, R> row[U];
+            int yy[U], deg[U];
+            unsigned sv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                       // all loads first
+                const int64_t i = base + u * RPW + gid;
+                const int64_t ic = i < a.N ? i : a.N - 1;
+                deg[u] = a.rowptr[ic + 1] - a.rowptr[ic];
+                sv[u] = a.head_sel[ic];
+                yy[u] = (int)a.head_y[ic];
+                const float4 t = *reinterpret_cast<const float4 *>(a.out + ic * a.C + c0);
+                row[u].x[0][0] = t.x; row[u].x[0][1] = t.y; row[u].x[0][2] = t.z; row[u].x[0][3] = t.w;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = base + u * RPW + gid;
+                if (i >= a.N || deg[u] > WAVE_T) continue;      // (group-uniform; split rows: their finalize)
+                head_store_row<VEC, G, R>(a, row[u], (int)i, lg, yy[u], sv[u], ha, true);
+            }
+        }
+    }
+    return ha;
+}
+
+// one entry of head_part per WORKGROUP of the head role: the waves' sums through LDS, added in wave order
+// (s_mem: 4 floats per wave).  Called by every thread of the workgroup.
+__device__ __forceinline__ void head_block_entry(const FwdArgs &a, int entry, const HeadAcc &ha, float *s_mem)
+{
+    float v0 = ha.loss, v1 = ha.corr, v2 = ha.lossb, v3 = ha.corrb;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        v0 += __shfl_xor(v0, m, 64); v1 += __shfl_xor(v1, m, 64);
+        v2 += __shfl_xor(v2, m, 64); v3 += __shfl_xor(v3, m, 64);
+    }
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (lane_id() == 0) *reinterpret_cast<float4 *>(s_mem + 4 * wave) = make_float4(v0, v1, v2, v3);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < nwaves; ++w) {
+            const float4 q = *reinterpret_cast<const float4 *>(s_mem + 4 * w);
+            t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+        }
+        *reinterpret_cast<float4 *>(a.head_part + 4 * (size_t)entry) = t;
+    }
+}
+
+// workgroups of the head role in a launch of `block` threads (head_part entry = the workgroup's index):
+// enough waves to fill the chip, never more than the rows need
+inline int head_role_blocks(int64_t N, int G, int block)
+{
+    // (inside the finalize launch the workgroups hold 75 registers - six waves per SIMD, three 512-thread
+    // workgroups per CU - and the finalize's own workgroups sit beside them: ONE round of 2 per CU)
+    const int64_t cap = block == BLOCK ? 256 * 32 : (int64_t)256 * 2 * (block / 64);
+    const int64_t waves = std::min<int64_t>(ceil_div(N, 2 * (64 / G)), cap);
+    return ceil_div(waves, block / 64);
+}
+
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_agg_head_rows(const FwdArgs a)
+{
+    __shared__ __align__(16) float s_mem[4 * WAVES];
+    const int nw = gridDim.x * WAVES;
+    const HeadAcc ha = head_rows_role<VEC, G, R>(a, blockIdx.x * WAVES + (threadIdx.x >> 6), nw);
+    head_block_entry(a, blockIdx.x, ha, s_mem);
 }
 
 #ifndef SNGNN_FWD_WAVES
@@ -340,7 +490,7 @@ __device__ __forceinline__ WaveSel wave_select(const float *sc, int n, int base,
 // ---------------------------------------------------------------------------
 // One set of 64/G small rows (one per lane group) whose column ids are already in
 // LDS (s_col[gid][t]).  d = this group's row descriptor (deg 0 for a padding slot).
-template <int VEC, int G, int R, bool OTF, bool EPI>
+template <int VEC, int G, int R, bool OTF, int EPI>
 __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, bool valid,
                                                int *lds_wave, const int *s_col_set)
 {
@@ -492,7 +642,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
         if (a.kbits && valid && lg == 0) reinterpret_cast<unsigned short *>(a.kbits)[i] = (unsigned short)kb;
     if (valid) {
         acc.div((float)max(deg, 1));
-        if constexpr (EPI) row_epilogue<VEC, G, R>(a, acc, i, lg);
+        if constexpr (EPI == 1) row_epilogue<VEC, G, R>(a, acc, i, lg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
 }
@@ -503,7 +653,7 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
 // current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool OTF, bool EPI>
+template <int VEC, int G, int R, bool OTF, int EPI>
 __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
@@ -780,7 +930,7 @@ __device__ __forceinline__ WaveSel banded_select(const FwdArgs &a, const Row<VEC
 // ---------------------------------------------------------------------------
 // Class B: SMALL_T < deg <= WAVE_T, one wave per row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool FILT, bool OTF, bool EPI>
+template <int VEC, int G, int R, bool FILT, bool OTF, int EPI>
 __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -884,7 +1034,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     acc.reduce_across_groups();
     if (gid == 0) {
         acc.div((float)deg);
-        if constexpr (EPI) row_epilogue<VEC, G, R>(a, acc, i, lg);
+        if constexpr (EPI == 1) row_epilogue<VEC, G, R>(a, acc, i, lg);
         acc.store(a.out + (size_t)i * a.C, a.C, lg);
     }
     // (stored at the END of the row: a store up front would pin the scoring pass's first
@@ -973,7 +1123,7 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // EPI: the hidden-layer store epilogue (FwdArgs::epilogue) compiled into the row stores - its own
 // instantiation, so the plain forward keeps its register allocation (a runtime flag cost the
 // filter variant two spilled registers and 2 us)
-template <int VEC, int G, int R, bool FILT, bool OTF, bool EPI = false>
+template <int VEC, int G, int R, bool FILT, bool OTF, int EPI = 0>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
     static_assert(!(FILT && OTF), "the filter belongs to the table mode");
@@ -1154,10 +1304,34 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
 constexpr int FIN_WAVE_MIN_ROWS = 2048;   // fewer moderate split rows than this: one launch (k_agg_fin_cand) for all
-constexpr int FINC_BLOCK = 1024, FINC_WAVES = FINC_BLOCK / 64;   // 16 waves: the tournament's first level runs wide
+#ifndef SNGNN_FINC_BLOCK
+#define SNGNN_FINC_BLOCK 512
+#endif
+constexpr int FINC_BLOCK = SNGNN_FINC_BLOCK, FINC_WAVES = FINC_BLOCK / 64;   // 16 waves: the tournament's first level runs wide
 constexpr size_t FINC_LDS_BUDGET = 150 * 1024;
 
 inline size_t finc_lds_bytes(int C, int max_slots) { return ((size_t)FINC_WAVES * C + 1) * 4 + (size_t)max_slots * 24 + 16; }
+
+// a split row's head (FwdArgs::head_sel): the finished mean row sits in LDS (s_row[0, C)); the first lane
+// group of wave 0 takes it through head_store_row and the row's entry of head_part is written.
+// Called by the whole workgroup, behind the barrier that made s_row complete.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void fin_row_head(const FwdArgs &a, int i, int p, const float *s_row)
+{
+    if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+        if (threadIdx.x >= 64) return;                         // (wave-uniform)
+        const int lane = lane_id();
+        const int gid = lane / G, lg = lane % G;
+        HeadAcc ha;
+        if (gid == 0) {
+            Row<VEC, G, R> row;
+            const float4 t = *reinterpret_cast<const float4 *>(s_row + (4 * lg < a.C ? 4 * lg : 0));
+            row.x[0][0] = t.x; row.x[0][1] = t.y; row.x[0][2] = t.z; row.x[0][3] = t.w;
+            head_store_row<VEC, G, R>(a, row, i, lg, (int)a.head_y[i], a.head_sel[i], ha);
+        }
+        head_write_entry(a, a.head_nmain + p, ha);
+    }
+}
 
 template <int VEC, int G, int R>
 __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_slots, unsigned char *dyn)
@@ -1197,7 +1371,12 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         for (int c = tid; c < a.C; c += FINC_BLOCK) {
             float s = 0.f;
             for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + c];
-            a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
+            if (a.head_sel) s_part[c] = s / (float)deg;         // (C <= 64 <= FINC_BLOCK: the thread's own channel only)
+            else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
+        }
+        if (a.head_sel) {
+            __syncthreads();
+            fin_row_head<VEC, G, R>(a, i, p, s_part);
         }
         if (emit) {
             // selection of a streaming split row: every edge >= thr, ranked.  Rare
@@ -1296,7 +1475,12 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     for (int ch = tid; ch < a.C; ch += FINC_BLOCK) {
         float s = 0.f;
         for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
-        a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
+        if (a.head_sel) s_part[ch] = s / (float)deg;
+        else a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
+    }
+    if (a.head_sel) {
+        __syncthreads();
+        fin_row_head<VEC, G, R>(a, i, p, s_part);
     }
 }
 
@@ -1323,8 +1507,13 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     const int i = d.x, rs = d.y, deg = d.z;
     if (a.skip_row(i)) return;                              // (wave-uniform)
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const bool head = a.head_sel != nullptr;
+    int head_yy = 0;
+    unsigned head_sv = 0u;
+    if (head) { head_yy = (int)a.head_y[i]; head_sv = a.head_sel[i]; }
     if (a.k < 0) {
         // (rows of at most 16 tasks come here: their partial rows are loaded together)
+        float *s_row = reinterpret_cast<float *>(s_key_w);      // head: the row through LDS (C <= 64 floats fit)
         for (int c = lane; c < a.C; c += 64) {
             float v[16];
 #pragma unroll
@@ -1333,7 +1522,21 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += v[u];
             for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-            a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
+            if (head) s_row[c] = s / (float)deg;
+            else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
+        }
+        if (head) {
+            if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+                wave_lds_sync();
+                HeadAcc ha;
+                if (gid == 0) {
+                    RowT row;
+                    const float4 t = *reinterpret_cast<const float4 *>(s_row + (4 * lg < a.C ? 4 * lg : 0));
+                    row.x[0][0] = t.x; row.x[0][1] = t.y; row.x[0][2] = t.z; row.x[0][3] = t.w;
+                    head_store_row<VEC, G, R>(a, row, i, lg, head_yy, head_sv, ha);
+                }
+                head_write_entry(a, a.head_nmain + p, ha);
+            }
         }
         return;
     }
@@ -1384,6 +1587,12 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     }
     acc.reduce_across_groups();
     acc.div((float)deg);
+    if (head) {
+        HeadAcc ha;
+        if (gid == 0) head_store_row<VEC, G, R>(a, acc, i, lg, head_yy, head_sv, ha);
+        head_write_entry(a, a.head_nmain + p, ha);
+        return;
+    }
     row_epilogue<VEC, G, R>(a, acc, i, lg);
     if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
 }
@@ -1405,9 +1614,16 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
 // others one moderate row per wave - 140 workgroups that all start at once instead of 825
 // tournaments of which 512 fit the chip (finalize 8.8 -> see DESIGN.md 4.1).
 template <int VEC, int G, int R>
-__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split)
+__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split,
+                                                              int n_fin_blocks)
 {
     extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
+    if ((int)blockIdx.x >= n_fin_blocks) {                 // (workgroup-uniform) the head role of the launch
+        const int hb = (int)blockIdx.x - n_fin_blocks;
+        const HeadAcc ha = head_rows_role<VEC, G, R>(a, hb * FINC_WAVES + (threadIdx.x >> 6), a.head_nmain * FINC_WAVES);
+        head_block_entry(a, hb, ha, reinterpret_cast<float *>(dyn));
+        return;
+    }
     if ((int)blockIdx.x < n_big) {                         // (workgroup-uniform)
         fin_cand_row<VEC, G, R>(a, blockIdx.x, max_slots, dyn);
         return;
@@ -1429,6 +1645,31 @@ inline bool fwd_use_candidates(int top_k, int C, int max_split_deg)
     return finc_lds_bytes(C, max_slots) <= FINC_LDS_BUDGET;
 }
 
+// how the split rows of a call are finalized (rows are in descending degree order: the first n_big_true
+// need the workgroup tournament, the rest fit one wave-level selection)
+struct FinShape { int n_wave, n_big, n_big_true; bool mixed; };
+inline FinShape finalize_shape(const FwdArgs &a)
+{
+    FinShape f;
+    f.n_wave = a.n_split - std::min(a.n_split, a.n_split_gt_wave);
+    // (no selection, k < 0: the split is by the number of partial rows to add, > 16 tasks -> workgroup)
+    f.n_big = a.k < 0 ? a.n_split - f.n_wave
+                      : ((a.k > 0 && f.n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - f.n_wave : (a.k > 0 ? a.n_split : 0));
+    f.n_big_true = a.n_split - f.n_wave;         // rows that need the tournament
+    // few moderate rows (arxiv-like graphs: a few hundred split rows in all; products-like ones have 10^5): ONE launch
+    f.mixed = a.n_split > 0 && a.use_cand && a.k > 0 && f.n_big == a.n_split && f.n_wave > 0 && f.n_big_true < a.n_split;
+    return f;
+}
+inline bool head_role_in_finalize(const FwdArgs &a) { return finalize_shape(a).mixed; }
+
+// the head role as a launch of its own (finalize shapes that do not carry it; graphs without split rows)
+template <int VEC, int G, int R>
+int launch_head_rows(const FwdArgs &a, hipStream_t st)
+{
+    if (a.head_sel && a.head_nmain > 0) k_agg_head_rows<VEC, G, R><<<a.head_nmain, BLOCK, 0, st>>>(a);
+    return SNGNN_OK;
+}
+
 // launches of the split rows' finalize (after their tasks, same stream)
 template <int VEC, int G, int R>
 int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
@@ -1442,24 +1683,21 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        // rows are in descending degree order: the first n_big need the workgroup tournament,
-        // the rest fit one wave-level selection
-        // (a second launch only pays when there are many such rows: arxiv-like graphs have a
-        // few hundred split rows in all, products-like ones 10^5)
-        const int n_wave = a.n_split - std::min(a.n_split, a.n_split_gt_wave);
-        // (no selection, k < 0: the split is by the number of partial rows to add, > 16 tasks -> workgroup)
-        const int n_big = a.k < 0 ? a.n_split - n_wave
-                                  : ((a.k > 0 && n_wave >= FIN_WAVE_MIN_ROWS) ? a.n_split - n_wave : (a.k > 0 ? a.n_split : 0));
-        const int n_big_true = a.n_split - n_wave;         // rows that need the tournament
-        if (a.k > 0 && n_big == a.n_split && n_wave > 0 && n_big_true < a.n_split) {
+        const FinShape fs = finalize_shape(a);
+        const int n_wave = fs.n_wave, n_big = fs.n_big, n_big_true = fs.n_big_true;
+        if (fs.mixed) {
             // few moderate rows: one mixed launch
             const size_t dyn_mixed = std::max(dyn, (size_t)FINC_WAVES * CAND_MAX_K * 12);
             if (dyn_mixed > 48 * 1024)
                 SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_mixed));
-            k_agg_fin_mixed<VEC, G, R><<<n_big_true + ceil_div(n_wave, FINC_WAVES), FINC_BLOCK, dyn_mixed, st>>>(
-                a, max_slots, n_big_true, a.n_split);
+            const int n_fin_blocks = n_big_true + ceil_div(n_wave, FINC_WAVES);
+            const int n_head_blocks = a.head_sel ? a.head_nmain : 0;
+            k_agg_fin_mixed<VEC, G, R><<<n_fin_blocks + n_head_blocks, FINC_BLOCK, dyn_mixed, st>>>(
+                a, max_slots, n_big_true, a.n_split, n_fin_blocks);
+            return SNGNN_OK;
         } else {
+            launch_head_rows<VEC, G, R>(a, st);
             if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
             if (a.n_split > n_big)
                 k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
@@ -1474,7 +1712,9 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
         if (dyn > 48 * 1024)
             SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin<VEC, G, R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        k_agg_fin<VEC, G, R><<<a.n_split, FIN_BLOCK, dyn, st>>>(a, lds_scores);
+        k_agg_fin<VEC, G, R><<<a.n_split, FIN_BLOCK, dyn, st>>>(a, lds_scores);      // (no head there: the host refuses)
+    } else {
+        launch_head_rows<VEC, G, R>(a, st);
     }
     return SNGNN_OK;
 }
@@ -1483,15 +1723,19 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 // between its two events, so the event pair's own cost is spread over reps launches
 extern int g_prof_reps;
 
-template <int VEC, int G, int R, bool EPI>
-int launch_agg_fwd_impl(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
+template <int VEC, int G, int R, int EPI>
+int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
     const int reps = ev ? std::max(g_prof_reps, 1) : 1;
     constexpr int RPW = 64 / G;
-    const int n_small = a.N - a.n_med_end;
-    const int64_t items = (int64_t)a.n_tasks + (a.n_med_end - a.n_split) + ceil_div(n_small, RPW);
+    const int n_small = a0.N - a0.n_med_end;
+    const int64_t items = (int64_t)a0.n_tasks + (a0.n_med_end - a0.n_split) + ceil_div(n_small, RPW);
     // persistent grid: what the chip holds at the kernel's occupancy, or less
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
+    FwdArgs a = a0;
+    // head_part: one entry per workgroup of the head role, then one per split row.  (The role rides in the
+    // mixed finalize launch - FINC_BLOCK threads - where there is one, else in a launch of its own.)
+    a.head_nmain = a.head_sel ? head_role_blocks(a.N, G, head_role_in_finalize(a) ? FINC_BLOCK : BLOCK) : 0;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     for (int rep = 0; rep < reps && grid > 0; ++rep) {
         if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
@@ -1511,19 +1755,23 @@ int launch_agg_fwd_impl(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hip
         SN_HIP(hipEventRecord(ev[3], st));       // empty interval: the cost of an event pair
     }
     SN_HIP(hipGetLastError());
+    if (a.head_sel)
+        return launch_head_reduce(a.head_part, a.head_nmain + a.n_split, a.head_scale, a.head_scale_b,
+                                  (a.head_flags & 1) ? 2 : 1, 4, a.head_out, st);
     return SNGNN_OK;
 }
 
 template <int VEC, int G, int R>
 int launch_agg_fwd(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
-    return launch_agg_fwd_impl<VEC, G, R, false>(a, max_split_deg, ev, st);
+    return launch_agg_fwd_impl<VEC, G, R, 0>(a, max_split_deg, ev, st);
 }
 template <int VEC, int G, int R>
 int launch_agg_fwd_epi(const FwdArgs &a, int max_split_deg, hipEvent_t *ev, hipStream_t st)
 {
-    return launch_agg_fwd_impl<VEC, G, R, true>(a, max_split_deg, ev, st);
+    return launch_agg_fwd_impl<VEC, G, R, 1>(a, max_split_deg, ev, st);
 }
+
 
 // one translation unit per VEC instantiates these
 int launch_agg_fwd_epi_v4(const RowCfg &cfg, const FwdArgs &a, int max_split_deg, hipEvent_t *ev,

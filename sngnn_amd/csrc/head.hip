@@ -11,7 +11,7 @@
 //                    chunks accumulate in registers and a second kernel adds the partials
 //                    in fixed order (deterministic, no float atomics).
 // Both are HBM-bound streams: 4 N C (+ 4 N C for the gradient) and 4 N (F + C) bytes.
-#include "common.h"
+#include "head_row.h"
 
 namespace sngnn {
 
@@ -145,39 +145,7 @@ __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, 
 // its first arg-max, the sum of the exponentials and the label's logit are 4-step DPP
 // reductions inside the group (no LDS, no shuffles).  Two rows per group in flight.
 // Same per-row arithmetic up to the order of the exp sum (a fixed tree here).
-template <int CTRL> __device__ __forceinline__ float dpp_maxf(float v)
-{
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)));
-}
-template <int CTRL> __device__ __forceinline__ int dpp_mini(int v)
-{
-    return min(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false));
-}
-template <int CTRL> __device__ __forceinline__ float dpp_addf(float v)
-{
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-template <int G> __device__ __forceinline__ float gmaxf(float v)
-{
-    v = dpp_maxf<0xB1>(v); v = dpp_maxf<0x4E>(v); v = dpp_maxf<0x141>(v);
-    if constexpr (G == 16) v = dpp_maxf<0x140>(v);
-    return v;
-}
-template <int G> __device__ __forceinline__ int gmini(int v)
-{
-    v = dpp_mini<0xB1>(v); v = dpp_mini<0x4E>(v); v = dpp_mini<0x141>(v);
-    if constexpr (G == 16) v = dpp_mini<0x140>(v);
-    return v;
-}
-template <int G> __device__ __forceinline__ float gsumf(float v)
-{
-    v = dpp_addf<0xB1>(v); v = dpp_addf<0x4E>(v); v = dpp_addf<0x141>(v);
-    if constexpr (G == 16) v = dpp_addf<0x140>(v);
-    return v;
-}
-
-__device__ __forceinline__ float fast_exp_neg(float t) { return __builtin_amdgcn_exp2f(t * 1.44269504088896341f); }
-
+// (the per-row arithmetic: head_row.h)
 template <int G, bool TWO>
 __global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z, const int64_t *__restrict__ y,
                                                      const unsigned char *__restrict__ sel, int64_t N, int C,
@@ -213,28 +181,8 @@ __global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z
                 if (gi && in) *reinterpret_cast<float4 *>(gi) = make_float4(0.f, 0.f, 0.f, 0.f);
                 continue;
             }
-            const float v0 = in ? t[u].x : -INFINITY, v1 = in ? t[u].y : -INFINITY;
-            const float v2 = in ? t[u].z : -INFINITY, v3 = in ? t[u].w : -INFINITY;
-            const float mx = gmaxf<G>(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
-            // first channel that attains the maximum (torch.max on the CPU keeps the first)
-            int a = 1 << 30;
-            if (v3 == mx) a = c0 + 3;
-            if (v2 == mx) a = c0 + 2;
-            if (v1 == mx) a = c0 + 1;
-            if (v0 == mx) a = c0;
-            const int arg = gmini<G>(a);
-            // exp(t) for t <= 0 as 2^(t log2 e): v_exp_f32 (1 ulp) on a product rounded once - a
-            // relative error of at most |t| 2^-24 + 2^-23 per term, i.e. below 3e-6 even for the
-            // terms 40 below the maximum (which weigh e^-40); the library expf spends ~15
-            // instructions per value on the last bit and made this kernel VALU-bound
-            const float e0 = in ? fast_exp_neg(v0 - mx) : 0.f, e1 = in ? fast_exp_neg(v1 - mx) : 0.f;
-            const float e2 = in ? fast_exp_neg(v2 - mx) : 0.f, e3 = in ? fast_exp_neg(v3 - mx) : 0.f;
-            const float se = gsumf<G>((e0 + e1) + (e2 + e3));
-            const int yy = yi[u];
-            const int k = yy - c0;                            // the label's logit sits in exactly one lane
-            const float mine = (in && k >= 0 && k < 4) ? (k == 0 ? v0 : k == 1 ? v1 : k == 2 ? v2 : v3) : 0.f;
-            const float zy = gsumf<G>(mine);
-            const float row_loss = -(zy - mx - logf(se)), row_corr = (arg == yy) ? 1.f : 0.f;
+            const HeadRow hr = head_row<G>(t[u], in, c0, yi[u]);
+            const float row_loss = hr.loss, row_corr = hr.corr;
             if (lg == 0) {
                 if constexpr (TWO) {
                     if (sv[u] & 1) { loss += row_loss; corr += row_corr; }
@@ -244,11 +192,7 @@ __global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z
                     corr += row_corr;
                 }
             }
-            if (gi && in) {
-                const float inv = scale / se;
-                *reinterpret_cast<float4 *>(gi) = make_float4(e0 * inv - (k == 0 ? scale : 0.f), e1 * inv - (k == 1 ? scale : 0.f),
-                                                              e2 * inv - (k == 2 ? scale : 0.f), e3 * inv - (k == 3 ? scale : 0.f));
-            }
+            if (gi && in) *reinterpret_cast<float4 *>(gi) = head_row_grad(hr, scale);
         }
     }
     loss = wsum(loss);
@@ -485,6 +429,14 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 }
 
 }  // namespace sngnn
+
+int sngnn::launch_head_reduce(const float *part, int entries, float scale_a, float scale_b, int sets, int stride,
+                              float *out, hipStream_t st)
+{
+    k_head_reduce<<<sets, 256, 0, st>>>(part, entries, scale_a, scale_b, stride, out);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
 
 using namespace sngnn;
 

@@ -28,10 +28,22 @@ class _Stack(nn.Module):
             for bn in self.bns:
                 bn.reset_parameters()
 
-    def forward_logits(self, data):
+    def forward_head(self, data, head):
+        """:meth:`forward_logits` with the classification head (``ops.HeadEpilogue``: log_softmax, the NLL
+        of a split, its accuracy count and, training, d loss / d logits) run inside the LAST layer's
+        own launches where that layer can (SNConv / SNConv_plus on one GPU, at most 64 classes in rows
+        of 16-byte vectors): ``head.applied`` says whether it did - the result is then what the head
+        was asked to leave (the gradient, or the logits) and ``head.metrics`` are written; otherwise
+        the result is the logits and the caller runs the head itself."""
+        return self.forward_logits(data, head)
+
+    def forward_logits(self, data, head=None):
         """Everything before the final ``log_softmax`` (lets a trainer fuse the
         classification head, sngnn_amd/train.py:GraphedEpoch)."""
         x, edge_index = data.x, data.edge_index
+        if head is not None:
+            head.applied = False
+        takes_head = head is not None and isinstance(self.lins[-1], (SNConv, SNConv_plus))
         # relu + dropout between two conv layers as the store epilogue of the aggregation that
         # produces their operand, and backward as the store epilogue of the next ``lin``'s input
         # gradient (ops.HiddenEpilogue) - without batch norm in between, on one GPU, for the layers
@@ -57,6 +69,8 @@ class _Stack(nn.Module):
                 # batch statistics over every rank's rows, as the single-process batch has them
                 x = self.bns[i](x) if part is None else sn_dist.sync_batch_norm(self.bns[i], x, part)
             x = self.dropout(x)
+        if takes_head:
+            return self.lins[-1](x, edge_index, None, act if fusable else None, head)
         if fusable and act is not None:
             return self.lins[-1](x, edge_index, None, act)
         return self.lins[-1](x, edge_index)

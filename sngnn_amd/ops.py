@@ -235,6 +235,44 @@ class HiddenEpilogue:
         return self.training and self.p > 0.0
 
 
+class HeadEpilogue:
+    """What follows the LAST conv layer - the wrappers' ``log_softmax`` (models.py:86,211,303) and the
+    harness' ``nll_loss`` on a mask + accuracy count (train.py:81-84, 98-102, 112-116) - inside the
+    aggregation's own launches (``sngnn_epilogue_t.head_*``): the split rows go through the head in
+    their finalize, all other rows are read back by extra workgroups of that same launch - a latency
+    chain on an otherwise idle chip - instead of two more launches behind it (``head_nll`` /
+    ``head_nll2``, which compute the same per-row bits).
+
+    ``y`` int64 [N]; ``sel`` uint8 [N] - one split: != 0 marks its rows; two splits (``n_b`` given):
+    bit 0 = split A, bit 1 = split B; ``metrics`` float32 [2] / [4] receives (mean NLL, correct
+    count) per split.  ``grad``: one split, training - the layer's output tensor then holds
+    d loss / d logits (zero rows outside the split) and ``G.backward(G.detach())`` is the backward
+    of ``loss.backward()``; otherwise the output holds the logits.
+    ``applied``: set by the conv layer when its shape took the fused form."""
+
+    def __init__(self, y, sel, metrics, n_a: int, n_b: Optional[int] = None, grad: bool = False):
+        if y.dtype != torch.int64 or sel.dtype != torch.uint8 or metrics.dtype != torch.float32:
+            raise ValueError("y must be int64, sel uint8, metrics float32")
+        sets = 1 if n_b is None else 2
+        if metrics.numel() != 2 * sets or not metrics.is_contiguous():
+            raise ValueError("metrics must be a contiguous float32 tensor of 2 elements per split")
+        if grad and sets != 1:
+            raise ValueError("grad: one split only")
+        self.y, self.sel, self.metrics = y.contiguous(), sel.contiguous(), metrics
+        self.sets, self.n_a, self.n_b = sets, int(n_a), int(n_b or 0)
+        self.grad = bool(grad)
+        self.applied = False
+
+    @property
+    def out_mode(self) -> int:
+        return 2 if self.grad else 1
+
+
+def head_supported(graph: Graph, channels: int, top_k: Optional[int]) -> bool:
+    """``sngnn_agg_head_supported``: whether a forward on this graph at this width can take the head."""
+    return bool(_lib.load().sngnn_agg_head_supported(graph.handle, int(channels), -1 if top_k is None else int(top_k)))
+
+
 class _Aggregate(torch.autograd.Function):
     """autograd seam of the fused aggregation.  The output is freshly allocated
     and not saved, so the models' in-place ReLU on it is safe (models.py:81,206,298).
@@ -242,13 +280,19 @@ class _Aggregate(torch.autograd.Function):
     dropped out; the output is then saved, as the mask its own backward needs."""
 
     @staticmethod
-    def forward(ctx, h, graph, top_k, thr, unit=None, epi=None, bias=None):
+    def forward(ctx, h, graph, top_k, thr, unit=None, epi=None, bias=None, head=None):
         need_grad = ctx.needs_input_grad[0]
         ctx.epi = epi
         # training calls: where the library can, the forward writes WHICH edges it kept as packed bits
         # itself (sngnn_epilogue_t.kept_bits) - no per-edge weights, no packing launch in the backward
         ctx.bits = need_grad and kept_bits_supported(graph, top_k, h.size(1))
-        if epi is not None or ctx.bits:
+        ctx.bias_grad = False
+        if head is not None:
+            # the classification head inside the forward's launches (HeadEpilogue): ``out`` = the gradient of
+            # the split's mean NLL (training) or the logits
+            out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, None, bias, ctx.bits, head)
+            ctx.bias_grad = bias is not None and ctx.needs_input_grad[6]
+        elif epi is not None or ctx.bits:
             out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, epi, bias, ctx.bits)
             ctx.bias_grad = epi is not None and bias is not None and ctx.needs_input_grad[6]
         elif unit is not None and unit.n is not None:
@@ -284,11 +328,13 @@ class _Aggregate(torch.autograd.Function):
                 _lib.check(rc, "sngnn_epilogue_backward")
             if ctx.bias_grad:
                 grad_bias = grad_out.sum(dim=0)
+        if epi is None and ctx.bias_grad:          # (the head epilogue added the conv's bias)
+            grad_bias = grad_out.sum(dim=0)
         if ctx.bits:         # (``wsel`` holds the kept bits)
             grad_h = aggregate_backward_bits(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
         else:
             grad_h = aggregate_backward(ctx.graph, h, grad_out.contiguous(), wsel, ctx.top_k)
-        return grad_h, None, None, None, None, None, grad_bias
+        return grad_h, None, None, None, None, None, grad_bias, None
 
 
 class UnitRows:
@@ -322,7 +368,7 @@ def _forward_prepared(graph: Graph, unit: "UnitRows", top_k, thr, need_grad):
 
 
 def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optional["HiddenEpilogue"], bias,
-                      bits: bool = False):
+                      bits: bool = False, head: Optional["HeadEpilogue"] = None):
     """``sngnn_agg_forward_epilogue`` / ``_prepared_epilogue``: the forward whose stores apply
     bias + relu + dropout (``epi``; draws the keep mask - the caller's Bernoulli(1 - p), torch's
     generator: graph-capture safe - when the epilogue drops and has no seed) and / or that writes
@@ -357,6 +403,14 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optiona
         bias = bias.detach().contiguous()
     st = _lib.Epilogue(_lib.ptr(bias), _lib.ptr(keep), float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p),
                        _lib.ptr(kbits))
+    if head is not None:
+        if head.y.numel() != n or head.sel.numel() != n or head.y.device != h.device or head.sel.device != h.device:
+            raise ValueError("head: y and sel must hold one entry per target row, on h's device")
+        hws = _workspace("agg_head", lib.sngnn_agg_head_workspace_bytes(graph.handle), h.device)
+        st.head_y, st.head_sel = head.y.data_ptr(), head.sel.data_ptr()
+        st.head_sets, st.head_out_mode = head.sets, head.out_mode
+        st.head_n_a, st.head_n_b = head.n_a, head.n_b
+        st.head_metrics, st.head_workspace = head.metrics.data_ptr(), hws.data_ptr()
     ws = graph.workspace(c)
     import ctypes
     with torch.cuda.device(h.device):
@@ -375,12 +429,16 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optiona
 
 def aggregate(h: torch.Tensor, graph: Graph, top_k: Optional[int], thr: float,
               unit: Optional["UnitRows"] = None, epilogue: Optional["HiddenEpilogue"] = None,
-              bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+              bias: Optional[torch.Tensor] = None, head: Optional["HeadEpilogue"] = None) -> torch.Tensor:
     """Differentiable fused aggregation: [N_total, C] -> [N, C] (N_total == N unless
     ``graph`` is a node-range partition).  ``unit``: F.normalize(h) as left by ``lin``'s
     epilogue (``UnitRows``) - the normalisation pass is skipped then.  ``epilogue`` (+ ``bias``):
     the hidden layer's bias / relu / dropout applied by the forward's stores (``HiddenEpilogue``)."""
-    return _Aggregate.apply(h, graph, top_k, thr, unit, epilogue, bias if epilogue is not None else None)
+    if head is not None:
+        # (``head``: the last layer's classification head inside the forward's launches - HeadEpilogue; returns
+        # the gradient of the split's mean NLL, or the logits)
+        return _Aggregate.apply(h, graph, top_k, thr, unit, None, bias, head)
+    return _Aggregate.apply(h, graph, top_k, thr, unit, epilogue, bias if epilogue is not None else None, None)
 
 
 def attention_forward(graph: Graph, h: torch.Tensor, save_for_backward: bool = True):

@@ -105,6 +105,9 @@ class GraphedEpoch:
         self.count = {k: max(int(m.sum()), 1) for k, m in self.mask.items()}
         self._eval_sets = (self.mask["val"] | (self.mask["test"] << 1)).contiguous()   # bit 0: val, bit 1: test
         self.fused = hasattr(model, "forward_logits")
+        # the head inside the last layer's launches (models._Stack.forward_head) where the model offers it
+        self.fused_head = (self.fused and hasattr(model, "forward_head")
+                           and os.environ.get("SNGNN_FUSE_HEAD", "1") == "1")
         self.metrics = torch.zeros(6, dtype=torch.float32, device=dev)
         for g in optimizer.param_groups:
             g["capturable"] = True
@@ -181,7 +184,18 @@ class GraphedEpoch:
         # the graph's private pool, same addresses on every replay) instead of zero-filling
         # and accumulating - two small kernels per parameter less
         self.opt.zero_grad(set_to_none=True)
-        if self.fused:
+        if self.fused_head:
+            # the LAST layer's launches run the head (ops.HeadEpilogue): its output IS d loss / d logits
+            head = self._ops.HeadEpilogue(self.data.y, self.mask["train"], self.metrics[0:2], self.count["train"],
+                                          grad=True)
+            g = self.model.forward_head(self.data, head)
+            if head.applied:
+                g.backward(g.detach())
+            else:
+                (loss, correct), grad = self._ops.head_nll_with_grad(
+                    g, self.data.y, self.mask["train"], self.count["train"], out=self.metrics[0:2])
+                g.backward(grad)
+        elif self.fused:
             # the head kernel hands back d loss / d logits directly: backward starts at the logits
             logits = self.model.forward_logits(self.data)
             (loss, correct), grad = self._ops.head_nll_with_grad(
@@ -193,7 +207,22 @@ class GraphedEpoch:
         self.opt.step()
         with torch.no_grad():
             self.model.eval()
-            shared = self._forward() if self.share_eval_forward else None
+            if self.fused_head and self.share_eval_forward:
+                head = self._ops.HeadEpilogue(self.data.y, self._eval_sets, self.metrics[2:6], self.count["val"],
+                                              self.count["test"])
+                shared = self.model.forward_head(self.data, head)
+                if head.applied:
+                    return
+            elif self.fused_head:
+                for which, slot in (("val", 2), ("test", 4)):
+                    head = self._ops.HeadEpilogue(self.data.y, self.mask[which], self.metrics[slot:slot + 2],
+                                                  self.count[which])
+                    z = self.model.forward_head(self.data, head)
+                    if not head.applied:
+                        self._loss(which, z)
+                return
+            else:
+                shared = self._forward() if self.share_eval_forward else None
             if shared is not None and self.fused and shared.size(1) <= 64:
                 # both splits' metrics in one pass over the logits, straight into metrics[2:6]
                 self._ops.head_nll2(shared, self.data.y, self._eval_sets, self.count["val"],
