@@ -1304,13 +1304,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_agg_fin(const FwdArgs a, int lds_
 // time (tournament of wave-level top-k) and gathers the <= k winners.
 // ---------------------------------------------------------------------------
 constexpr int FIN_WAVE_MIN_ROWS = 2048;   // fewer moderate split rows than this: one launch (k_agg_fin_cand) for all
-#ifndef SNGNN_FINC_BLOCK
-#define SNGNN_FINC_BLOCK 512
-#endif
-constexpr int FINC_BLOCK = SNGNN_FINC_BLOCK, FINC_WAVES = FINC_BLOCK / 64;   // 16 waves: the tournament's first level runs wide
+// Waves per workgroup of the candidate finalize (template NW): 16 where the biggest row's tournament has more
+// than 1 024 candidates to get through (its first level runs wide: arxiv size at top_k 16, 1 632 keys:
+// 7.6 us against 8.5 with 8 waves), else 8 - a smaller workgroup is less launch to pay (top_k 1: 1.9
+// against 2.7 us) - and 8 whenever the head role rides in the launch (75 registers: three 512-thread
+// workgroups fit a CU, one of 1 024 threads).
+constexpr int FINC_WAVES_MAX = 16;
 constexpr size_t FINC_LDS_BUDGET = 150 * 1024;
-
-inline size_t finc_lds_bytes(int C, int max_slots) { return ((size_t)FINC_WAVES * C + 1) * 4 + (size_t)max_slots * 24 + 16; }
+inline size_t finc_lds_bytes(int C, int max_slots, int /*nw*/ = FINC_WAVES_MAX) { return ((size_t)FINC_WAVES_MAX * C + 1) * 4 + (size_t)max_slots * 24 + 16; }
 
 // a split row's head (FwdArgs::head_sel): the finished mean row sits in LDS (s_row[0, C)); the first lane
 // group of wave 0 takes it through head_store_row and the row's entry of head_part is written.
@@ -1333,7 +1334,7 @@ __device__ __forceinline__ void fin_row_head(const FwdArgs &a, int i, int p, con
     }
 }
 
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, int NW>
 __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_slots, unsigned char *dyn)
 {
     using RowT = Row<VEC, G, R>;
@@ -1347,9 +1348,9 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     const bool emit = a.sel_src != nullptr && a.k >= 0;
     const bool rank = a.k >= 0 && deg > a.k;
 
-    // dynamic LDS: [FINC_WAVES * C] partial rows | keysA | keysB [max_slots] | srcA | srcB | count
+    // dynamic LDS: [FINC_WAVES_MAX * C] partial rows | keysA | keysB [max_slots] | srcA | srcB | count
     float *s_part = reinterpret_cast<float *>(dyn);
-    unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)FINC_WAVES * a.C + ((FINC_WAVES * a.C) & 1));
+    unsigned long long *kA = reinterpret_cast<unsigned long long *>(s_part + (size_t)FINC_WAVES_MAX * a.C + ((FINC_WAVES_MAX * a.C) & 1));
     unsigned long long *kB = kA + max_slots;
     int *sA = reinterpret_cast<int *>(kB + max_slots);
     int *sB = sA + max_slots;
@@ -1357,21 +1358,24 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
 
     if (!rank) {
         // streaming row (deg <= top_k or no selection): add the tasks' partial rows.  The
-        // FINC_WAVES waves each sum every FINC_WAVES-th task (their loads in flight together),
-        // then the slices are added in slice order: a fixed order, and a hub's ~100 partial
+        // FINC_WAVES_MAX slices, slice s = the sum of every FINC_WAVES_MAX-th task from s on (a wave takes
+        // the slices wave, wave + NW, ..: their loads in flight together), then the slices are added in
+        // slice order: a fixed order WHATEVER the workgroup size, and a hub's ~100 partial
         // rows cost a handful of memory round trips instead of one each.
         for (int c0 = 0; c0 < a.C; c0 += 64) {
             const int c = c0 + lane;
-            float s = 0.f;
-            if (c < a.C)
-                for (int t = t0 + wave; t < t1; t += FINC_WAVES) s += a.partial[(size_t)t * a.C + c];
-            if (c < a.C) s_part[(size_t)wave * a.C + c] = s;
+            for (int sl = wave; sl < FINC_WAVES_MAX; sl += NW) {
+                float s = 0.f;
+                if (c < a.C)
+                    for (int t = t0 + sl; t < t1; t += FINC_WAVES_MAX) s += a.partial[(size_t)t * a.C + c];
+                if (c < a.C) s_part[(size_t)sl * a.C + c] = s;
+            }
         }
         __syncthreads();
-        for (int c = tid; c < a.C; c += FINC_BLOCK) {
+        for (int c = tid; c < a.C; c += (NW * 64)) {
             float s = 0.f;
-            for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + c];
-            if (a.head_sel) s_part[c] = s / (float)deg;         // (C <= 64 <= FINC_BLOCK: the thread's own channel only)
+            for (int w = 0; w < FINC_WAVES_MAX; ++w) s += s_part[(size_t)w * a.C + c];
+            if (a.head_sel) s_part[c] = s / (float)deg;         // (C <= 64 <= (NW * 64): the thread's own channel only)
             else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
         if (a.head_sel) {
@@ -1382,7 +1386,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
             // selection of a streaming split row: every edge >= thr, ranked.  Rare
             // (needs top_k >= deg > WAVE_T); done by plain counting from the scratch scores.
             const float *sc = a.scores + a.split_soff[p];
-            for (int e = tid; e < deg; e += FINC_BLOCK) {
+            for (int e = tid; e < deg; e += (NW * 64)) {
                 const float se = sc[e];
                 if (!(se >= a.thr)) continue;
                 int rk = 0;
@@ -1395,7 +1399,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     }
 
     int n = (t1 - t0) * a.k;
-    for (int q = tid; q < n; q += FINC_BLOCK) {
+    for (int q = tid; q < n; q += (NW * 64)) {
         kA[q] = a.cand_key[(size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k];
         sA[q] = a.cand_src[(size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k];
     }
@@ -1405,7 +1409,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     // selection - after ONE level (128 per wave needed two levels and a third selection)
     while (n > 128) {
         const int groups = (n + 255) / 256;
-        for (int g = wave; g < groups; g += FINC_WAVES) {
+        for (int g = wave; g < groups; g += NW) {
             unsigned long long key[4];
             int q[4];
             bool kp[4];
@@ -1448,7 +1452,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     // gather first (the long latency), bookkeeping stores behind it
     RowT acc;
     acc.zero();
-    for (int q0 = 0; q0 < nsel; q0 += FINC_WAVES * NG) {
+    for (int q0 = 0; q0 < nsel; q0 += NW * NG) {
         const int q = q0 + wave * NG + gid;
         if (q < nsel) {
             const int j = wsrc[q];
@@ -1457,7 +1461,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
             acc.axpy(key_score(win[q]) * (a.nrm ? a.nrm[j] : 1.0f), x);
         }
     }
-    for (int q = tid; q < nsel; q += FINC_BLOCK) {
+    for (int q = tid; q < nsel; q += (NW * 64)) {
         const unsigned long long kq = win[q];
         const float sq = key_score(kq);
         if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
@@ -1472,9 +1476,9 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     acc.reduce_across_groups();
     if (gid == 0) acc.store(s_part + (size_t)wave * a.C, a.C, lg);
     __syncthreads();
-    for (int ch = tid; ch < a.C; ch += FINC_BLOCK) {
+    for (int ch = tid; ch < a.C; ch += (NW * 64)) {
         float s = 0.f;
-        for (int w = 0; w < FINC_WAVES; ++w) s += s_part[(size_t)w * a.C + ch];
+        for (int w = 0; w < NW; ++w) s += s_part[(size_t)w * a.C + ch];
         if (a.head_sel) s_part[ch] = s / (float)deg;
         else a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
     }
@@ -1484,11 +1488,11 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     }
 }
 
-template <int VEC, int G, int R>
-__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_cand(const FwdArgs a, int max_slots)
+template <int VEC, int G, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void k_agg_fin_cand(const FwdArgs a, int max_slots)
 {
     extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
-    fin_cand_row<VEC, G, R>(a, blockIdx.x, max_slots, dyn);
+    fin_cand_row<VEC, G, R, NW>(a, blockIdx.x, max_slots, dyn);
 }
 
 // The same finalize for split rows whose candidates fit one wave-level selection
@@ -1613,26 +1617,26 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
 // split rows in all): workgroups [0, n_big) run the tournament of one big row each, the
 // others one moderate row per wave - 140 workgroups that all start at once instead of 825
 // tournaments of which 512 fit the chip (finalize 8.8 -> see DESIGN.md 4.1).
-template <int VEC, int G, int R>
-__global__ __launch_bounds__(FINC_BLOCK) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split,
+template <int VEC, int G, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split,
                                                               int n_fin_blocks)
 {
     extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
     if ((int)blockIdx.x >= n_fin_blocks) {                 // (workgroup-uniform) the head role of the launch
         const int hb = (int)blockIdx.x - n_fin_blocks;
-        const HeadAcc ha = head_rows_role<VEC, G, R>(a, hb * FINC_WAVES + (threadIdx.x >> 6), a.head_nmain * FINC_WAVES);
+        const HeadAcc ha = head_rows_role<VEC, G, R>(a, hb * NW + (threadIdx.x >> 6), a.head_nmain * NW);
         head_block_entry(a, hb, ha, reinterpret_cast<float *>(dyn));
         return;
     }
     if ((int)blockIdx.x < n_big) {                         // (workgroup-uniform)
-        fin_cand_row<VEC, G, R>(a, blockIdx.x, max_slots, dyn);
+        fin_cand_row<VEC, G, R, NW>(a, blockIdx.x, max_slots, dyn);
         return;
     }
     const int wave = threadIdx.x >> 6;
-    const int p = n_big + ((int)blockIdx.x - n_big) * FINC_WAVES + wave;
+    const int p = n_big + ((int)blockIdx.x - n_big) * NW + wave;
     if (p >= n_split) return;                              // wave-uniform
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(dyn) + wave * CAND_MAX_K;
-    int *s_src = reinterpret_cast<int *>(dyn + FINC_WAVES * CAND_MAX_K * 8) + wave * CAND_MAX_K;
+    int *s_src = reinterpret_cast<int *>(dyn + NW * CAND_MAX_K * 8) + wave * CAND_MAX_K;
     fin_wave_row<VEC, G, R>(a, p, s_key, s_src);
 }
 
@@ -1670,38 +1674,53 @@ int launch_head_rows(const FwdArgs &a, hipStream_t st)
     return SNGNN_OK;
 }
 
+// waves per workgroup of the candidate finalize for a call (FINC_WAVES_MAX's comment)
+inline int finc_waves(const FwdArgs &a, int max_split_deg)
+{
+    const int64_t max_slots = (int64_t)ceil_div(max_split_deg, CHUNK) * std::max(a.k, 0);
+    return (a.head_sel == nullptr && (a.k < 0 || max_slots > 1024)) ? 16 : 8;
+}
+
+// the candidate finalize's launches at NW waves per workgroup
+template <int VEC, int G, int R, int NW>
+int launch_cand_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
+{
+    const int max_tasks = ceil_div(max_split_deg, CHUNK);
+    const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
+    const size_t dyn = finc_lds_bytes(a.C, max_slots, NW);
+    if (dyn > FINC_LDS_BUDGET) { set_error("internal: candidate finalize does not fit LDS"); return SNGNN_EINVAL; }
+    if (dyn > 48 * 1024)
+        SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R, NW>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const FinShape fs = finalize_shape(a);
+    const int n_wave = fs.n_wave, n_big = fs.n_big, n_big_true = fs.n_big_true;
+    if (fs.mixed) {
+        // few moderate rows: one mixed launch
+        const size_t dyn_mixed = std::max(dyn, (size_t)NW * CAND_MAX_K * 12);
+        if (dyn_mixed > 48 * 1024)
+            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R, NW>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_mixed));
+        const int n_fin_blocks = n_big_true + ceil_div(n_wave, NW);
+        const int n_head_blocks = a.head_sel ? a.head_nmain : 0;
+        k_agg_fin_mixed<VEC, G, R, NW><<<n_fin_blocks + n_head_blocks, NW * 64, dyn_mixed, st>>>(
+            a, max_slots, n_big_true, a.n_split, n_fin_blocks);
+    } else {
+        launch_head_rows<VEC, G, R>(a, st);
+        if (n_big > 0) k_agg_fin_cand<VEC, G, R, NW><<<n_big, NW * 64, dyn, st>>>(a, max_slots);
+        if (a.n_split > n_big)
+            k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
+    }
+    return SNGNN_OK;
+}
+
 // launches of the split rows' finalize (after their tasks, same stream)
 template <int VEC, int G, int R>
 int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 {
     if (a.n_split > 0 && a.use_cand) {
         // streaming rows and candidate tournament
-        const int max_tasks = ceil_div(max_split_deg, CHUNK);
-        const int max_slots = std::max(1, max_tasks * std::max(a.k, 0));
-        const size_t dyn = finc_lds_bytes(a.C, max_slots);
-        if (dyn > FINC_LDS_BUDGET) { set_error("internal: candidate finalize does not fit LDS"); return SNGNN_EINVAL; }
-        if (dyn > 48 * 1024)
-            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        const FinShape fs = finalize_shape(a);
-        const int n_wave = fs.n_wave, n_big = fs.n_big, n_big_true = fs.n_big_true;
-        if (fs.mixed) {
-            // few moderate rows: one mixed launch
-            const size_t dyn_mixed = std::max(dyn, (size_t)FINC_WAVES * CAND_MAX_K * 12);
-            if (dyn_mixed > 48 * 1024)
-                SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_mixed));
-            const int n_fin_blocks = n_big_true + ceil_div(n_wave, FINC_WAVES);
-            const int n_head_blocks = a.head_sel ? a.head_nmain : 0;
-            k_agg_fin_mixed<VEC, G, R><<<n_fin_blocks + n_head_blocks, FINC_BLOCK, dyn_mixed, st>>>(
-                a, max_slots, n_big_true, a.n_split, n_fin_blocks);
-            return SNGNN_OK;
-        } else {
-            launch_head_rows<VEC, G, R>(a, st);
-            if (n_big > 0) k_agg_fin_cand<VEC, G, R><<<n_big, FINC_BLOCK, dyn, st>>>(a, max_slots);
-            if (a.n_split > n_big)
-                k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
-        }
+        if (finc_waves(a, max_split_deg) == 16) return launch_cand_finalize<VEC, G, R, 16>(a, max_split_deg, st);
+        return launch_cand_finalize<VEC, G, R, 8>(a, max_split_deg, st);
     } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)std::min(std::max(a.k, 0), max_split_deg) * 4;
         const size_t budget = 120 * 1024;
@@ -1734,8 +1753,8 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     FwdArgs a = a0;
     // head_part: one entry per workgroup of the head role, then one per split row.  (The role rides in the
-    // mixed finalize launch - FINC_BLOCK threads - where there is one, else in a launch of its own.)
-    a.head_nmain = a.head_sel ? head_role_blocks(a.N, G, head_role_in_finalize(a) ? FINC_BLOCK : BLOCK) : 0;
+    // mixed finalize launch - 512 threads then - where there is one, else in a launch of its own.)
+    a.head_nmain = a.head_sel ? head_role_blocks(a.N, G, head_role_in_finalize(a) ? 512 : BLOCK) : 0;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     for (int rep = 0; rep < reps && grid > 0; ++rep) {
         if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
