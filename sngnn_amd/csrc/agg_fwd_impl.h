@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void fin_row_head(const FwdArgs &a, int i, int p, con
     }
 }
 
-template <int VEC, int G, int R, int NW>
+template <int VEC, int G, int R, int NW, bool HEAD>
 __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_slots, unsigned char *dyn)
 {
     using RowT = Row<VEC, G, R>;
@@ -1375,10 +1375,10 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         for (int c = tid; c < a.C; c += (NW * 64)) {
             float s = 0.f;
             for (int w = 0; w < FINC_WAVES_MAX; ++w) s += s_part[(size_t)w * a.C + c];
-            if (a.head_sel) s_part[c] = s / (float)deg;         // (C <= 64 <= (NW * 64): the thread's own channel only)
+            if constexpr (HEAD) s_part[c] = s / (float)deg;     // (C <= 64 <= (NW * 64): the thread's own channel only)
             else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
-        if (a.head_sel) {
+        if constexpr (HEAD) {
             __syncthreads();
             fin_row_head<VEC, G, R>(a, i, p, s_part);
         }
@@ -1479,20 +1479,20 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
     for (int ch = tid; ch < a.C; ch += (NW * 64)) {
         float s = 0.f;
         for (int w = 0; w < NW; ++w) s += s_part[(size_t)w * a.C + ch];
-        if (a.head_sel) s_part[ch] = s / (float)deg;
+        if constexpr (HEAD) s_part[ch] = s / (float)deg;
         else a.out[(size_t)i * a.C + ch] = a.epilogue(s / (float)deg, i, ch);
     }
-    if (a.head_sel) {
+    if constexpr (HEAD) {
         __syncthreads();
         fin_row_head<VEC, G, R>(a, i, p, s_part);
     }
 }
 
-template <int VEC, int G, int R, int NW>
+template <int VEC, int G, int R, int NW, bool HEAD>
 __global__ __launch_bounds__(NW * 64) void k_agg_fin_cand(const FwdArgs a, int max_slots)
 {
     extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
-    fin_cand_row<VEC, G, R, NW>(a, blockIdx.x, max_slots, dyn);
+    fin_cand_row<VEC, G, R, NW, HEAD>(a, blockIdx.x, max_slots, dyn);
 }
 
 // The same finalize for split rows whose candidates fit one wave-level selection
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(NW * 64) void k_agg_fin_cand(const FwdArgs a, int m
 // barrier.  On graphs with many moderately large rows
 // (products-like: ~10^5 split rows) the 1024-thread tournament above is mostly idle.
 // s_key_w / s_src_w: the wave's own CAND_MAX_K LDS slots.
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool HEAD>
 __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned long long *s_key_w, int *s_src_w)
 {
     using RowT = Row<VEC, G, R>;
@@ -1511,10 +1511,9 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     const int i = d.x, rs = d.y, deg = d.z;
     if (a.skip_row(i)) return;                              // (wave-uniform)
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    const bool head = a.head_sel != nullptr;
     int head_yy = 0;
     unsigned head_sv = 0u;
-    if (head) { head_yy = (int)a.head_y[i]; head_sv = a.head_sel[i]; }
+    if constexpr (HEAD) { head_yy = (int)a.head_y[i]; head_sv = a.head_sel[i]; }
     if (a.k < 0) {
         // (rows of at most 16 tasks come here: their partial rows are loaded together)
         float *s_row = reinterpret_cast<float *>(s_key_w);      // head: the row through LDS (C <= 64 floats fit)
@@ -1526,10 +1525,10 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += v[u];
             for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-            if (head) s_row[c] = s / (float)deg;
+            if constexpr (HEAD) s_row[c] = s / (float)deg;
             else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
         }
-        if (head) {
+        if constexpr (HEAD) {
             if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
                 wave_lds_sync();
                 HeadAcc ha;
@@ -1591,7 +1590,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     }
     acc.reduce_across_groups();
     acc.div((float)deg);
-    if (head) {
+    if constexpr (HEAD) {
         HeadAcc ha;
         if (gid == 0) head_store_row<VEC, G, R>(a, acc, i, lg, head_yy, head_sv, ha);
         head_write_entry(a, a.head_nmain + p, ha);
@@ -1602,7 +1601,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
 }
 
 // 4 rows per 256-thread workgroup
-template <int VEC, int G, int R>
+template <int VEC, int G, int R, bool HEAD>
 __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int first, int count)
 {
     __shared__ unsigned long long s_key[WAVES][CAND_MAX_K];
@@ -1610,26 +1609,30 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     const int wave = threadIdx.x >> 6;
     const int q = blockIdx.x * WAVES + wave;
     if (q >= count) return;                                   // wave-uniform
-    fin_wave_row<VEC, G, R>(a, first + q, s_key[wave], s_src[wave]);
+    fin_wave_row<VEC, G, R, HEAD>(a, first + q, s_key[wave], s_src[wave]);
 }
 
 // Both in ONE launch when the moderate split rows are few (arxiv-like graphs: a few hundred
 // split rows in all): workgroups [0, n_big) run the tournament of one big row each, the
 // others one moderate row per wave - 140 workgroups that all start at once instead of 825
 // tournaments of which 512 fit the chip (finalize 8.8 -> see DESIGN.md 4.1).
-template <int VEC, int G, int R, int NW>
+// HEAD: its own instantiation (the head's code inside the plain one cost it 9 registers, 12 bytes of
+// scratch per lane and ~0.5 us of the headline step)
+template <int VEC, int G, int R, int NW, bool HEAD>
 __global__ __launch_bounds__(NW * 64) void k_agg_fin_mixed(const FwdArgs a, int max_slots, int n_big, int n_split,
                                                               int n_fin_blocks)
 {
     extern __shared__ __align__(16) unsigned char dyn[];   // no static LDS in front of it
-    if ((int)blockIdx.x >= n_fin_blocks) {                 // (workgroup-uniform) the head role of the launch
-        const int hb = (int)blockIdx.x - n_fin_blocks;
-        const HeadAcc ha = head_rows_role<VEC, G, R>(a, hb * NW + (threadIdx.x >> 6), a.head_nmain * NW);
-        head_block_entry(a, hb, ha, reinterpret_cast<float *>(dyn));
-        return;
+    if constexpr (HEAD) {
+        if ((int)blockIdx.x >= n_fin_blocks) {             // (workgroup-uniform) the head role of the launch
+            const int hb = (int)blockIdx.x - n_fin_blocks;
+            const HeadAcc ha = head_rows_role<VEC, G, R>(a, hb * NW + (threadIdx.x >> 6), a.head_nmain * NW);
+            head_block_entry(a, hb, ha, reinterpret_cast<float *>(dyn));
+            return;
+        }
     }
     if ((int)blockIdx.x < n_big) {                         // (workgroup-uniform)
-        fin_cand_row<VEC, G, R, NW>(a, blockIdx.x, max_slots, dyn);
+        fin_cand_row<VEC, G, R, NW, HEAD>(a, blockIdx.x, max_slots, dyn);
         return;
     }
     const int wave = threadIdx.x >> 6;
@@ -1637,7 +1640,7 @@ __global__ __launch_bounds__(NW * 64) void k_agg_fin_mixed(const FwdArgs a, int 
     if (p >= n_split) return;                              // wave-uniform
     unsigned long long *s_key = reinterpret_cast<unsigned long long *>(dyn) + wave * CAND_MAX_K;
     int *s_src = reinterpret_cast<int *>(dyn + NW * CAND_MAX_K * 8) + wave * CAND_MAX_K;
-    fin_wave_row<VEC, G, R>(a, p, s_key, s_src);
+    fin_wave_row<VEC, G, R, HEAD>(a, p, s_key, s_src);
 }
 
 // whether split rows keep chunk-local candidates (else: scores to HBM scratch + k_agg_fin)
@@ -1682,7 +1685,7 @@ inline int finc_waves(const FwdArgs &a, int max_split_deg)
 }
 
 // the candidate finalize's launches at NW waves per workgroup
-template <int VEC, int G, int R, int NW>
+template <int VEC, int G, int R, int NW, bool HEAD>
 int launch_cand_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 {
     const int max_tasks = ceil_div(max_split_deg, CHUNK);
@@ -1690,7 +1693,7 @@ int launch_cand_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
     const size_t dyn = finc_lds_bytes(a.C, max_slots, NW);
     if (dyn > FINC_LDS_BUDGET) { set_error("internal: candidate finalize does not fit LDS"); return SNGNN_EINVAL; }
     if (dyn > 48 * 1024)
-        SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R, NW>,
+        SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_cand<VEC, G, R, NW, HEAD>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const FinShape fs = finalize_shape(a);
     const int n_wave = fs.n_wave, n_big = fs.n_big, n_big_true = fs.n_big_true;
@@ -1698,17 +1701,17 @@ int launch_cand_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
         // few moderate rows: one mixed launch
         const size_t dyn_mixed = std::max(dyn, (size_t)NW * CAND_MAX_K * 12);
         if (dyn_mixed > 48 * 1024)
-            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R, NW>,
+            SN_HIP(hipFuncSetAttribute((const void *)k_agg_fin_mixed<VEC, G, R, NW, HEAD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_mixed));
         const int n_fin_blocks = n_big_true + ceil_div(n_wave, NW);
-        const int n_head_blocks = a.head_sel ? a.head_nmain : 0;
-        k_agg_fin_mixed<VEC, G, R, NW><<<n_fin_blocks + n_head_blocks, NW * 64, dyn_mixed, st>>>(
+        const int n_head_blocks = HEAD ? a.head_nmain : 0;
+        k_agg_fin_mixed<VEC, G, R, NW, HEAD><<<n_fin_blocks + n_head_blocks, NW * 64, dyn_mixed, st>>>(
             a, max_slots, n_big_true, a.n_split, n_fin_blocks);
     } else {
-        launch_head_rows<VEC, G, R>(a, st);
-        if (n_big > 0) k_agg_fin_cand<VEC, G, R, NW><<<n_big, NW * 64, dyn, st>>>(a, max_slots);
+        if constexpr (HEAD) launch_head_rows<VEC, G, R>(a, st);
+        if (n_big > 0) k_agg_fin_cand<VEC, G, R, NW, HEAD><<<n_big, NW * 64, dyn, st>>>(a, max_slots);
         if (a.n_split > n_big)
-            k_agg_fin_wave<VEC, G, R><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
+            k_agg_fin_wave<VEC, G, R, HEAD><<<ceil_div(a.n_split - n_big, WAVES), BLOCK, 0, st>>>(a, n_big, a.n_split - n_big);
     }
     return SNGNN_OK;
 }
@@ -1719,8 +1722,11 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 {
     if (a.n_split > 0 && a.use_cand) {
         // streaming rows and candidate tournament
-        if (finc_waves(a, max_split_deg) == 16) return launch_cand_finalize<VEC, G, R, 16>(a, max_split_deg, st);
-        return launch_cand_finalize<VEC, G, R, 8>(a, max_split_deg, st);
+        if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+            if (a.head_sel) return launch_cand_finalize<VEC, G, R, 8, true>(a, max_split_deg, st);
+        }
+        if (finc_waves(a, max_split_deg) == 16) return launch_cand_finalize<VEC, G, R, 16, false>(a, max_split_deg, st);
+        return launch_cand_finalize<VEC, G, R, 8, false>(a, max_split_deg, st);
     } else if (a.n_split > 0) {
         const size_t fixed = (size_t)a.C * (FIN_BLOCK / 64) * 4 + (size_t)std::min(std::max(a.k, 0), max_split_deg) * 4;
         const size_t budget = 120 * 1024;
