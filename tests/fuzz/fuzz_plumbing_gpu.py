@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check (not part of the suite) of the kernels around the aggregation: self.lin
-forward / weight gradient (MFMA paths and fallbacks), the fused head and the blend, on random
-shapes against PyTorch.  usage: fuzz_plumbing_gpu.py [seconds] [first_seed]"""
+forward / weight gradient (MFMA paths and fallbacks), the fused head (stand-alone and inside the
+aggregation's launches) and the blend, on random shapes against PyTorch.  usage: fuzz_plumbing_gpu.py [seconds] [first_seed]"""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
-cases = 0
+cases = head_cases = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 15, 16, 17, 63, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 5000, 16384, 30001]))
@@ -74,6 +74,42 @@ while time.time() < t_end:
             assert abs(float(loss) - float(lref)) <= 3e-6 * max(1.0, abs(float(lref))), "head loss"
             assert int(corr) == int((z.detach()[mask].max(1)[1] == y[mask]).sum()), "head accuracy"
             assert (z.grad - gz).abs().max() <= 2e-6 * max(1e-3, float(gz.abs().max())) + 1e-9, "head grad"
+        # the head inside the aggregation's launches (ops.HeadEpilogue) on a random graph over the same rows:
+        # gradient rows bit-equal to the stand-alone head's on the stored logits, metrics to 2e-6
+        if c % 4 == 0 and c <= 64 and 2 <= n <= 20000:
+            from sngnn_amd.graph import Graph
+            from tests.helpers import random_graph
+            nh = int(rng.integers(0, 3))
+            hubs = tuple((int(rng.integers(0, n)), int(rng.integers(1, n + 1))) for _ in range(nh))
+            ei = random_graph(n, int(rng.integers(1, 8 * n)), seed=seed, hubs=hubs)
+            gph = Graph(ei.to(dev), n, True, bool(rng.integers(0, 2)))
+            kk = rng.choice([None, 1, 2, 16, 31])
+            kk = None if kk is None else int(kk)
+            thr_h = float(rng.choice([-1.5, 0.0, 0.3]))
+            if ops.head_supported(gph, c, kk):
+                hh = z.detach()
+                bias_h = (torch.randn(c, generator=gen) * 0.3).to(dev) if rng.integers(0, 2) else None
+                logits = ops.aggregate_forward(gph, hh, kk, thr_h)[0]
+                if bias_h is not None:
+                    logits = logits + bias_h
+                m8 = mask.to(torch.uint8)
+                nm = max(int(mask.sum()), 1)
+                (l0, c0), g0 = ops.head_nll_with_grad(logits, y, m8, nm)
+                met = torch.zeros(2, device=dev)
+                gfused = ops.aggregate(hh, gph, kk, thr_h, None, None, bias_h, ops.HeadEpilogue(y, m8, met, nm, grad=True))
+                assert torch.equal(gfused, g0), "head epilogue gradient"
+                assert float(met[1]) == float(c0) and abs(float(met[0]) - float(l0)) <= 2e-6 * max(1.0, abs(float(l0))), \
+                    "head epilogue metrics"
+                sets = (torch.randint(0, 4, (n,), generator=gen)).to(torch.uint8).to(dev)
+                na, nb = max(int((sets & 1).ne(0).sum()), 1), max(int((sets & 2).ne(0).sum()), 1)
+                m4r = ops.head_nll2(logits, y, sets, na, nb)
+                m4 = torch.zeros(4, device=dev)
+                lg2 = ops.aggregate(hh, gph, kk, thr_h, None, None, bias_h, ops.HeadEpilogue(y, sets, m4, na, nb))
+                assert torch.equal(lg2, logits), "head epilogue leaves the logits"
+                assert float(m4[1]) == float(m4r[1]) and float(m4[3]) == float(m4r[3]), "head epilogue counts"
+                for qq in (0, 2):
+                    assert abs(float(m4[qq]) - float(m4r[qq])) <= 2e-6 * max(1.0, abs(float(m4r[qq]))), "head epilogue losses"
+                head_cases += 1
         # blend
         o0 = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
         o1 = torch.randn(n, c, generator=gen).to(dev).requires_grad_(True)
@@ -95,4 +131,4 @@ while time.time() < t_end:
     seed += 1
     if cases % 100 == 0:
         print(f"{cases} cases ok (last {tag})", flush=True)
-print(f"done: {cases} random cases passed, next seed {seed}")
+print(f"done: {cases} random cases passed ({head_cases} with the head inside the aggregation), next seed {seed}")
