@@ -73,6 +73,18 @@ class Graph:
             self._ws[key] = ws
         return ws
 
+    def head_workspace(self) -> torch.Tensor:
+        """Scratch of the classification head inside this graph's forward (``sngnn_epilogue_t.head_workspace``):
+        one buffer per stream, owned by the graph like :meth:`workspace` - a captured epoch that holds the
+        graph holds the buffer its launches point into."""
+        key = ("head", torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = int(_lib.load().sngnn_agg_head_workspace_bytes(self._h))
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
     def array(self, name: str) -> np.ndarray:
         """Host copy of one of the structure arrays (tests / inspection)."""
         which = _ARRAYS[name]

@@ -406,7 +406,7 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optiona
     if head is not None:
         if head.y.numel() != n or head.sel.numel() != n or head.y.device != h.device or head.sel.device != h.device:
             raise ValueError("head: y and sel must hold one entry per target row, on h's device")
-        hws = _workspace("agg_head", lib.sngnn_agg_head_workspace_bytes(graph.handle), h.device)
+        hws = graph.head_workspace()
         st.head_y, st.head_sel = head.y.data_ptr(), head.sel.data_ptr()
         st.head_sets, st.head_out_mode = head.sets, head.out_mode
         st.head_n_a, st.head_n_b = head.n_a, head.n_b
