@@ -22,6 +22,10 @@ CASES = [
     (2000, 12000, 12, 1, 0.0, ((0, 1999),)),
     (500, 3000, 4, 3, -1.0, ()),
     (40000, 300000, 40, 16, 0.0, ((0, 30000), (1, 9000), (2, 1100))),
+    # products-like: thousands of moderate split rows - the finalize is two launches (tournament rows,
+    # wave rows) and the head role a launch of its own in front of them
+    (6000, 1300000, 40, 16, 0.0, ((0, 5000), (1, 2500))),
+    (6000, 1300000, 8, None, 0.0, ((0, 5000),)),
 ]
 
 
