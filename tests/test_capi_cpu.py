@@ -68,3 +68,28 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "sngnn_oracle" not in src, f
+
+
+def test_epilogue_struct_layout_matches_the_header(tmp_path):
+    """``_lib.Epilogue`` (ctypes) against ``sngnn_epilogue_t`` as a C compiler lays it out: size and
+    the offset of every field (a mismatch would hand the library garbage pointers silently)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from sngnn_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    fields = [name for name, _ in _lib.Epilogue._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sngnn_hip.h"', 'int main(void) {',
+             '  printf("size %zu\\n", sizeof(sngnn_epilogue_t));']
+    lines += [f'  printf("{f} %zu\\n", offsetof(sngnn_epilogue_t, {f}));' for f in fields]
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([cc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["size"]) == C.sizeof(_lib.Epilogue)
+    for f in fields:
+        assert int(out[f]) == getattr(_lib.Epilogue, f).offset, f
