@@ -201,3 +201,33 @@ def test_agnn_graphed_epoch_matches_eager(cuda):
     for a, b in zip(runs[0]["history"], runs[1]["history"]):
         for k in ("train_loss", "val_loss", "test_loss", "train_acc", "val_acc", "test_acc"):
             assert abs(a[k] - b[k]) <= 1e-4 * max(1.0, abs(a[k])), (a["epoch"], k, a[k], b[k])
+
+
+def test_attention_at_full_arxiv_size_against_oracle_autograd(cuda):
+    """The cosine-attention mode at BASELINE config 4's size (169 343 nodes, 1.16 M edges, the 13 k-edge
+    hub: split rows of more than a hundred tasks, the task-wide finalizes), C = 40: forward, alpha and
+    the gradient against the oracle's restatement of AGNNConv (models.py:377-405) and its autograd."""
+    from sngnn_amd import ops, synth
+    from sngnn_amd.graph import Graph, LOOPS_REPLACE
+    d = synth.make_dataset("arxiv", with_features=False)
+    n = d.x.size(0)
+    gen = torch.Generator().manual_seed(11)
+    h = torch.randn(n, 40, generator=gen)
+    gout = torch.randn(n, 40, generator=gen)
+    h_ref = h.clone().requires_grad_(True)
+    ref = O.attention_reference(h_ref, d.edge_index)
+    (ref["out"] * gout).sum().backward()
+    g = Graph(d.edge_index.to(cuda), n, True, LOOPS_REPLACE)
+    assert g.num_edges == ref["ei"].size(1) and g.max_in_degree > 10000
+    out, alpha = ops.attention_forward(g, h.to(cuda))
+    assert_close(out, ref["out"])
+    eid = torch.from_numpy(g.array("eid").astype(np.int64))
+    a_list = torch.empty(g.num_edges)
+    a_list[eid] = alpha.cpu()
+    assert_close(a_list, ref["alpha"], what="alpha", rtol=1e-5, atol=1e-7)
+    # every row's coefficients sum to one (the hub's 13 k of them too)
+    sums = torch.zeros(n).index_add_(0, ref["ei"][1], a_list)
+    assert float((sums - 1).abs().max()) <= 2e-5
+    hg = h.to(cuda).requires_grad_(True)
+    (ops.attention(hg, g) * gout.to(cuda)).sum().backward()
+    assert_grad_close(hg.grad, h_ref.grad, "grad_h at arxiv size")
