@@ -124,3 +124,34 @@ def test_signed_propagate_is_deterministic_and_caches_its_structure(cuda):
     assert layer._structure is st
     with pytest.raises(ValueError):
         layer(h, adj, dp)                                  # CPU features: no CPU path
+
+
+def test_layer_at_arxiv_size_against_the_oracle(cuda):
+    """GGCNlayer_SP on the symmetrised, self-looped, symmetrically normalised adjacency of BASELINE config
+    4's graph (169 343 nodes, 2.4 M off-diagonal entries; the hub's row has > 13 000 of them: split rows
+    of the signed-attention kernels), C = 40: output, grad_h and all five parameter gradients."""
+    from sngnn_amd import synth
+    from sngnn_amd.ggcn import precompute_degree_s
+    d = synth.make_dataset("arxiv", with_features=False)
+    n = d.x.size(0)
+    ei = d.edge_index
+    ei = ei[:, ei[0] != ei[1]]
+    both = torch.cat([ei, ei.flip(0), torch.arange(n).repeat(2, 1)], dim=1)
+    a = torch.sparse_coo_tensor(both, torch.ones(both.size(1)), (n, n)).coalesce()
+    idx = a._indices()
+    deg = torch.zeros(n).index_add_(0, idx[0], torch.ones(idx.size(1)))          # duplicates merged: 0/1 pattern
+    val = 1.0 / torch.sqrt(deg[idx[0]] * deg[idx[1]])
+    adj = torch.sparse_coo_tensor(idx, val, (n, n)).coalesce()
+    dp = O.ggcn_degree_precompute(adj)
+    assert torch.equal(precompute_degree_s(adj.to(cuda))._values().cpu(), dp._values())
+    f, c = 24, 40
+    gen = torch.Generator().manual_seed(21)
+    h = torch.randn(n, f, generator=gen)
+    gout = torch.randn(n, c, generator=gen)
+    torch.manual_seed(21)
+    ref = O.GGCNlayer_SP(f, c, "cpu")
+    with torch.no_grad():
+        ref.coeff.copy_(torch.tensor([0.5, -0.3, 0.2]))
+        ref.deg_coeff.copy_(torch.tensor([0.4, -0.1]))
+    ours, ref = _layer_pair(f, c, dict(), ref.state_dict(), cuda)
+    _compare(ours, ref, adj, dp, h, gout, cuda)
