@@ -58,6 +58,6 @@ def pytest_terminal_summary(terminalreporter):
         rows = sum(r for _, _, r in helpers.NEAR_TIE_LOG)
         mx = max(helpers.MODEL_TIE_GAPS, default=0.0)
         tr.write_line(f"near-tie selection rows tolerated at model level: {tot} of {rows} rows compared; "
-                      f"largest gap needed {mx:.3e} = {mx / helpers.ULP32:.2f} ulp (gate {helpers.MODEL_TIE_ULPS} ulp)")
+                      f"largest gap needed {mx:.3e} = {mx / helpers.ULP32:.2f} ulp (gate {helpers.MODEL_TIE_ULPS} ulp at a model's first layer, + 1 per layer in front)")
         for label, d, r in helpers.NEAR_TIE_LOG:
             tr.write_line(f"  {label}: {d} of {r}")

@@ -155,8 +155,11 @@ REPORT_LINES = []       # free-form lines for the summary (measured errors of th
 OPERATOR_TIE_LOG = []   # the same at operator level (same inputs on both sides)
 # Model level: the two sides' ``lin`` results differ in the last ulp (rocBLAS / MFMA vs the CPU's
 # GEMM), so the cosines differ by an INPUT perturbation on top of the summation order: one more
-# ulp per operand.  Gate 3 ulps (2 + 1 for the perturbed operand; round 3 allowed 5; the measured
-# maximum over the full-size configs is 1.5), gaps logged separately.
+# ulp per operand.  Gate 3 ulps at a model's FIRST layer (2 + 1 for the perturbed operand; round 3
+# allowed 5; the measured maximum over configs 1-3 at full size is 1.5, config 4's 1-layer model: no
+# differing row of 169 343) and one more ulp per layer in front (that layer's ``lin`` and aggregation
+# round differently on the two sides as well: the second layer of config 4's 2-layer model, whose input
+# rows are nearly parallel - every cosine within 1.3e-5 of 1 - needs 3.5), gaps logged separately.
 MODEL_TIE_ULPS = 3.0
 MODEL_TIE_GAPS = []
 
@@ -166,7 +169,7 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
     compare the rows' selections on each side's OWN ``h = lin(x)`` - the two ``lin`` results
     differ in the last ulp (rocBLAS / MFMA vs the CPU's GEMM), which is where a model-level
     near-tie flip comes from.  A differing row must pass ``check_selection``'s near-tie rule
-    (oracle cosines within MODEL_TIE_ULPS ulps, no structural tie involved).  Returns and logs
+    (oracle cosines within MODEL_TIE_ULPS ulps, + 1 per layer in front; no structural tie involved).  Returns and logs
     (rows that differ, rows compared)."""
     from sngnn_amd import conv as CV
     from sngnn_amd import ops
@@ -198,7 +201,7 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
         _, _, _, sel_src, sel_w = ops.aggregate_forward(g, h_g.contiguous(), int(k), float(cr.thr),
                                                         want_selection=True)
         differ += check_selection(res, sel_src, sel_w, int(k), float(cr.thr), strict=False, h=h_r,
-                                  tie_ulps=MODEL_TIE_ULPS, gaps=MODEL_TIE_GAPS)
+                                  tie_ulps=MODEL_TIE_ULPS + li, gaps=MODEL_TIE_GAPS)
         rows += h_r.size(0)
     NEAR_TIE_LOG.append((label, differ, rows))
     return differ, rows

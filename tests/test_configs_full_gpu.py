@@ -8,7 +8,10 @@ config 2  Chameleon  SNGNN_Plus top_k 10 thr 0.9 hidden 32, 1 layer (README.md:6
                                                           N 2 277  E 36 101  F 2 325  C 5 / 32 -> 5
 config 3  Actor      SNGNN_Plus_Plus top_k 10 thr 0.9 init_beta 0.0
                                                           N 7 600  E 30 019  F 932    C 5 / 32 -> 5
-(configs 4 and 5: tests/test_golden_gpu.py full-arxiv cases, tests/test_products_gpu.py)."""
+config 4  arxiv      SNGNN_Plus top_k 16 thr 0.0, 1 layer (C 40) and 2 layers (32 -> 40)
+                                                          N 169 343  E 1 166 243  F 128
+(config 4's operator alone, forward and backward against the C / torch oracles: tests/test_golden_gpu.py;
+config 5: tests/test_products_gpu.py)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -100,3 +103,19 @@ def test_config3_actor_sngnn_plus_plus_full_size(cuda, layers):
     differ, rows = _check(cuda, "SNGNN_Plus_Plus", (f, 32, 5, n, layers, 10, 0.0, 0.3, 1, 0.0), data,
                           f"actor SNGNN_Plus_Plus {layers}-layer thr=0 beta=0.3", train_modes=(True, False))
     assert differ <= (max(2, rows // 500) if layers == 1 else rows // 50)
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_config4_arxiv_sngnn_plus_full_size(cuda, layers):
+    """The MODEL at config 4's size: 128 -> 40 (README.md:63's shape of a run) and 128 -> 32 -> 40, top_k 16,
+    thr 0.0, loops removed; dropout 0 so that the two sides see the same activations.  Log-probs, every
+    parameter gradient, and the per-row selections of every layer (near ties counted)."""
+    data = synth.make_dataset("arxiv")
+    n, f = data.x.shape
+    assert (n, f) == (169343, 128) and int(torch.bincount(data.edge_index[1], minlength=n).max()) > 10000
+    differ, rows = _check(cuda, "SNGNN_Plus", (f, 32, 40, n, layers, 16, 0.0, 1, 0.0), data,
+                          f"arxiv SNGNN_Plus {layers}-layer", train_modes=(True,))
+    # (1 layer: no differing row.  2 layers: the second conv sees rows that are nearly parallel - every cosine
+    # within 1.3e-5 of 1 - so its 16th and 17th candidates are often a few ulps apart: 119 of its 169 343
+    # rows, each checked to BE such a tie - largest gap 3.5 ulps - and counted in the summary)
+    assert rows == n * layers and differ <= (rows // 5000 if layers == 1 else rows // 1000)
