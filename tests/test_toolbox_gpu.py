@@ -194,6 +194,35 @@ def test_knn_graph_matches_dense_topk(cuda, n, f, k, excl, route):
         assert got[3, 0] == 7 and got[7, 0] == 3
 
 
+@pytest.mark.parametrize("n,f,k", [(40000, 64, 16), (169343, 128, 16)])
+def test_knn_graph_at_large_n_on_sampled_rows(cuda, n, f, k):
+    """Above KNN_DENSE_MAX_N the builder is the fused MFMA scan with its per-row top-k epilogue (N^2 scores
+    never stored; the second case is BASELINE config 4's node count and feature width: 7.3 TFLOP of
+    cosines).  300 sampled rows (the planted duplicate and zero rows among them) against a float64 scan of
+    all N candidates: every returned cosine right, rank order, nothing better than the k-th left out."""
+    from sngnn_amd import toolbox as T
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, f, generator=gen)
+    x[7] = x[3]
+    x[11] = 0.0
+    idx, sim = T.knn_graph(x.to(cuda), k, exclude_self=True)
+    idx, sim = idx.cpu(), sim.cpu()
+    assert (idx >= 0).all() and (idx < n).all()
+    rows = torch.cat([torch.tensor([3, 7, 11, 0, n - 1]), torch.randint(0, n, (295,), generator=gen)])
+    xn = torch.nn.functional.normalize(x.double(), dim=1)
+    S = xn[rows] @ xn.t()                                   # [300, N] in float64
+    S[torch.arange(rows.numel()), rows] = -float("inf")     # exclude_self
+    got, gs = idx[rows], sim[rows]
+    assert (got != rows.unsqueeze(1)).all()
+    assert all(len(set(r.tolist())) == k for r in got)
+    true = S.gather(1, got)
+    assert (gs.double() - true).abs().max() <= 2e-6
+    assert (gs[:, 1:] <= gs[:, :-1] + 1e-7).all()
+    kth = torch.topk(S, k, dim=1).values[:, -1]
+    assert (true.min(dim=1).values >= kth - 2e-6).all()
+    assert got[0, 0] == 7 and got[1, 0] == 3                # the duplicates find each other first
+
+
 def test_knn_edge_index_feeds_the_conv_layer(cuda):
     import sngnn_amd
     from sngnn_amd import toolbox as T
