@@ -87,6 +87,26 @@ def test_class_similarity_without_forming_S(cuda, n, f, c):
     assert (T.class_similarity_dense_large(x.to(cuda), y.to(cuda)).cpu() - rmat).abs().max() < tol
 
 
+@pytest.mark.parametrize("n,f,c", [(40000, 64, 7), (169343, 128, 40)])
+def test_class_similarity_at_large_n_against_the_closed_form(cuda, n, f, c):
+    """At sizes where S cannot be formed (the second case: config 4's node count, feature width and class
+    count - 28.7 G cosines summed by the tile kernel's epilogue): the block mean over a class pair is
+    <sum of A's unit rows, sum of B's unit rows> / (|A| |B|), which float64 evaluates in O(N F)."""
+    from sngnn_amd import toolbox as T
+    x = torch.randn(n, f, generator=torch.Generator().manual_seed(c))
+    y = torch.randint(0, c, (n,), generator=torch.Generator().manual_seed(n))
+    y[:c] = torch.arange(c)
+    mat = T.class_similarity_dense_large(x.to(cuda), y.to(cuda)).cpu().double()
+    xn = torch.nn.functional.normalize(x, dim=1).double()          # (the reference normalises in fp32)
+    sums = torch.zeros(c, f, dtype=torch.float64).index_add_(0, y, xn)
+    cnt = torch.bincount(y, minlength=c).double()
+    want = (sums @ sums.t()) / (cnt[:, None] * cnt[None, :])
+    assert mat.shape == want.shape
+    # a block mean is a sum of |A||B| cosines of either sign divided by their number: judged on the scale of
+    # the diagonal blocks (which hold the |A| ones of the self pairs) and of fp32 sums of that many terms
+    assert float((mat - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-7
+
+
 def test_toolbox_argument_errors(cuda):
     from sngnn_amd import toolbox as T
     x = torch.randn(10, 4)
