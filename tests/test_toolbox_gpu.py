@@ -107,6 +107,37 @@ def test_class_similarity_at_large_n_against_the_closed_form(cuda, n, f, c):
     assert float((mat - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-7
 
 
+def test_graph_statistics_at_config4_size(cuda):
+    """The "large" statistics (dense.py:9-101) on config 4's graph and feature shape, where the reference
+    loops over 1 000-row blocks / over every node in Python: node similarity against the closed form
+    |sum of unit rows|^2 in float64; linked-node and neighbourhood similarity against a float64 per-edge
+    cosine and its group means."""
+    from sngnn_amd import synth
+    from sngnn_amd import toolbox as T
+    d = synth.make_dataset("arxiv")
+    x, ei = d.x, d.edge_index
+    n = x.size(0)
+    xn = torch.nn.functional.normalize(x, dim=1).double()
+    # node similarity: the reference's value (its precedence slip included) and the corrected mean
+    total = float(xn.sum(0).square().sum())
+    _, quirk = T.node_similarity_dense_large_parted(x.to(cuda))
+    _, mean = T.node_similarity_dense_large_parted(x.to(cuda), corrected=True)
+    assert abs(float(quirk) - (total - n) / (n - 1) * n) <= 2e-5 * abs((total - n) / (n - 1) * n) + 1e-3
+    assert abs(float(mean) - (total - n) / (n * (n - 1.0))) <= 2e-5 * abs(total / (n * (n - 1.0))) + 1e-9
+    # per-edge cosines, listed by (src, dst) order; means per source node
+    order = torch.argsort(ei[0] * n + ei[1], stable=True)
+    es = ei[:, order]
+    cos = (xn[es[0]] * xn[es[1]]).sum(1)
+    sim, m = T.linked_node_similarity_dense_large(x.to(cuda), ei.to(cuda))
+    assert float((sim.cpu().double().flatten() - cos).abs().max()) <= 2e-6
+    assert abs(float(m) - float(cos.mean())) <= 2e-6
+    per_node, nm = T.neighborhood_similarity_dense_large(x.to(cuda), ei.to(cuda))
+    cnt = torch.bincount(es[0], minlength=n).double()
+    want = torch.zeros(n, dtype=torch.float64).index_add_(0, es[0], cos) / cnt.clamp_min(1)
+    assert float((per_node.cpu().double().flatten() - want).abs().max()) <= 5e-6
+    assert abs(float(nm) - float(want.sum() / n)) <= 2e-6
+
+
 def test_toolbox_argument_errors(cuda):
     from sngnn_amd import toolbox as T
     x = torch.randn(10, 4)
