@@ -72,7 +72,7 @@ static int backward_impl(const sngnn_graph_t *g, const float *h, int C, const fl
     // workspace layout (sngnn_graph_workspace_bytes): [2 floats per edge: the kept-bit mask
     // lives in its first words; the attention mode keeps records there] | dnT | partT | partS
     float *ws = (float *)workspace;
-    a.wd = nullptr;
+    a.wd = nullptr; a.rec_dot = nullptr;
     a.kmask = (unsigned *)ws;
     a.kmask_words = (g->Ep + 31) / 32;
     a.Ep = g->Ep;

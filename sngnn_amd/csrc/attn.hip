@@ -62,6 +62,7 @@ extern "C" int sngnn_attn_backward(const sngnn_graph_t *g, const float *h, int C
     a.dnT = ws + ds_len;
     a.partT = a.dnT + (size_t)g->N * C;
     a.partS = a.partT + (size_t)g->n_tasks * (2 * C + 4);
+    a.rec_dot = a.partS + (size_t)g->n_stasks * 2 * C;
     a.grad_h = grad_h;
     a.n_split = g->n_split; a.n_med_end = g->rows_gt(SMALL_T); a.n_tasks = g->n_tasks;
     a.task_slot = g->task_slot; a.task_chunk = g->task_chunk; a.split_task0 = g->split_task0;

@@ -292,8 +292,9 @@ __device__ __forceinline__ void attn_t_small(const BwdArgs &a, int blk, int *lds
     }
     fma_row<VEC, G, R>(A, -dot, B);                       // dnT_i = A - dot * B
     A.store(a.dnT + (size_t)i * a.C, a.C, lg);
+    if (lg == 0) a.rec_dot[i] = dot;
     wave_lds_sync();
-    for (int t = lg; t < deg; t += G) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
+    for (int t = lg; t < deg; t += G) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_t[t]);   // raw: BwdArgs::rec_dot
 }
 
 template <int VEC, int G, int R>
@@ -343,19 +344,20 @@ __device__ __forceinline__ void attn_t_wave(const BwdArgs &a, int blk, int *lds_
     A.reduce_across_groups();
     B.reduce_across_groups();
     wave_lds_sync();
+    // the records carry {alpha_e, t_e}: pass S subtracts dot_i itself (BwdArgs::rec_dot) - a split row's
+    // dot_i is only known after its finalize
+    for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + e0 + t]] = make_float2(s_a[t], s_t[t]);
     if (task) {
-        // records carry the raw t_e for now; the row's finalize knows dot_i and makes them ds_e
         float *p = a.partT + (size_t)tq * (2 * a.C + 4);
         if (gid == 0) {
             A.store(p, a.C, lg);
             B.store(p + a.C, a.C, lg);
             if (lg == 0) p[2 * a.C] = dot;
         }
-        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + e0 + t]] = make_float2(s_a[t], s_t[t]);
     } else {
         fma_row<VEC, G, R>(A, -dot, B);
         if (gid == 0) A.store(a.dnT + (size_t)i * a.C, a.C, lg);
-        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
+        if (lane == 0) a.rec_dot[i] = dot;
     }
 }
 
@@ -370,13 +372,11 @@ __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t(const BwdArgs a)
     else attn_t_small<VEC, G, R>(a, b - a.nbA - a.nbB, lw);
 }
 
-// Split rows after the tasks.  The first version was one 256-thread workgroup per row that summed
-// dot_i with ONE thread and rewrote the row's records one per thread and trip behind a
-// csc_pos -> record chain: 68 us per backward at arxiv size (r04 epoch profile), the 13 k-edge hub's
-// latency chain.  Now one launch, two roles, both task-wide: workgroups [0, n_split) sum the
-// partial rows of one split row into dnT; the others take one TASK per wave and turn its 128
-// records' raw t_e into ds_e.  Every wave derives dot_i itself from the row's task partials
-// (attn_row_dot: the same fixed order everywhere, so dnT and the records use the same bits).
+// Split rows after the tasks: dnT_i and dot_i from the row's task partials, one workgroup per row, every step
+// wide.  (Round 4, two steps.  The first version summed dot_i with ONE thread and rewrote the row's records
+// from raw t_e to ds_e one per thread and trip behind a csc_pos -> record chain: 68 us per backward at arxiv
+// size, the 13 k-edge hub's latency chain.  A wave per 128-edge task for the rewrite: 23 us.  Now no record is
+// rewritten at all - pass S subtracts dot_i itself.)
 __device__ __forceinline__ float attn_row_dot(const BwdArgs &a, int t0, int t1, size_t stride)
 {
     float dp = 0.f;
@@ -391,30 +391,11 @@ static __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t_fin(const BwdArgs a
     __shared__ float sA[WAVES][64], sB[WAVES][64];
     const size_t stride = 2 * (size_t)a.C + 4;
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= a.n_split) {
-        const int tq = ((int)blockIdx.x - a.n_split) * WAVES + q;
-        if (tq >= a.n_tasks) return;
-        const int p = a.task_slot[tq];
-        const int i = a.rperm[p];
-        const int rs = a.rowptr[i];
-        const int e0 = a.task_chunk[tq] * CHUNK;
-        const int n = min(a.rowptr[i + 1] - rs - e0, CHUNK);
-        const float dot = attn_row_dot(a, a.split_task0[p], a.split_task0[p + 1], stride);
-        int cp[CHUNK / 64];
-        float2 rec[CHUNK / 64];
-#pragma unroll
-        for (int u = 0; u < CHUNK / 64; ++u) cp[u] = cl + 64 * u < n ? a.csc_pos[rs + e0 + cl + 64 * u] : -1;
-#pragma unroll
-        for (int u = 0; u < CHUNK / 64; ++u) rec[u] = cp[u] >= 0 ? a.wd[cp[u]] : make_float2(0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < CHUNK / 64; ++u)
-            if (cp[u] >= 0) a.wd[cp[u]] = make_float2(rec[u].x, rec[u].x * (rec[u].y - dot));
-        return;
-    }
     const int p = blockIdx.x;
     const int i = a.rperm[p];
     const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    const float dot = attn_row_dot(a, t0, t1, stride);
+    const float dot = attn_row_dot(a, t0, t1, stride);      // (every wave: the same fixed order)
+    if (threadIdx.x == 0) a.rec_dot[i] = dot;
     for (int c0 = 0; c0 < a.C; c0 += 64) {
         const int c = c0 + cl;
         float va = 0.f, vb = 0.f;
@@ -444,7 +425,7 @@ template <int VEC, int G, int R> int launch_attn_bwd(const BwdArgs &a0, hipStrea
     a.nbB = ceil_div(a.n_med_end - a.n_split, WAVES);
     int nbC = ceil_div(a.N - a.n_med_end, (int64_t)WAVES * RPW);
     if (a.nbA + a.nbB + nbC > 0) k_attn_bwd_t<VEC, G, R><<<a.nbA + a.nbB + nbC, BLOCK, 0, st>>>(a);
-    if (a.n_split > 0) k_attn_bwd_t_fin<<<a.n_split + ceil_div(a.n_tasks, WAVES), BLOCK, 0, st>>>(a);
+    if (a.n_split > 0) k_attn_bwd_t_fin<<<a.n_split, BLOCK, 0, st>>>(a);
     // pass S: the aggregation's kernels (every edge kept, weight alpha_e, no mean division)
     a.nbA = ceil_div(a.n_stasks, WAVES);
     a.nbB = ceil_div(a.n_smed_end - a.n_ssplit, WAVES);

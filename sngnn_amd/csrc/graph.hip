@@ -595,7 +595,8 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
     //           split-source task
     //           (attention mode: 2 rows + 4 scalars) | partS (2 rows) per split-source task
     int64_t bwd = (2 * g->Ep + 3) / 4 * 4 * 4 + g->N * (int64_t)C * 4 +
-                  (int64_t)g->n_tasks * (2 * C + 4) * 4 + (int64_t)g->n_stasks * C * 4 * 2;
+                  (int64_t)g->n_tasks * (2 * C + 4) * 4 + (int64_t)g->n_stasks * C * 4 * 2 +
+                  (g->N + 3) / 4 * 4 * 4;            // (attention mode: dot_i per target, BwdArgs::rec_dot)
     int64_t b = std::max(fwd, bwd);
     return (b + 255) / 256 * 256;
 }

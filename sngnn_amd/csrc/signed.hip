@@ -56,7 +56,7 @@ extern "C" int sngnn_signed_backward(const sngnn_graph_t *g, const float *wh, in
     a.sperm = g->sperm;
     // workspace layout (sngnn_graph_workspace_bytes): wd (2 floats per edge) | dnT | partT | partS
     float *ws = (float *)workspace;
-    a.wd = (float2 *)ws;
+    a.wd = (float2 *)ws; a.rec_dot = nullptr;       // (final records)
     a.kmask = nullptr; a.kmask_words = 0; a.inv_deg = nullptr;
     const size_t ds_len = (2 * (size_t)g->Ep + 3) / 4 * 4;
     a.dnT = ws + ds_len;
