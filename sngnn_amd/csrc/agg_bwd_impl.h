@@ -42,10 +42,12 @@ struct BwdArgs {
     const int4 *rdesc, *sdesc;    // per degree-sorted slot: {node, first entry, degree, 0}: one load, not a chain of three
     const int32_t *cscptr, *csc_eid, *csc_dst, *csc_pos, *sperm;
     float2 *wd;                   // [E'] per-edge record in CSC order (attention mode: attn_impl.h)
-    float *rec_dot;               // attention mode: [N] dot_i = sum_e alpha_e t_e of target i (pass T writes it); the
-                                  // records then hold {alpha_e, t_e} and pass S forms ds_e = alpha_e (t_e - dot_i)
-                                  // itself, from a 4-byte read that travels with its row gathers.  nullptr: the
-                                  // records hold the final {w, ds} (signed mode)
+    float *rec_dot;               // attention mode: [N] dot_i = sum_e alpha_e t_e of the SPLIT targets (their finalize
+                                  // writes it).  A record of an edge into a split row is {-alpha_e, t_e} - the sign
+                                  // marks it raw, alpha > 0 - and pass S forms ds_e = alpha_e (t_e - dot_i) itself,
+                                  // from a 4-byte read that travels with its row gathers (825 distinct addresses at
+                                  // arxiv size: cache-resident; the other edges read entry 0).  Every other record,
+                                  // and every record when this is nullptr (signed mode), is the final {w, ds}
     unsigned *kmask;              // [kmask_words = ceil(E'/32)] kept bits: two-pass mode in CSC order (set by pass T, read
                                   // by pass S); node-centric mode in CSR order (k_pack_kept), read by both parts
     int64_t kmask_words, Ep;
@@ -439,13 +441,16 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
         // (odd count: the repeat enters with zero weights - unconditional, so that all four row
         // loads are in flight together)
         if constexpr (REC) {
-            float ds0 = s_ds[q0], ds1 = s_ds[q1];
-            if (a.rec_dot) {                                      // (uniform) travels with the rows
-                ds0 = s_w[q0] * (ds0 - a.rec_dot[i0]);
-                ds1 = s_w[q1] * (ds1 - a.rec_dot[i1]);
+            float w0 = s_w[q0], w1 = s_w[q1], ds0 = s_ds[q0], ds1 = s_ds[q1];
+            if (a.rec_dot) {                                      // (uniform) raw records: BwdArgs::rec_dot
+                const bool r0 = w0 < 0.f, r1 = w1 < 0.f;
+                const float t0_ = a.rec_dot[r0 ? i0 : 0], t1_ = a.rec_dot[r1 ? i1 : 0];   // unconditional loads
+                w0 = fabsf(w0); w1 = fabsf(w1);
+                ds0 = r0 ? w0 * (ds0 - t0_) : ds0;
+                ds1 = r1 ? w1 * (ds1 - t1_) : ds1;
             }
-            s_edge_rows<VEC, G, R>(x0, g0, s_w[q0], ds0, msg, dns);
-            s_edge_rows<VEC, G, R>(x1, g1, two ? s_w[q1] : 0.f, two ? ds1 : 0.f, msg, dns);
+            s_edge_rows<VEC, G, R>(x0, g0, w0, ds0, msg, dns);
+            s_edge_rows<VEC, G, R>(x1, g1, two ? w1 : 0.f, two ? ds1 : 0.f, msg, dns);
         } else {
             const float d0 = a.inv_deg[i0], d1 = a.inv_deg[i1];       // travel with the rows
             s_edge_recompute<VEC, G, R>(x0, g0, fin.hv, invv, d0, 1.0f, msg, dns);
@@ -836,9 +841,12 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
         gb.load(a.gout + (size_t)ib * a.C, a.C, lg);
         if constexpr (REC) {
             float2 ra = s_rec[qa], rb = s_rec[qb];
-            if (a.rec_dot) {                                      // (uniform) travels with the rows
-                ra.y = ra.x * (ra.y - a.rec_dot[ia]);
-                rb.y = rb.x * (rb.y - a.rec_dot[ib]);
+            if (a.rec_dot) {                                      // (uniform) raw records: BwdArgs::rec_dot
+                const bool wa = ra.x < 0.f, wb = rb.x < 0.f;
+                const float da_ = a.rec_dot[wa ? ia : 0], db_ = a.rec_dot[wb ? ib : 0];   // unconditional loads
+                ra.x = fabsf(ra.x); rb.x = fabsf(rb.x);
+                ra.y = wa ? ra.x * (ra.y - da_) : ra.y;
+                rb.y = wb ? rb.x * (rb.y - db_) : rb.y;
             }
             if (!la) ra = make_float2(0.f, 0.f);
             if (!lb) rb = make_float2(0.f, 0.f);

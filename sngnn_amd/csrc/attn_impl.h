@@ -292,9 +292,8 @@ __device__ __forceinline__ void attn_t_small(const BwdArgs &a, int blk, int *lds
     }
     fma_row<VEC, G, R>(A, -dot, B);                       // dnT_i = A - dot * B
     A.store(a.dnT + (size_t)i * a.C, a.C, lg);
-    if (lg == 0) a.rec_dot[i] = dot;
     wave_lds_sync();
-    for (int t = lg; t < deg; t += G) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_t[t]);   // raw: BwdArgs::rec_dot
+    for (int t = lg; t < deg; t += G) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
 }
 
 template <int VEC, int G, int R>
@@ -344,20 +343,20 @@ __device__ __forceinline__ void attn_t_wave(const BwdArgs &a, int blk, int *lds_
     A.reduce_across_groups();
     B.reduce_across_groups();
     wave_lds_sync();
-    // the records carry {alpha_e, t_e}: pass S subtracts dot_i itself (BwdArgs::rec_dot) - a split row's
-    // dot_i is only known after its finalize
-    for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + e0 + t]] = make_float2(s_a[t], s_t[t]);
     if (task) {
+        // a split row's dot_i is only known after its finalize: its records stay RAW, {-alpha_e, t_e} (the
+        // sign is the mark), and pass S subtracts dot_i itself (BwdArgs::rec_dot)
         float *p = a.partT + (size_t)tq * (2 * a.C + 4);
         if (gid == 0) {
             A.store(p, a.C, lg);
             B.store(p + a.C, a.C, lg);
             if (lg == 0) p[2 * a.C] = dot;
         }
+        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + e0 + t]] = make_float2(-s_a[t], s_t[t]);
     } else {
         fma_row<VEC, G, R>(A, -dot, B);
         if (gid == 0) A.store(a.dnT + (size_t)i * a.C, a.C, lg);
-        if (lane == 0) a.rec_dot[i] = dot;
+        for (int t = lane; t < n; t += 64) a.wd[a.csc_pos[rs + t]] = make_float2(s_a[t], s_a[t] * (s_t[t] - dot));
     }
 }
 
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(BLOCK) void k_attn_bwd_t(const BwdArgs a)
 // wide.  (Round 4, two steps.  The first version summed dot_i with ONE thread and rewrote the row's records
 // from raw t_e to ds_e one per thread and trip behind a csc_pos -> record chain: 68 us per backward at arxiv
 // size, the 13 k-edge hub's latency chain.  A wave per 128-edge task for the rewrite: 23 us.  Now no record is
-// rewritten at all - pass S subtracts dot_i itself.)
+// rewritten at all - the tasks mark theirs raw and pass S subtracts dot_i itself, BwdArgs::rec_dot.)
 __device__ __forceinline__ float attn_row_dot(const BwdArgs &a, int t0, int t1, size_t stride)
 {
     float dp = 0.f;
