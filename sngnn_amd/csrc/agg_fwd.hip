@@ -168,6 +168,8 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     FwdArgs a;
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
     a.filt = nrm ? (const uint4 *)filt : nullptr;
+    // (sngnn_filter_enable(2) forces it at any threshold: the tests' and the fuzz runs' way in)
+    a.filt_small = (a.filt != nullptr && top_k >= 0 && g_filter_mode != 0 && (thr >= 0.25f || g_filter_mode == 2)) ? 1 : 0;
     // OTF (nrm == NULL, n = raw rows): bound on |fast cosine - reference-order cosine|.  Either
     // value is within (2 C + 8) u of the real cosine (u = 2^-24: C products and sums of the dot,
     // C / 2 + 3 for each norm, the scalings), so they differ by less than (4 C + 16) u; twice
@@ -281,14 +283,17 @@ static void *ws_filter(void *workspace, int64_t Ntot, int C)
 }
 static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
 {
-    if (g_filter_mode == 0 || top_k < 0 || filter_row_bytes(C) == 0 || g->rows_gt(std::max(top_k, SMALL_T)) == 0)
-        return false;
+    if (g_filter_mode == 0 || top_k < 0 || filter_row_bytes(C) == 0) return false;
+    // a pruning threshold: the small rows read the table too (FwdArgs::filt_small) - any graph
+    if (thr >= 0.25f || g_filter_mode == 2) return true;
+    if (g->rows_gt(std::max(top_k, SMALL_T)) == 0) return false;
     // The filter prunes the edges that cannot reach thr and, in rows much longer than top_k, the
     // ones far below the k-th; it costs one more table to write (+3 us at arxiv size) and a
-    // second phase per row.  Measured at config 4: thr 0.9 or top_k 1 -> -7 us
-    // per forward; top_k 16 with thr 0.0 (a wave row keeps 16 of ~38, every kept row is
-    // fetched in fp32 anyway) -> +2 us.  Hence: on for a selective threshold or a small top_k.
-    return g_filter_mode == 2 || thr >= 0.25f || top_k <= 8;
+    // second phase per row.  Measured at config 4: thr 0.9 -> -12 us per forward
+    // (small rows included), top_k 1 -> -7 us; top_k 16 with thr 0.0 (a wave row keeps 16 of ~38,
+    // every kept row is fetched in fp32 anyway) -> +2 us.  Hence: on for a selective threshold
+    // (above) or, where wave / split rows exist, a small top_k.
+    return top_k <= 8;
 }
 
 static int agg_forward_impl(const sngnn_graph_t *g, const float *h, int C, int top_k,

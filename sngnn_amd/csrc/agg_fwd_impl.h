@@ -55,6 +55,11 @@ struct FwdArgs {
     const float *nrm;
     float delta;          // OTF: bound on |fast - exact| (launcher: (4 C + 32) 2^-24)
     const uint4 *filt;    // [Ntot, filter_row_halfs(C)] fp16 filter rows (agg_fwd_filter.h) or nullptr
+    int filt_small;       // the filter also in front of the SMALL rows (small_rows_set_filt): pays when a threshold
+                          // prunes - then most rows fetch no fp32 row at all (arxiv size, top_k 16 / thr 0.9: main
+                          // kernel 40.4 -> 36.2 us); with thr 0 it is a second dependent round trip per set for
+                          // rows that keep something anyway (top_k 1: 49.3 -> 61.3 us), so the launcher sets it
+                          // for thr >= 0.25 only
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
@@ -647,13 +652,172 @@ __device__ __forceinline__ void small_rows_set(const FwdArgs &a, const int4 d, b
     }
 }
 
+// The same set with the fp16 FILTER in front (agg_fwd_filter.h; the FILT kernel, table mode, G >= 16 >=
+// SMALL_T: lane lg of a group owns edge lg of its row).  The unfiltered set gathers the fp32 unit row of
+// EVERY in-edge to score it - two lines at C = 40 or 64 - although a ranking row keeps top_k of them and
+// a threshold may drop most: 95 % of an arxiv-like graph's rows are small rows.  Here every edge is scored
+// from its one-line filter row first (|s~ - s| <= FILT_EPS), and only the CANDIDATES
+//        s~ >= thr - eps   and   fewer than top_k edges with s~' > s~ + 2 eps
+// are fetched and scored in fp32: every edge of the exact selection is a candidate (the filter header's
+// argument), the exact rule then runs on the candidates' exact scores, so indices, weights, ranks and kept
+// bits are those of the unfiltered set, bit for bit.
+template <int VEC, int G, int R, int EPI>
+__device__ __forceinline__ void small_rows_set_filt(const FwdArgs &a, const int4 d, bool valid,
+                                                    int *lds_wave, const int *s_col_set)
+{
+    static_assert(G >= SMALL_T, "one lane per edge of a small row");
+    using RowT = Row<VEC, G, R>;
+    constexpr int U = Unroll<R>::U;
+    constexpr int UF = (R == 1) ? 4 : 2;                 // filter rows in flight per lane group
+    constexpr int SETW = WaveLds<G>::SETW;
+    constexpr int FR = G * R;                            // 8-byte lane entries per filter row
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int i = d.x, rs = d.y, deg = d.z;
+    const bool emit = a.sel_src != nullptr;
+    const bool rank = deg > a.k;                         // (a.k >= 0: the filter belongs to selecting calls)
+    const bool need_sc = rank || emit;
+    const int self = i + a.row_off;
+    const uint2 *f2 = reinterpret_cast<const uint2 *>(a.filt);
+
+    const int *s_col = s_col_set + gid * SMALL_T;
+    float *s_sc = reinterpret_cast<float *>(lds_wave + 2 * SETW) + gid * SMALL_T;   // approximate, then exact scores
+    float *s_w = reinterpret_cast<float *>(lds_wave + 3 * SETW) + gid * SMALL_T;    // kept weights
+    int *s_c = reinterpret_cast<int *>(s_w);                                        // (before that: candidate edges)
+
+    RowT ni;
+    ni.load(a.n + (size_t)self * a.C, a.C, lg);
+    uint2 fi[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) fi[q] = f2[(size_t)self * FR + q * G + lg];
+    const int dmax = wave_max_i(deg);
+
+    // phase 1: approximate scores of all edges from the filter rows
+    for (int t0 = 0; t0 < dmax; t0 += UF) {
+        uint2 x[UF][R];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int j = (t0 + u) < deg ? s_col[t0 + u] : self;
+#pragma unroll
+            for (int q = 0; q < R; ++q) x[u][q] = f2[(size_t)j * FR + q * G + lg];
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            float pr = 0.f;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                pr = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, fi[q].x), __builtin_bit_cast(half2_t, x[u][q].x), pr, false);
+                pr = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, fi[q].y), __builtin_bit_cast(half2_t, x[u][q].y), pr, false);
+            }
+            const float sa = group_sum<G>(pr) * FILT_UNSCALE;
+            if (t0 + u < deg && lg == 0) s_sc[t0 + u] = sa;
+        }
+    }
+    wave_lds_sync();
+
+    // phase 2: lane lg decides edge lg
+    const bool has = lg < deg;
+    const float sa = has ? s_sc[lg] + 0.0f : -INFINITY;
+    const float lo = a.thr - FILT_EPS;
+    bool cand = has && sa >= lo;
+    if (cand && rank) {
+        int above = 0;
+        for (int b = 0; b < deg; ++b) {
+            const float sb = s_sc[b];
+            above += (sb >= lo) && (sb > sa + 2.0f * FILT_EPS);
+        }
+        cand = above < a.k;
+    }
+    const unsigned long long gm = fwd_group_bits<G>(__ballot(cand), gid);
+    const int nc = __popcll(gm);
+    wave_lds_sync();                                          // (every s_sc read above is done)
+    if (cand) s_c[__popcll(gm & ((1ull << lg) - 1ull))] = lg;
+    if (has && !cand) {
+        s_sc[lg] = -INFINITY;                                 // never selected, ranks below every candidate
+        if (!need_sc && a.wsel) a.wsel[rs + lg] = SNGNN_UNSELECTED;
+    }
+    wave_lds_sync();
+
+    // phase 3: the candidates' fp32 rows and exact scores
+    RowT acc;
+    acc.zero();
+    unsigned kb = 0u;
+    const int ncmax = wave_max_i(nc);
+    for (int q0 = 0; q0 < ncmax; q0 += U) {
+        RowT x[U];
+        float nj[U];
+        int e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            e[u] = (q0 + u) < nc ? s_c[q0 + u] : -1;
+            const int j = e[u] >= 0 ? s_col[e[u]] : self;
+            x[u].load(a.n + (size_t)j * a.C, a.C, lg);
+            nj[u] = need_sc ? 0.f : a.nrm[j];                 // a streaming row weighs the row it has just scored
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float sx = unit_dot<VEC, G, R>(ni, x[u]);
+            if (e[u] >= 0) {
+                if (need_sc) {
+                    if (lg == 0) s_sc[e[u]] = sx;
+                } else {
+                    const bool sel = sx >= a.thr;
+                    if (sel) acc.axpy(sx * nj[u], x[u]);
+                    if (a.wsel && lg == 0) a.wsel[rs + e[u]] = sel ? sx : SNGNN_UNSELECTED;
+                    kb |= sel ? (1u << e[u]) : 0u;
+                }
+            }
+        }
+    }
+    if (a.inv_norm && valid && lg == 0) a.inv_norm[i] = ieee_div(1.0f, a.nrm[self]);
+
+    if (need_sc) {
+        wave_lds_sync();
+        // phase 4: the exact rule on the exact scores (non-candidates hold -inf) - the unfiltered set's code
+        for (int e = lg; e < deg; e += G) {
+            const float se = s_sc[e];
+            int rk = 0;
+            for (int b = 0; b < deg; ++b) {
+                const float sb = s_sc[b];
+                rk += (sb > se) || (sb == se && b < e);
+            }
+            const bool sel = rk < a.k && se >= a.thr;
+            s_w[e] = sel ? se : SNGNN_UNSELECTED;
+            if (a.wsel) a.wsel[rs + e] = sel ? se : SNGNN_UNSELECTED;
+            if (a.kbits) kb |= (unsigned)fwd_group_bits<G>(__ballot(sel), gid) << (e - lg);
+            if (emit && sel) {
+                a.sel_src[(size_t)i * a.k + rk] = s_col[e];
+                a.sel_w[(size_t)i * a.k + rk] = se;
+            }
+        }
+        wave_lds_sync();
+        // the kept rows again (they were candidates a moment ago: cache-hot), in edge order
+        for (int t = 0; t < deg; ++t) {
+            const float w = s_w[t];
+            if (w != SNGNN_UNSELECTED) {
+                const int j = s_col[t];
+                RowT xr;
+                xr.load(a.n + (size_t)j * a.C, a.C, lg);
+                acc.axpy(w * a.nrm[j], xr);
+            }
+        }
+        wave_lds_sync();       // s_sc / s_w are reused by the next set
+    }
+    if (a.kbits && valid && lg == 0) reinterpret_cast<unsigned short *>(a.kbits)[i] = (unsigned short)kb;
+    if (valid) {
+        acc.div((float)max(deg, 1));
+        if constexpr (EPI == 1) row_epilogue<VEC, G, R>(a, acc, i, lg);
+        acc.store(a.out + (size_t)i * a.C, a.C, lg);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Class C driver: waves are persistent, each walks sets wave_id, wave_id + n_waves, ...
 // and keeps the NEXT set's descriptors and column ids in flight while it works on the
 // current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool OTF, int EPI>
+template <int VEC, int G, int R, bool OTF, int EPI, bool FILT = false>
 __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
@@ -705,8 +869,16 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         const int4 d_n2 = load_desc(s_n2);
         load_cols(d_nxt, cols);                 // in flight during this set's work
         wave_lds_sync();
-        if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull)
-            small_rows_set<VEC, G, R, OTF, EPI>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+        if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull) {
+            bool done = false;
+            if constexpr (FILT && G >= SMALL_T && !OTF) {
+                if (a.filt_small) {                               // (uniform)
+                    small_rows_set_filt<VEC, G, R, EPI>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+                    done = true;
+                }
+            }
+            if (!done) small_rows_set<VEC, G, R, OTF, EPI>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
+        }
         store_cols(cols, lds_wave + SETW * (buf ^ 1));
         d_cur = d_nxt;
         d_nxt = d_n2;
@@ -1141,7 +1313,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI>(a, it, nw, nsets, lw);
+    if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI, FILT>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------

@@ -37,7 +37,11 @@ if os.environ.get("ROLES") is not None:           # only some row classes of the
 if os.environ.get("TABLE") is not None:           # how sngnn_agg_forward scores: 0 auto, 1 unit-row table always, 2 on the fly always
     lib.sngnn_tuning_set(2, int(os.environ["TABLE"]))
     print("scoring mode", os.environ["TABLE"], "(0 auto, 1 table, 2 on the fly)")
-for k, thr in ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0)):
+REGIMES = ((16, 0.0), (16, 0.9), (1, 0.99), (None, 0.0))
+if os.environ.get("REGIMES"):                     # e.g. REGIMES="1:0.0,16:0.0,none:0.0"
+    REGIMES = tuple((None if a.lower() == "none" else int(a), float(b))
+                    for a, b in (item.split(":") for item in os.environ["REGIMES"].split(",")))
+for k, thr in REGIMES:
     res, wall = [], []
     for rnd in range(int(os.environ.get("ROUNDS", 4))):
         lib.sngnn_profile_enable(1)
