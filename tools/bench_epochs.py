@@ -28,6 +28,9 @@ MODELS = {
     # the reference's training scripts: hidden_channels 64, top_k 1 (train_script_SNGNN_plus.sh:13,17)
     "plus_2layer_h64_k1": lambda: sngnn_amd.SNGNN_Plus(128, 64, c, n, 2, 1, 0.0, 1, 0.5),
     "plus_3layer_h64_k1": lambda: sngnn_amd.SNGNN_Plus(128, 64, c, n, 3, 1, 0.0, 1, 0.5),
+    # the script's own threshold too (train_script_SNGNN_plus.sh:19: thr 0.99)
+    "plus_2layer_h64_k1_thr0.99": lambda: sngnn_amd.SNGNN_Plus(128, 64, c, n, 2, 1, 0.99, 1, 0.5),
+    "plusplus_2layer_h64_k1_thr0.99": lambda: sngnn_amd.SNGNN_Plus_Plus(128, 64, c, n, 2, 1, 0.99, 0.5, 1, 0.5),
     "plusplus_1layer": lambda: sngnn_amd.SNGNN_Plus_Plus(128, 32, c, n, 1, 16, 0.0, 0.3, 1, 0.5),
     "sngnn_1layer": lambda: sngnn_amd.SNGNN(128, 32, c, 1),
     "agnn_1layer": lambda: sngnn_amd.AGNN(128, 32, c, 1),
