@@ -169,7 +169,10 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.n = n; a.nrm = nrm; a.C = C; a.N = (int)g->N; a.row_off = (int)g->row_off;
     a.filt = nrm ? (const uint4 *)filt : nullptr;
     // (sngnn_filter_enable(2) forces it at any threshold: the tests' and the fuzz runs' way in)
-    a.filt_small = (a.filt != nullptr && top_k >= 0 && g_filter_mode != 0 && (thr >= 0.25f || g_filter_mode == 2)) ? 1 : 0;
+    // (top_k >= 4: at top_k 1 the small-row form gains 1.5 us where it prunes - 39.3 -> 37.6-38.8 us at thr
+    // 0.99 - and costs 13.6 us per call where it does not: the reference scripts' own knobs)
+    a.filt_small = (a.filt != nullptr && top_k >= 0 && g_filter_mode != 0 &&
+                    ((thr >= 0.25f && top_k >= 4) || g_filter_mode == 2)) ? 1 : 0;
     // OTF (nrm == NULL, n = raw rows): bound on |fast cosine - reference-order cosine|.  Either
     // value is within (2 C + 8) u of the real cosine (u = 2^-24: C products and sums of the dot,
     // C / 2 + 3 for each norm, the scalings), so they differ by less than (4 C + 16) u; twice
@@ -285,7 +288,8 @@ static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
 {
     if (g_filter_mode == 0 || top_k < 0 || filter_row_bytes(C) == 0) return false;
     // a pruning threshold: the small rows read the table too (FwdArgs::filt_small) - any graph
-    if (thr >= 0.25f || g_filter_mode == 2) return true;
+    if ((thr >= 0.25f && top_k >= 4) || g_filter_mode == 2) return true;
+    if (thr >= 0.25f) return g->rows_gt(std::max(top_k, SMALL_T)) != 0;
     if (g->rows_gt(std::max(top_k, SMALL_T)) == 0) return false;
     // The filter prunes the edges that cannot reach thr and, in rows much longer than top_k, the
     // ones far below the k-th; it costs one more table to write (+3 us at arxiv size) and a

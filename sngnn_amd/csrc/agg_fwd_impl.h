@@ -59,7 +59,7 @@ struct FwdArgs {
                           // prunes - then most rows fetch no fp32 row at all (arxiv size, top_k 16 / thr 0.9: main
                           // kernel 40.4 -> 36.2 us); with thr 0 it is a second dependent round trip per set for
                           // rows that keep something anyway (top_k 1: 49.3 -> 61.3 us), so the launcher sets it
-                          // for thr >= 0.25 only
+                          // for thr >= 0.25 (and top_k >= 4) only
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
@@ -817,7 +817,7 @@ __device__ __forceinline__ void small_rows_set_filt(const FwdArgs &a, const int4
 // current one, so a set costs one memory round trip (its feature rows) instead of a
 // chain of three (descriptor -> columns -> rows).
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool OTF, int EPI, bool FILT = false>
+template <int VEC, int G, int R, bool OTF, int EPI, bool FS = false>
 __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int stride, int nsets, int *lds_wave)
 {
     constexpr int RPW = 64 / G;
@@ -871,7 +871,7 @@ __device__ __forceinline__ void role_small(const FwdArgs &a, int set0, int strid
         wave_lds_sync();
         if (a.row_flag == nullptr || __ballot(d_cur.w >= 0) != 0ull) {
             bool done = false;
-            if constexpr (FILT && G >= SMALL_T && !OTF) {
+            if constexpr (FS && G >= SMALL_T && !OTF) {
                 if (a.filt_small) {                               // (uniform)
                     small_rows_set_filt<VEC, G, R, EPI>(a, d_cur, d_cur.w >= 0, lds_wave, lds_wave + SETW * buf);
                     done = true;
@@ -1295,10 +1295,14 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // EPI: the hidden-layer store epilogue (FwdArgs::epilogue) compiled into the row stores - its own
 // instantiation, so the plain forward keeps its register allocation (a runtime flag cost the
 // filter variant two spilled registers and 2 us)
-template <int VEC, int G, int R, bool FILT, bool OTF, int EPI = 0>
+// FS: the filter also in front of the small rows (small_rows_set_filt) - its own instantiation: compiled into
+// the plain FILT kernel it cost that kernel's other calls 2.5 us (41.8 against 39.3 us at top_k 1 / thr 0.99
+// without the small-row form: six spilled registers)
+template <int VEC, int G, int R, bool FILT, bool OTF, int EPI = 0, bool FS = false>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
     static_assert(!(FILT && OTF), "the filter belongs to the table mode");
+    static_assert(FILT || !FS, "the small-row filter belongs to the FILT kernel");
     __shared__ __align__(16) int lds[WAVES][WaveLds<G>::WORDS];
     const int wave = threadIdx.x >> 6;
     int *lw = lds[wave];
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     it -= n_wave_rows;
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI, FILT>(a, it, nw, nsets, lw);
+    if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI, FS>(a, it, nw, nsets, lw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1938,7 +1942,8 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
         if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
             k_agg_fwd<VEC, G, R, false, true, EPI><<<grid, BLOCK, 0, st>>>(a);
         } else if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
-            if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false, EPI><<<grid, BLOCK, 0, st>>>(a);
+            if (a.filt && a.k >= 0 && a.filt_small) k_agg_fwd<VEC, G, R, true, false, EPI, true><<<grid, BLOCK, 0, st>>>(a);
+            else if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false, EPI><<<grid, BLOCK, 0, st>>>(a);
             else k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
         } else {
             k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
