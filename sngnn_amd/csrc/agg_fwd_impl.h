@@ -685,8 +685,6 @@ __device__ __forceinline__ void small_rows_set_filt(const FwdArgs &a, const int4
     float *s_w = reinterpret_cast<float *>(lds_wave + 3 * SETW) + gid * SMALL_T;    // kept weights
     int *s_c = reinterpret_cast<int *>(s_w);                                        // (before that: candidate edges)
 
-    RowT ni;
-    ni.load(a.n + (size_t)self * a.C, a.C, lg);
     uint2 fi[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) fi[q] = f2[(size_t)self * FR + q * G + lg];
@@ -743,6 +741,11 @@ __device__ __forceinline__ void small_rows_set_filt(const FwdArgs &a, const int4
     acc.zero();
     unsigned kb = 0u;
     const int ncmax = wave_max_i(nc);
+    // (the row's own fp32 unit row only now, with the first candidates' rows: a set without candidates - most
+    // sets behind a threshold that prunes - touches one-line filter rows only)
+    RowT ni;
+    if (ncmax > 0) ni.load(a.n + (size_t)self * a.C, a.C, lg);
+    else ni.zero();
     for (int q0 = 0; q0 < ncmax; q0 += U) {
         RowT x[U];
         float nj[U];
