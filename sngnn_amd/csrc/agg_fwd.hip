@@ -290,14 +290,14 @@ static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
     // a pruning threshold: the small rows read the table too (FwdArgs::filt_small) - any graph
     if ((thr >= 0.25f && top_k >= 4) || g_filter_mode == 2) return true;
     if (thr >= 0.25f) return g->rows_gt(std::max(top_k, SMALL_T)) != 0;
-    if (g->rows_gt(std::max(top_k, SMALL_T)) == 0) return false;
-    // The filter prunes the edges that cannot reach thr and, in rows much longer than top_k, the
-    // ones far below the k-th; it costs one more table to write (+3 us at arxiv size) and a
-    // second phase per row.  Measured at config 4: thr 0.9 -> -12 us per forward
-    // (small rows included), top_k 1 -> -7 us; top_k 16 with thr 0.0 (a wave row keeps 16 of ~38,
-    // every kept row is fetched in fp32 anyway) -> +2 us.  Hence: on for a selective threshold
-    // (above) or, where wave / split rows exist, a small top_k.
-    return top_k <= 8;
+    // No threshold to prune with: the filter could still skip, in rows much longer than top_k, the edges
+    // far below the k-th - round 3's rule was "on for top_k <= 8" (-7 us per forward at top_k 1 then).
+    // Re-measured in round 4 (same box, arxiv size, C = 40, thr 0; filter on / off): top_k 1: 70.7 / 69.5
+    // us per call, top_k 4: 73.6 / 70.9, top_k 8: 75.0 / 72.6 - the main kernel gains ~1 us, the extra table
+    // costs the normalisation pass 3; and a model's later layers (nearly parallel rows: every edge a
+    // candidate) lose more: 2- / 3-layer hidden-64 top_k-1 epochs 0.711 / 1.099 ms with, 0.703 / 1.052
+    // without.  Hence: a selective threshold only.
+    return false;
 }
 
 static int agg_forward_impl(const sngnn_graph_t *g, const float *h, int C, int top_k,
