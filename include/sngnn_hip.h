@@ -232,6 +232,9 @@ typedef struct sngnn_epilogue {
     int64_t head_n_a, head_n_b;     /* rows in split A / B: the means' denominators                              */
     float *head_metrics;            /* dev f32 [2 * head_sets]: (mean NLL, correct count) per split              */
     void *head_workspace;           /* dev, sngnn_agg_head_workspace_bytes(g) bytes                              */
+    int no_filter;                  /* != 0: this call does not use the fp16 filter whatever sngnn_filter_enable */
+                                    /* would decide - the caller knows its rows (nearly parallel ones all pass   */
+                                    /* the threshold: nothing to prune, the filter is a pass for nothing)       */
 } sngnn_epilogue_t;
 int64_t sngnn_agg_head_workspace_bytes(const sngnn_graph_t *g);
 /* 1 if a forward on this graph at this width / top_k can take the head epilogue (C % 4 == 0, C <= 64, the

@@ -101,7 +101,7 @@ class Epilogue(C.Structure):
                 ("seed", C.c_void_p), ("p", C.c_float), ("kept_bits", C.c_void_p),
                 ("head_y", C.c_void_p), ("head_sel", C.c_void_p), ("head_sets", C.c_int), ("head_out_mode", C.c_int),
                 ("head_n_a", C.c_int64), ("head_n_b", C.c_int64), ("head_metrics", C.c_void_p),
-                ("head_workspace", C.c_void_p)]
+                ("head_workspace", C.c_void_p), ("no_filter", C.c_int)]
 
 
 _lib = None

@@ -10,9 +10,11 @@ call into libsngnn_hip (plus one for the SNGNN++ adjacency branch).
 from __future__ import annotations
 
 import math
+from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from . import dist as sn_dist
@@ -93,12 +95,43 @@ def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None, act_in=
     return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head), None, None), c, table
 
 
-def _unit_for(lin: nn.Linear, graph, top_k, thr) -> "ops.UnitRows":
+class _FilterHint:
+    """Whether a layer's rows give the fp16 filter anything to prune.  The library switches the filter on
+    by the call's knobs (a threshold >= 0.25); what it cannot see is the data: where nearly every in-edge
+    passes the threshold - a deep layer's rows are nearly parallel - every edge is a candidate and the
+    filter is a pass for nothing (an arxiv-sized second layer at thr 0.99: 56.6 us without, 69.3 with).
+    The layer therefore looks at its own ``h`` now and then - the cosines of 4 096 sampled edges, outside
+    graph captures, on its first forward and every 64th eager one after - and tells the next forwards
+    (``sngnn_epilogue_t.no_filter``).  A matter of time only: the results do not depend on the filter."""
+    SAMPLE, EVERY = 4096, 64
+
+    def __init__(self):
+        self.no_filter = False
+        self._calls = 0
+
+    def due(self) -> bool:
+        self._calls += 1
+        return (self._calls % self.EVERY == 1) and not torch.cuda.is_current_stream_capturing()
+
+    @torch.no_grad()
+    def probe(self, h: torch.Tensor, edge_index: torch.Tensor, thr: float) -> None:
+        e = edge_index.size(1)
+        if e == 0 or h.size(0) == 0:
+            return
+        pick = torch.randint(0, e, (min(self.SAMPLE, e),), device=edge_index.device)
+        src, dst = edge_index[0, pick], edge_index[1, pick]
+        ok = (src < h.size(0)) & (dst < h.size(0))
+        s = F.cosine_similarity(h[src.clamp_max(h.size(0) - 1)], h[dst.clamp_max(h.size(0) - 1)], dim=1)
+        self.no_filter = bool(((s >= thr - 1.1e-3) & ok).float().mean() > 0.5)
+
+
+def _unit_for(lin: nn.Linear, graph, top_k, thr, hint: "Optional[_FilterHint]" = None) -> "ops.UnitRows":
     """The holder ``lin``'s normalising epilogue fills (ops.UnitRows); it asks for the fp16 filter
     rows only when the forward that follows will read them."""
     c = lin.out_features
     cp = c if (c % 4 == 0 or c < 16) else (c + 3) // 4 * 4
-    return ops.UnitRows(ops.filter_wanted(graph, cp, int(top_k), float(thr)))
+    want = ops.filter_wanted(graph, cp, int(top_k), float(thr))
+    return ops.UnitRows(want, no_filter=want and hint is not None and hint.no_filter)
 
 
 def _true_width(out: torch.Tensor, c: int) -> torch.Tensor:
@@ -226,11 +259,20 @@ class SNConv_plus(nn.Module):
         if self.bias is not None:
             self.bias.data.fill_(0)
 
+    def _filter_hint(self) -> _FilterHint:
+        hint = getattr(self, "_filt_hint", None)
+        if hint is None:
+            hint = self._filt_hint = _FilterHint()
+        return hint
+
     def forward(self, x, edge_index, epilogue=None, act_in=None, head=None):
         """``epilogue`` / ``act_in`` / ``head``: see SNConv.forward."""
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        unit = _unit_for(self.lin, graph, self.top_k, self.thr)
+        hint = self._filter_hint()
+        unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
+            hint.probe(h.detach(), edge_index, float(self.thr))
         if _fuse_head(head, graph, h, c, shard, int(self.top_k)):
             return ops.aggregate(h, graph, int(self.top_k), float(self.thr), unit, None, self.bias, head)
         if _fuse_epilogue(epilogue, h, c, shard):
@@ -387,6 +429,8 @@ class SNConv_plus_plus(nn.Module):
             self._src_min_cache = hit
         return hit[1]
 
+    _filter_hint = SNConv_plus._filter_hint
+
     def forward(self, x, edge_index, epilogue=None, act_in=None):
         """``epilogue`` / ``act_in``: see SNConv.forward; here the BLEND is the layer's last kernel and
         takes the epilogue (one GPU, no conv bias - i.e. no batch norm flag, models.py:52-53)."""
@@ -399,8 +443,11 @@ class SNConv_plus_plus(nn.Module):
         if part is None and self.w.shard_range is not None:
             raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
-        unit = _unit_for(self.lin, graph, self.top_k, self.thr)
+        hint = self._filter_hint()
+        unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
+            hint.probe(h.detach(), edge_index, float(self.thr))
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:

@@ -326,7 +326,7 @@ static int agg_forward_impl(const sngnn_graph_t *g, const float *h, int C, int t
     float *n = (float *)workspace;
     float *nrm = (float *)((char *)workspace + (g->Ntot * (int64_t)C * 4 + 255) / 256 * 256);
     void *scratch = (char *)workspace + fwd_table_bytes(g->Ntot, C);
-    void *filt = use_filter(g, C, top_k, thr) ? ws_filter(workspace, g->Ntot, C) : nullptr;
+    void *filt = (use_filter(g, C, top_k, thr) && !(epi && epi->no_filter)) ? ws_filter(workspace, g->Ntot, C) : nullptr;
     hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
     for (int rep = 0; rep < (ev ? g_prof_reps : 1); ++rep)
@@ -395,7 +395,7 @@ static int agg_forward_prepared_impl(const sngnn_graph_t *g, const float *n, con
     hipEvent_t *ev = g_prof_on ? g_prof_ev : nullptr;
     if (ev) { SN_HIP(hipEventRecord(ev[0], st)); }
     const void *f = nullptr;
-    if (use_filter(g, C, top_k, thr)) {
+    if (use_filter(g, C, top_k, thr) && !(epi && epi->no_filter)) {
         f = filt;
         if (!f) {       // the caller holds no filter rows: one more pass over its unit rows
             void *wf = ws_filter(workspace, g->Ntot, C);

@@ -292,7 +292,7 @@ class _Aggregate(torch.autograd.Function):
             # the split's mean NLL (training) or the logits
             out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, None, bias, ctx.bits, head)
             ctx.bias_grad = bias is not None and ctx.needs_input_grad[6]
-        elif epi is not None or ctx.bits:
+        elif epi is not None or ctx.bits or (unit is not None and unit.no_filter):
             out, wsel = _forward_epilogue(graph, h, unit, top_k, thr, need_grad, epi, bias, ctx.bits)
             ctx.bias_grad = epi is not None and bias is not None and ctx.needs_input_grad[6]
         elif unit is not None and unit.n is not None:
@@ -343,8 +343,11 @@ class UnitRows:
     (``sngnn_linear_forward_normalized``).  ``want_filter``: whether the consumer will use them
     (``ops.filter_wanted``).  ``n`` stays None when the layer's shape took another route."""
 
-    def __init__(self, want_filter: bool = False):
-        self.want_filter = bool(want_filter)
+    def __init__(self, want_filter: bool = False, no_filter: bool = False):
+        self.want_filter = bool(want_filter) and not no_filter
+        # the caller knows its rows do not prune (conv._FilterHint): the forward is told not to build
+        # filter rows of its own either (sngnn_epilogue_t.no_filter)
+        self.no_filter = bool(no_filter)
         self.n = self.nrm = self.filt = None
 
 
@@ -403,6 +406,8 @@ def _forward_epilogue(graph: Graph, h, unit, top_k, thr, need_grad, epi: Optiona
         bias = bias.detach().contiguous()
     st = _lib.Epilogue(_lib.ptr(bias), _lib.ptr(keep), float(epi.scale), int(epi.relu), _lib.ptr(seed), float(epi.p),
                        _lib.ptr(kbits))
+    if unit is not None and getattr(unit, "no_filter", False):
+        st.no_filter = 1
     if head is not None:
         if head.y.numel() != n or head.sel.numel() != n or head.y.device != h.device or head.sel.device != h.device:
             raise ValueError("head: y and sel must hold one entry per target row, on h's device")

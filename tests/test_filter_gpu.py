@@ -168,3 +168,32 @@ def test_scoring_on_the_fly_selects_what_the_table_selects(cuda, n, e, c, hubs, 
     w1, w2 = res[1][1][kept1], res[2][1][kept2]
     assert (w1 - w2).abs().max() <= 2e-5 if w1.numel() else True     # weights: fast vs exact
     assert (res[1][0] - res[2][0]).abs().max() <= 2e-5 * max(1.0, float(res[1][0].abs().max()))
+
+
+def test_layer_level_filter_hint(cuda):
+    """conv._FilterHint: a layer whose rows give the filter nothing to prune (nearly parallel rows behind a
+    threshold they all pass) tells its next forwards not to use it (sngnn_epilogue_t.no_filter); a layer
+    whose threshold prunes keeps it.  Either way the same bits."""
+    import sngnn_amd
+    from sngnn_amd import ops
+    from tests.helpers import random_graph
+    n, f, c = 3000, 24, 40
+    ei = random_graph(n, 30000, seed=5, hubs=((0, 2500), (1, 300))).to(cuda)
+    gen = torch.Generator().manual_seed(0)
+    x_par = (torch.rand(n, f, generator=gen) * 0.05 + 1.0).to(cuda)         # every cosine ~ 1
+    x_rnd = torch.randn(n, f, generator=gen).to(cuda)
+    for x, expect in ((x_par, True), (x_rnd, False)):
+        torch.manual_seed(1)
+        conv = sngnn_amd.SNConv_plus(f, c, n, top_k=16, thr=0.9).to(cuda)
+        with torch.no_grad():
+            conv.lin.weight.abs_()                                              # keep parallel rows parallel
+            g = sngnn_amd.graph.GLOBAL_CACHE.get(ei, n, True, True)
+            assert ops.filter_wanted(g, c, 16, 0.9)
+            out1 = conv(x, ei)                  # first forward: filter by the knobs; the probe runs
+            assert conv._filt_hint.no_filter is expect
+            out2 = conv(x, ei)                  # second: by the hint
+        assert torch.equal(out1, out2)
+        xg = x.clone().requires_grad_(True)
+        o = conv(xg, ei)
+        o.square().sum().backward()
+        assert torch.equal(o.detach(), out1) and torch.isfinite(xg.grad).all()
