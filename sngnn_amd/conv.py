@@ -118,7 +118,9 @@ class _FilterHint:
         e = edge_index.size(1)
         if e == 0 or h.size(0) == 0:
             return
-        pick = torch.randint(0, e, (min(self.SAMPLE, e),), device=edge_index.device)
+        gen = torch.Generator(device=edge_index.device)          # (its own generator: the global CUDA stream of
+        gen.manual_seed(0x5EED + self._calls)                     # random numbers - dropout masks - is not touched)
+        pick = torch.randint(0, e, (min(self.SAMPLE, e),), device=edge_index.device, generator=gen)
         src, dst = edge_index[0, pick], edge_index[1, pick]
         ok = (src < h.size(0)) & (dst < h.size(0))
         s = F.cosine_similarity(h[src.clamp_max(h.size(0) - 1)], h[dst.clamp_max(h.size(0) - 1)], dim=1)
