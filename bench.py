@@ -32,7 +32,12 @@ The line's keys (beyond the driver's contract):
                   single-launch event interval are in the line).  traffic = counter bytes per launch of
                   the main kernel in the committed PMC passes (profiles/traffic.json), not re-measured.
   roofline_step   the headline figure under its round-3 name.
-  variants        BASELINE.md's other config-4 cases (C = 32; thr = 0.9) timed the same way.
+  variants        BASELINE.md's other config-4 cases (C = 32; thr = 0.9) timed the same way; their fractions
+                  are EFFECTIVE (B_fwd of the unpruned byte model over the time - a pruning threshold moves
+                  fewer bytes: `traffic`).
+  roofline.gather_floor_ms / kernel_over_floor   sngnn_gather_floor timed in this run: the forward's row reads
+                  and stores on this graph and table with no arithmetic - what the memory system needs for the
+                  access pattern - and the main kernel's time over it.
   epoch_ms        train + validation + test step replayed from one HIP graph, the reference's
                   THREE forwards (train.py:134-143); epoch_ms_shared_eval = validation and test
                   read one eval-mode forward (bit-identical metrics); epoch_ms_eager = the
@@ -154,6 +159,29 @@ def profile_forward(lib, _lib, ops, graph, table, top_k, thr, calls, reps):
         acc.append((z.value, m.value, f.value, e0.value))
     lib.sngnn_profile_enable(0)
     return tuple(float(v) for v in np.mean(np.array(acc[1:] if len(acc) > 1 else acc), axis=0))
+
+
+def gather_floor(lib, _lib, graph, table, mode, batches=6, reps=20):
+    """``sngnn_gather_floor``: the memory work of the forward's main kernel with none of its arithmetic, on
+    THIS graph and THIS table (mode 0: one row read per entry of the graph's column list; mode 1: + own row
+    read and output row written per node = every byte of B_fwd).  Average launch duration in ms: torch events
+    on the launch stream (the current one) around batches of ``reps`` back-to-back launches, median of the
+    batches after the first."""
+    c = table.size(1)
+    ws = torch.empty(int(lib.sngnn_gather_floor_workspace_bytes()), dtype=torch.uint8, device=table.device)
+    out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=table.device) if mode == 1 else None
+    st = torch.cuda.current_stream(table.device).cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(batches):
+        ev[0].record()
+        for _ in range(reps):
+            _lib.check(lib.sngnn_gather_floor(graph.handle, table.data_ptr(), c, mode, _lib.ptr(out), ws.data_ptr(), st),
+                       "sngnn_gather_floor")
+        ev[1].record()
+        ev[1].synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]) / reps)
+    return float(np.median(ms[1:]))
 
 
 def time_loop(fn, warmup, steps, sync):
@@ -341,9 +369,15 @@ def main():
                 traffic = prof.get(f"{args.workload}_k{args.top_k}")
                 # the same kernel's average duration in the committed rocprofv3 run of this command
                 rocprof_us = prof.get(f"{args.workload}_k{args.top_k}_kernel_us_rocprofv3")
-                traffic_src = prof.get("source")
+                traffic_src = prof.get(f"source_{args.workload}", prof.get("source") if args.workload == "arxiv" else None)
             except Exception:
                 traffic = rocprof_us = None
+        # the floor under the kernel: the same graph's column list gathered over the same table with no
+        # arithmetic at all (sngnn_gather_floor), timed here, on this box
+        floor_ms = floor_edges_ms = None
+        if c % 4 == 0 and c <= 256:
+            floor_edges_ms = gather_floor(lib, _lib, graph, table, 0)
+            floor_ms = gather_floor(lib, _lib, graph, table, 1)
         # the kernel figure: the live batched-event average, but never less than the committed
         # rocprofv3 average of the same command (dispatch to completion of one kernel: back-to-back
         # launches of one kernel can overlap a ramp with a drain and read lower); kernel_ms_source
@@ -389,6 +423,13 @@ def main():
                          "algorithmic_bytes": b_alg, "ms": ms_per_step,
                          "kernel": "k_agg_fwd", "kernel_ms": main_ms, "kernel_ms_source": kernel_ms_source,
                          "kernel_achieved": kernel_achieved, "kernel_frac": kernel_achieved / HBM_PEAK_GBS,
+                         "gather_floor_ms": floor_ms, "gather_floor_edges_only_ms": floor_edges_ms,
+                         "kernel_over_floor": None if not floor_ms else main_batched_ms / floor_ms,
+                         "gather_floor_what": "sngnn_gather_floor on this graph and table, this box, batched events like "
+                                              "kernel_ms_batched_events: every row read and row store of B_fwd (one 4C-byte row "
+                                              "per entry of the column list in CSR order, own row in, output row out) with no "
+                                              "arithmetic, no selection, no second fetch of kept rows; edges_only = the column "
+                                              "list's gather alone.  kernel_over_floor = kernel_ms_batched_events / gather_floor_ms",
                          "normalize_kernel_ms": norm_ms, "finalize_kernel_ms": fin_ms,
                          "launches_ms_sum": norm_ms + main_batched_ms + fin_ms,
                          "kernel_ms_batched_events": main_batched_ms,
@@ -450,10 +491,21 @@ def main():
                 vms = vdt / min(args.steps, 50) * 1e3
                 _, vmain, _, _ = profile_forward(lib, _lib, ops, vg, vh, args.top_k, vthr, 4, 20)
                 vb = algorithmic_bytes(vg.num_edges, vn, vcc)
+                vtraffic = None
+                try:
+                    vtraffic = json.load(open(tpath)).get(f"{args.workload}_k{args.top_k}_{name}")
+                except Exception:
+                    pass
                 variants[name] = {"channels": vcc, "thr": vthr, "ms_per_step": vms,
                                   "edges_per_s": vg.num_edges / (vms * 1e-3), "algorithmic_bytes": vb,
-                                  "kernel_ms": vmain, "frac": vb / (vmain * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "frac_step": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  "kernel_ms": vmain,
+                                  # EFFECTIVE fractions: B_fwd of the unpruned byte model over the time.  A threshold
+                                  # that prunes (the fp16 filter: no fp32 row for an edge that cannot be kept) moves
+                                  # fewer bytes than B_fwd - `traffic` is the counter traffic of the committed PMC
+                                  # pass of this variant - so this is a speed in roofline units, not a bandwidth
+                                  "effective_frac": vb / (vmain * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "effective_frac_step": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": vtraffic}
             result["variants"] = variants
         hg = h_local.clone().requires_grad_(True)
         gout = torch.randn_like(h_local)

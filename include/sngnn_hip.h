@@ -427,6 +427,19 @@ int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, flo
  */
 int sngnn_profile_enable(int on);
 int sngnn_profile_last_forward(float *norm_ms, float *main_ms, float *fin_ms, float *empty_ms);
+/*
+ * Measurement aid (no reference counterpart): the memory work of the aggregation forward
+ * (models.py:239,244-263: the gathers of PyG's propagate + the scatter-mean's output) with NONE of
+ * its arithmetic, over the caller's own graph and feature table - the floor bench.py prints beside
+ * the main kernel's time (roofline.gather_floor_ms / kernel_over_floor).
+ *   mode 0: one coalesced 4C-byte row read per entry of the graph's own column list (CSR order);
+ *   mode 1: the same + per owned node its own row read and an output row written to `out`
+ *           (dev f32 [N, C]; NULL in mode 0) - every byte of SURVEY.md 8d's B_fwd.
+ * table: dev f32 [N_total, C], C % 4 == 0, C <= 256; workspace: sngnn_gather_floor_workspace_bytes().
+ */
+int64_t sngnn_gather_floor_workspace_bytes(void);
+int sngnn_gather_floor(const sngnn_graph_t *g, const float *table, int C, int mode, float *out,
+                       void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
  * SNGNN++ adjacency-linear branch and blend.

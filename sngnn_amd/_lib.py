@@ -74,6 +74,8 @@ SIGNATURES = {
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),
     "sngnn_profile_last_forward": (_i32, [C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)]),
+    "sngnn_gather_floor_workspace_bytes": (_i64, []),
+    "sngnn_gather_floor": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "sngnn_adj_linear_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_adj_linear_backward": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_head_workspace_bytes": (_i64, [_i64]),

@@ -101,30 +101,51 @@ class _FilterHint:
     passes the threshold - a deep layer's rows are nearly parallel - every edge is a candidate and the
     filter is a pass for nothing (an arxiv-sized second layer at thr 0.99: 56.6 us without, 69.3 with).
     The layer therefore looks at its own ``h`` now and then - the cosines of 4 096 sampled edges, outside
-    graph captures, on its first forward and every 64th eager one after - and tells the next forwards
-    (``sngnn_epilogue_t.no_filter``).  A matter of time only: the results do not depend on the filter."""
+    graph captures, on its first forward and every 64th eager one after - and tells LATER forwards
+    (``sngnn_epilogue_t.no_filter``).  A matter of time only: the results do not depend on the filter.
+
+    The forward never waits for the answer (no host sync inside forward / backward - the
+    reference has one at models.py:257): the probe's verdict is one byte the device copies into pinned
+    host memory behind the sampled cosines; a later forward reads it once the copy's event has
+    completed (``Event.query``: non-blocking) and keeps the previous verdict until then."""
     SAMPLE, EVERY = 4096, 64
 
     def __init__(self):
         self.no_filter = False
         self._calls = 0
+        self._flag = None          # pinned uint8 [1]: the pending probe's verdict
+        self._event = None         # recorded behind the copy into _flag; None = nothing pending
 
     def due(self) -> bool:
         self._calls += 1
         return (self._calls % self.EVERY == 1) and not torch.cuda.is_current_stream_capturing()
 
+    def poll(self) -> None:
+        """Take a finished probe's verdict (never blocks; a probe still in flight stays pending)."""
+        # (an event query is not a legal call while a stream captures: the verdict waits for an eager forward)
+        if self._event is not None and not torch.cuda.is_current_stream_capturing() and self._event.query():
+            self.no_filter = bool(self._flag[0] != 0)          # (host memory: no device access)
+            self._event = None
+
     @torch.no_grad()
     def probe(self, h: torch.Tensor, edge_index: torch.Tensor, thr: float) -> None:
         e = edge_index.size(1)
-        if e == 0 or h.size(0) == 0:
+        if e == 0 or h.size(0) == 0 or self._event is not None:
             return
         gen = torch.Generator(device=edge_index.device)          # (its own generator: the global CUDA stream of
         gen.manual_seed(0x5EED + self._calls)                     # random numbers - dropout masks - is not touched)
         pick = torch.randint(0, e, (min(self.SAMPLE, e),), device=edge_index.device, generator=gen)
-        src, dst = edge_index[0, pick], edge_index[1, pick]
+        src, dst = edge_index[0].index_select(0, pick), edge_index[1].index_select(0, pick)
         ok = (src < h.size(0)) & (dst < h.size(0))
-        s = F.cosine_similarity(h[src.clamp_max(h.size(0) - 1)], h[dst.clamp_max(h.size(0) - 1)], dim=1)
-        self.no_filter = bool(((s >= thr - 1.1e-3) & ok).float().mean() > 0.5)
+        hs = h.index_select(0, src.clamp_max(h.size(0) - 1))
+        hd = h.index_select(0, dst.clamp_max(h.size(0) - 1))
+        s = F.cosine_similarity(hs, hd, dim=1)
+        verdict = (((s >= thr - 1.1e-3) & ok).float().mean() > 0.5).to(torch.uint8).reshape(1)
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.uint8).pin_memory()
+        self._flag.copy_(verdict, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(h.device))
 
 
 def _unit_for(lin: nn.Linear, graph, top_k, thr, hint: "Optional[_FilterHint]" = None) -> "ops.UnitRows":
@@ -271,6 +292,7 @@ class SNConv_plus(nn.Module):
         """``epilogue`` / ``act_in`` / ``head``: see SNConv.forward."""
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         hint = self._filter_hint()
+        hint.poll()
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
@@ -446,6 +468,7 @@ class SNConv_plus_plus(nn.Module):
             raise ValueError("this layer holds a shard of w (built under a partition): run it under one")
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         hint = self._filter_hint()
+        hint.poll()
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():

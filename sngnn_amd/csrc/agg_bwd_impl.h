@@ -443,7 +443,8 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
         if constexpr (REC) {
             float w0 = s_w[q0], w1 = s_w[q1], ds0 = s_ds[q0], ds1 = s_ds[q1];
             if (a.rec_dot) {                                      // (uniform) raw records: BwdArgs::rec_dot
-                const bool r0 = w0 < 0.f, r1 = w1 < 0.f;
+                // (the SIGN BIT is the mark: an alpha that underflowed to 0 is stored as -0.0f, which `< 0.f` misses)
+                const bool r0 = (__float_as_uint(w0) >> 31) != 0, r1 = (__float_as_uint(w1) >> 31) != 0;
                 const float t0_ = a.rec_dot[r0 ? i0 : 0], t1_ = a.rec_dot[r1 ? i1 : 0];   // unconditional loads
                 w0 = fabsf(w0); w1 = fabsf(w1);
                 ds0 = r0 ? w0 * (ds0 - t0_) : ds0;
@@ -842,7 +843,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
         if constexpr (REC) {
             float2 ra = s_rec[qa], rb = s_rec[qb];
             if (a.rec_dot) {                                      // (uniform) raw records: BwdArgs::rec_dot
-                const bool wa = ra.x < 0.f, wb = rb.x < 0.f;
+                const bool wa = (__float_as_uint(ra.x) >> 31) != 0, wb = (__float_as_uint(rb.x) >> 31) != 0;   // sign bit: -0.0f too
                 const float da_ = a.rec_dot[wa ? ia : 0], db_ = a.rec_dot[wb ? ib : 0];   // unconditional loads
                 ra.x = fabsf(ra.x); rb.x = fabsf(rb.x);
                 ra.y = wa ? ra.x * (ra.y - da_) : ra.y;

@@ -567,17 +567,24 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     if (g_knn_route == 2 || (g_knn_route == 0 && N <= KNN_DENSE_MAX_N && N >= 2)) {
         // materialise + select (see k_row_topk); S lives in a stream-ordered allocation
         SN_REQUIRE(N <= 65535, SNGNN_EINVAL, "the dense route is for small graphs");
+        // (outside the caller's allocator: up to 4.3 GB.  When the device cannot give it - the caller's pool holds
+        // most of HBM - the fused scan below does the same job from the few MB of the workspace, unless the
+        // dense route was forced)
         void *S = nullptr;
-        SN_REQUIRE(hipMallocAsync(&S, (size_t)N * N * 4, st) == hipSuccess, SNGNN_ENOMEM, "out of device memory");
-        int rc = sngnn_cosine_dense(x, N, F, (float *)S, stream);
-        if (rc == SNGNN_OK) {
-            int lowbits = 1;
-            while (((int64_t)1 << lowbits) < N && lowbits < 31) ++lowbits;
-            k_row_topk<<<(unsigned)((N + 3) / 4), 256, 0, st>>>((const float *)S, N, k, exclude_self, lowbits, nbr_idx, nbr_sim);
-            if (hipGetLastError() != hipSuccess) rc = SNGNN_EHIP;
+        const hipError_t got = hipMallocAsync(&S, (size_t)N * N * 4, st);
+        if (got == hipSuccess) {
+            int rc = sngnn_cosine_dense(x, N, F, (float *)S, stream);
+            if (rc == SNGNN_OK) {
+                int lowbits = 1;
+                while (((int64_t)1 << lowbits) < N && lowbits < 31) ++lowbits;
+                k_row_topk<<<(unsigned)((N + 3) / 4), 256, 0, st>>>((const float *)S, N, k, exclude_self, lowbits, nbr_idx, nbr_sim);
+                if (hipGetLastError() != hipSuccess) rc = SNGNN_EHIP;
+            }
+            (void)hipFreeAsync(S, st);
+            return rc;
         }
-        (void)hipFreeAsync(S, st);
-        return rc;
+        (void)hipGetLastError();          // clear the allocation failure
+        SN_REQUIRE(g_knn_route != 2, SNGNN_ENOMEM, "out of device memory for the dense route's N x N matrix");
     }
     float *inv = (float *)workspace;
     unsigned long long *part = (unsigned long long *)((char *)workspace + (N + 63) / 64 * 256);

@@ -82,14 +82,29 @@ class _Stack(nn.Module):
         """One counter per hidden layer for the in-kernel dropout draw (ops.HiddenEpilogue): started
         from torch's CPU generator (so ``torch.manual_seed`` makes a run reproducible) and advanced on
         the device once per training forward - inside a captured epoch too, where every replay must
-        drop differently."""
+        drop differently.  The counters are CREATED outside any capture (a host-to-device copy of
+        pageable memory inside one would either fail or be replayed: the same mask every epoch):
+        :meth:`prepare_capture` does it for a trainer, the first eager training forward otherwise."""
         s = getattr(self, "_drop_seed", None)
         if s is None or s.device != device or s.numel() != len(self.lins) - 1:
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the dropout seeds must exist before a graph capture: call "
+                                   "model.prepare_capture(device) (GraphedEpoch does) or run one eager "
+                                   "training forward first")
             s = torch.randint(0, 2 ** 62, (len(self.lins) - 1,), dtype=torch.int64).to(device)
             self._drop_seed = s
         else:
             s.add_(1)
         return s
+
+    def prepare_capture(self, device) -> None:
+        """Everything a training forward creates lazily on the host, created now - call before
+        capturing the model in a HIP graph (sngnn_amd.train.GraphedEpoch does)."""
+        device = torch.device(device)
+        if len(self.lins) > 1 and getattr(self.dropout, "p", 0.0) > 0.0:
+            s = getattr(self, "_drop_seed", None)
+            if s is None or s.device != device or s.numel() != len(self.lins) - 1:
+                self._dropout_seeds(device)
 
     def _build(self, conv, in_channels, hidden_channels, out_channels, num_layers):
         self.lins = nn.ModuleList()

@@ -214,10 +214,12 @@ class HiddenEpilogue:
 
     ``p`` / ``training``: the wrapper's Dropout.  ``applied``: set by the conv layer when its shape
     took the fused store (the caller falls back to the plain elementwise ops otherwise).
-    ``premasked``: set by the consumer's backward when it has already applied the mask to the
-    gradient it returns for the activated tensor - the contract between ``_Linear.backward`` and
-    ``_Aggregate.backward``, valid because the wrapper hands the activated tensor to exactly one
-    consumer (the next conv's ``lin``; models.py:205 -> :237)."""
+    ``premasked``: set by the consumer's backward (to the address of the gradient tensor it returns)
+    when it has already applied the mask to that gradient - the contract between ``_Linear.backward``
+    and ``_Aggregate.backward`` / ``_Blend.backward``.  The wrapper hands the activated tensor to exactly
+    one consumer (the next conv's ``lin``; models.py:205 -> :237); the producer's backward CHECKS that the
+    gradient it receives is that very tensor (``_take_premasked``) and raises otherwise.  A hook on a
+    hidden activation therefore sees the gradient of the PRE-activation (already masked)."""
 
     def __init__(self, relu: bool = True, p: float = 0.0, training: bool = False, seed: Optional[torch.Tensor] = None):
         """``seed``: int64 [1] device tensor - the dropout mask is then drawn inside the kernel from
@@ -233,6 +235,18 @@ class HiddenEpilogue:
     @property
     def drops(self) -> bool:
         return self.training and self.p > 0.0
+
+
+def _take_premasked(epi: "HiddenEpilogue", grad_out: torch.Tensor) -> None:
+    """The producer's side of the ``premasked`` hand-over: the gradient that arrives must be THE tensor the
+    consumer's masked store wrote.  Anything else means the activated tensor had a second consumer (a hook,
+    a skip connection, ``autograd.grad`` on it) whose contribution autograd added to the pre-masked one -
+    the sum can no longer be masked correctly, so refuse loudly instead of returning a wrong gradient."""
+    ptr, epi.premasked = epi.premasked, False
+    if grad_out.data_ptr() != ptr:
+        raise RuntimeError("the fused hidden epilogue (ops.HiddenEpilogue) needs the activated tensor to have exactly "
+                           "one consumer - the next layer's lin; its gradient arrived accumulated with another "
+                           "consumer's.  Set sngnn_amd.models.FUSE_HIDDEN = False for such a model.")
 
 
 class HeadEpilogue:
@@ -318,7 +332,7 @@ class _Aggregate(torch.autograd.Function):
         else:
             h, wsel, out = ctx.saved_tensors
             if epi.premasked:          # the consumer's store already applied relu' and the dropout mask
-                epi.premasked = False
+                _take_premasked(epi, grad_out)
             else:
                 g = grad_out.contiguous()
                 grad_out = torch.empty_like(g)
@@ -813,7 +827,7 @@ class _Linear(torch.autograd.Function):
                         rc = _lib.load().sngnn_linear_forward_masked(g.data_ptr(), wt.data_ptr(), None, n, ctx.c, fin,
                                                                      x.data_ptr(), float(act.scale), gx.data_ptr(),
                                                                      _stream(g.device))
-                        act.premasked = True
+                        act.premasked = gx.data_ptr()          # (which tensor: _take_premasked checks it)
                     else:
                         rc = _lib.load().sngnn_linear_forward(g.data_ptr(), wt.data_ptr(), None, n, ctx.c, fin,
                                                               gx.data_ptr(), _stream(g.device))
@@ -882,7 +896,7 @@ class _Blend(torch.autograd.Function):
         else:
             out0, out1, beta, out = ctx.saved_tensors
             if epi.premasked:          # the consumer's store already applied relu' and the dropout mask
-                epi.premasked = False
+                _take_premasked(epi, g)
             else:
                 act = out
         lib = _lib.load()

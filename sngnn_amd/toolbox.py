@@ -215,13 +215,16 @@ class _SparseCols:
         order = torch.argsort(cols * self.shape[0] + rows)          # by column, rows ascending
         self.rowidx = rows[order].to(torch.int32).contiguous()
         col_s, val_s = cols[order], val[order].to(torch.float32)
-        sq = torch.zeros(n_cols, dtype=torch.float64, device=val.device).index_add_(0, col_s, val_s.double() ** 2)
+        counts = torch.bincount(col_s, minlength=n_cols)
+        # (entries are in column order: a column's squares are one contiguous segment, added serially by one
+        # thread - no float atomics, the same bits on every run)
+        sq = torch.segment_reduce(val_s.double() ** 2, "sum", lengths=counts, unsafe=True)
         nrm = sq.sqrt()
         inv = torch.where(nrm > 0, 1.0 / nrm, torch.zeros_like(nrm))
         self.vals = (val_s.double() * inv[col_s]).to(torch.float32).contiguous()
         self.cols = col_s
         self.colptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=val.device)
-        self.colptr[1:] = torch.cumsum(torch.bincount(col_s, minlength=n_cols), 0)
+        self.colptr[1:] = torch.cumsum(counts, 0)
         self.device = val.device
 
     def pair_dot(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -243,6 +246,16 @@ class _SparseCols:
         m = torch.zeros(self.shape, dtype=torch.float32, device=self.device)
         m[self.rowidx.long(), self.cols] = self.vals
         return m
+
+
+def _group_sum_f64(val: torch.Tensor, key: torch.Tensor, n_groups: int) -> torch.Tensor:
+    """``out[g] = sum of val[key == g]`` in float64 with a FIXED order of additions: entries are brought
+    into (group, entry position) order by a stable sort and each group is added serially by one thread
+    (``torch.segment_reduce``) - where ``index_add_`` would use float atomics, whose order changes from
+    run to run."""
+    order = torch.argsort(key, stable=True)
+    counts = torch.bincount(key, minlength=n_groups)
+    return torch.segment_reduce(val.double()[order], "sum", lengths=counts, unsafe=True)
 
 
 def cosine_similarity_sparse(mat, device=None) -> torch.Tensor:
@@ -283,9 +296,7 @@ def class_similarity_sparse(x, y, device=None):
     yl = y.to(sp.device).long()
     n_classes = len(torch.unique(yl))
     rows = sp.shape[0]
-    m = torch.zeros(n_classes * rows, dtype=torch.float64, device=sp.device)
-    m.index_add_(0, yl[sp.cols] * rows + sp.rowidx.long(), sp.vals.double())
-    m = m.view(n_classes, rows)
+    m = _group_sum_f64(sp.vals, yl[sp.cols] * rows + sp.rowidx.long(), n_classes * rows).view(n_classes, rows)
     sums = m @ m.t()
     cnt = torch.bincount(yl, minlength=n_classes).double()
     return (sums / (cnt[:, None] * cnt[None, :])).to(torch.float32)

@@ -20,29 +20,30 @@ import torch.nn.functional as F
 from .synth import Data
 
 
+def _split_metrics(log_probs, labels, mask):
+    """(mean NLL, accuracy) of the rows a boolean mask selects - what every step of the reference's
+    loop computes on its own split (train.py:81-84, 98-102, 112-116)."""
+    rows, want = log_probs[mask], labels[mask]
+    hits = int((rows.argmax(dim=1) == want).sum())
+    return F.nll_loss(rows, want), hits / max(int(want.numel()), 1)
+
+
 def train_step(model, data, optimizer):
-    """train.py:73-89."""
+    """One optimisation step on the training split (the contract of train.py:73-89: returns the
+    loss tensor and the training accuracy of the forward the step was taken from)."""
     model.train()
     optimizer.zero_grad()
-    output = model(data)
-    train_loss = F.nll_loss(output[data.train_mask], data.y[data.train_mask])
-    _, pred = output.max(dim=1)
-    correct = int(pred[data.train_mask].eq(data.y[data.train_mask]).sum().item())
-    train_acc = correct / int(data.train_mask.sum())
-    train_loss.backward()
+    loss, acc = _split_metrics(model(data), data.y, data.train_mask)
+    loss.backward()
     optimizer.step()
-    return train_loss, train_acc
+    return loss, acc
 
 
 @torch.no_grad()
 def eval_step(model, data, mask):
-    """train.py:92-103 (validation) and :106-117 (test)."""
+    """Evaluation-mode loss and accuracy on ``mask`` (train.py:92-103 validation, :106-117 test)."""
     model.eval()
-    output = model(data)
-    _, pred = output.max(dim=1)
-    correct = int(pred[mask].eq(data.y[mask]).sum().item())
-    loss = F.nll_loss(output[mask], data.y[mask])
-    return loss, correct / int(mask.sum())
+    return _split_metrics(model(data), data.y, mask)
 
 
 def train(model, data, optimizer, epochs: int, patience: int, log=None) -> Dict:
@@ -122,6 +123,10 @@ class GraphedEpoch:
                     and all(dense(p) and p.is_cuda for p in g["params"])):
                 g["fused"] = True
         self._materialise_adam_state()
+        if hasattr(model, "prepare_capture"):
+            # host-side lazy state of a training forward (the in-kernel dropout's seed counters) must
+            # exist before the capture: with warmup=0 the first training forward IS the captured one
+            model.prepare_capture(dev)
         from .graph import GLOBAL_CACHE
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

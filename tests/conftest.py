@@ -53,6 +53,14 @@ def pytest_terminal_summary(terminalreporter):
         for label, d, r in helpers.OPERATOR_TIE_LOG:
             if d:
                 tr.write_line(f"  {label}: {d} of {r}")
+    if helpers.DEEP_OPERATOR_LOG:
+        tot = sum(d for _, d, _ in helpers.DEEP_OPERATOR_LOG)
+        rows = sum(r for _, _, r in helpers.DEEP_OPERATOR_LOG)
+        mx = max(helpers.DEEP_OPERATOR_GAPS, default=0.0)
+        tr.write_line(f"second-layer operator level (the oracle's own layer input on both sides): {tot} of {rows} rows, "
+                      f"largest gap {mx:.3e} = {mx / helpers.ULP32:.2f} ulp (gate {helpers.DEEP_GATE_ULPS} ulp)")
+        for label, d, r in helpers.DEEP_OPERATOR_LOG:
+            tr.write_line(f"  {label}: {d} of {r}")
     if helpers.NEAR_TIE_LOG:
         tot = sum(d for _, d, _ in helpers.NEAR_TIE_LOG)
         rows = sum(r for _, _, r in helpers.NEAR_TIE_LOG)

@@ -162,6 +162,11 @@ OPERATOR_TIE_LOG = []   # the same at operator level (same inputs on both sides)
 # rows are nearly parallel - every cosine within 1.3e-5 of 1 - needs 3.5), gaps logged separately.
 MODEL_TIE_ULPS = 3.0
 MODEL_TIE_GAPS = []
+# second and later layers at OPERATOR level: the oracle's own layer input fed to both sides (gate TIE_ULPS)
+DEEP_OPERATOR_LOG = []
+DEEP_OPERATOR_GAPS = []
+# (SNGNN_DEEP_GATE_ULPS: a measurement aid - run with a wide gate to read the largest gap off the summary)
+DEEP_GATE_ULPS = float(__import__("os").environ.get("SNGNN_DEEP_GATE_ULPS", TIE_ULPS))
 
 
 def model_selection_report(ours, ref, data_cpu, data_gpu, label):
@@ -203,5 +208,14 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
         differ += check_selection(res, sel_src, sel_w, int(k), float(cr.thr), strict=False, h=h_r,
                                   tie_ulps=MODEL_TIE_ULPS + li, gaps=MODEL_TIE_GAPS)
         rows += h_r.size(0)
+        if li >= 1:
+            # OPERATOR level on a deep layer's actual input: the ORACLE's h on both sides (identical
+            # operands), so only the kernel's own arithmetic can move a selection - held to the operator
+            # gate (TIE_ULPS), where the end-to-end comparison above allows one more ulp per layer
+            h_same = h_r.to(h_g.device).contiguous()
+            _, _, _, s2, w2 = ops.aggregate_forward(g, h_same, int(k), float(cr.thr), want_selection=True)
+            d2 = check_selection(res, s2, w2, int(k), float(cr.thr), strict=False, h=h_r,
+                                 tie_ulps=DEEP_GATE_ULPS, gaps=DEEP_OPERATOR_GAPS)
+            DEEP_OPERATOR_LOG.append((f"{label}, layer {li + 1}", d2, h_r.size(0)))
     NEAR_TIE_LOG.append((label, differ, rows))
     return differ, rows

@@ -93,3 +93,23 @@ def test_epilogue_struct_layout_matches_the_header(tmp_path):
     assert int(out["size"]) == C.sizeof(_lib.Epilogue)
     for f in fields:
         assert int(out[f]) == getattr(_lib.Epilogue, f).offset, f
+
+
+def test_hot_path_sources_hold_no_host_synchronisation():
+    """forward / backward only enqueue.  The translation units behind the conv layers'
+    forward and backward entries (aggregation, attention, signed propagation, adjacency branch, blend,
+    ``lin`` / head) call no blocking HIP API; the one exception is the profiling read-back
+    ``sngnn_profile_last_forward`` (bench.py's roofline leg, never on a model's path).  Graph construction
+    (graph.hip), the toolbox statistics and the kNN builder are setup / analysis calls and may block."""
+    hot = ("agg_fwd.hip", "agg_fwd_impl.h", "agg_fwd_filter.h", "agg_bwd.hip", "agg_bwd_impl.h", "attn.hip",
+           "attn_impl.h", "signed.hip", "signed_impl.h", "adj_linear.hip", "adj_linear_impl.h", "blend.hip",
+           "linear.hip", "head.hip", "head_row.h", "device_utils.h")
+    blocking = re.compile(r"\bhip(StreamSynchronize|DeviceSynchronize|EventSynchronize|Memcpy|MemcpyDtoH|Malloc|Free|"
+                          r"HostMalloc|MemcpyAsync)\s*\(")
+    for name in hot:
+        src = open(os.path.join(ROOT, "sngnn_amd", "csrc", name)).read()
+        for m in blocking.finditer(src):
+            line = src[:m.start()].count("\n") + 1
+            fn_start = src.rfind('extern "C"', 0, m.start())
+            owner = src[fn_start:src.find("(", fn_start)] if fn_start >= 0 else ""
+            assert name == "agg_fwd.hip" and "sngnn_profile_last_forward" in owner, (name, line, m.group(0))

@@ -189,9 +189,11 @@ def test_layer_level_filter_hint(cuda):
             conv.lin.weight.abs_()                                              # keep parallel rows parallel
             g = sngnn_amd.graph.GLOBAL_CACHE.get(ei, n, True, True)
             assert ops.filter_wanted(g, c, 16, 0.9)
-            out1 = conv(x, ei)                  # first forward: filter by the knobs; the probe runs
+            out1 = conv(x, ei)                  # first forward: filter by the knobs; the probe is ENQUEUED
+            assert conv._filt_hint.no_filter is False      # (the forward does not wait for its verdict)
+            torch.cuda.synchronize()
+            out2 = conv(x, ei)                  # second: takes the finished probe's verdict, runs by the hint
             assert conv._filt_hint.no_filter is expect
-            out2 = conv(x, ei)                  # second: by the hint
         assert torch.equal(out1, out2)
         xg = x.clone().requires_grad_(True)
         o = conv(xg, ei)

@@ -401,3 +401,152 @@ def test_hidden_epilogue_operator_with_dropout_matches_autograd_of_its_own_mask(
     want.backward(gout)
     assert float((gh - h.grad).abs().max()) <= 1e-6 * float(h.grad.abs().max())
     assert float((gb - bias.grad).abs().max()) <= 1e-5 * float(bias.grad.abs().max())
+
+
+@pytest.mark.parametrize("kind", ["SNGNN_Plus", "SNGNN"])
+def test_graphed_epoch_with_fused_dropout_draws_a_new_mask_every_replay(cuda, kind):
+    """train_graphed builds GraphedEpoch(warmup=0): the first TRAINING forward is the captured one.  The
+    fused hidden epilogue's dropout seeds must then already exist on the device (created outside the
+    capture, models._Stack.prepare_capture) and advance inside it: every replay drops other elements and
+    keeps about 1 - p of the activations relu left."""
+    import sngnn_amd
+    from sngnn_amd import train as T
+    from sngnn_amd import synth
+    data = synth.make_dataset("cora", scale=0.5).to(cuda)
+    n, f = data.x.shape
+    torch.manual_seed(7)
+    if kind == "SNGNN_Plus":
+        model, p = sngnn_amd.SNGNN_Plus(f, 32, 7, n, 2, 3, 0.0, 1, 0.4).to(cuda), 0.4
+    else:
+        model, p = sngnn_amd.SNGNN(f, 32, 7, 2).to(cuda), 0.5           # (models.py:283: fixed at 0.5)
+    assert getattr(model, "_drop_seed", None) is None
+    hidden = torch.zeros(n, 32, device=cuda)
+
+    def grab(mod, args, out):            # captured with the epoch: a copy of the TRAINING forward's activations
+        if mod.training:
+            hidden.copy_(out)
+    model.lins[0].register_forward_hook(grab)
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, weight_decay=0.0, capturable=True)   # lr 0: same weights
+    ge = T.GraphedEpoch(model, data, opt, warmup=0)
+    assert model._drop_seed is not None and model._drop_seed.is_cuda
+    seeds, masks = [], []
+    for _ in range(3):
+        ge.run()
+        seeds.append(int(model._drop_seed[0]))
+        masks.append((hidden != 0).clone())
+    assert seeds[1] == seeds[0] + 1 and seeds[2] == seeds[1] + 1, seeds        # advanced INSIDE the graph
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    # the same weights every replay (lr 0): an element relu kept is non-zero in a replay unless dropped
+    alive = masks[0] | masks[1] | masks[2]
+    for m in masks:
+        frac = float(m.sum()) / float(alive.sum())
+        assert abs(frac - (1.0 - p) / (1.0 - p ** 3)) < 0.03, frac
+    # a fresh model without the preparation refuses to create its seeds inside a capture
+    torch.manual_seed(7)
+    m2 = sngnn_amd.SNGNN_Plus(f, 32, 7, n, 2, 3, 0.0, 1, 0.4).to(cuda).train()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        m2.eval()
+        m2(data)
+        m2.train()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="dropout seeds"):
+        with torch.cuda.graph(g, stream=side):
+            m2(data)
+    torch.cuda.synchronize()
+
+
+def test_forward_and_backward_enqueue_only(cuda):
+    """no host synchronisation inside forward / backward (the reference has one per
+    top-k round, models.py:257).  After warm-up (graph build, workspaces, lazily created seeds) the three
+    models run forward + loss + backward under torch's sync debug mode "error" - every blocking call torch
+    makes (``.item()``, ``nonzero``, blocking copies) raises - including the forward in which the fp16
+    filter's data probe (conv._FilterHint) is due, and the one that takes its verdict."""
+    import sngnn_amd
+    from sngnn_amd import synth
+    d = synth.make_dataset("actor", with_features=False)
+    n, f, c = 7600, 48, 8
+    ei = d.edge_index.to(cuda)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, f, generator=gen).to(cuda)
+    y = torch.randint(0, c, (n,), generator=gen).to(cuda)
+    idx = torch.nonzero(torch.rand(n, generator=gen) < 0.6).flatten().to(cuda)      # (index form of the mask:
+    yi = y[idx]                                                                     #  boolean indexing is the harness' sync)
+    data = sngnn_amd.Data(x=x, edge_index=ei, y=y)
+    torch.manual_seed(1)
+    models = [sngnn_amd.SNGNN(f, 40, c, 2).to(cuda),
+              sngnn_amd.SNGNN_Plus(f, 40, c, n, 2, 16, 0.9, 1, 0.5).to(cuda),          # thr 0.9, C 40: the filter + its probe
+              sngnn_amd.SNGNN_Plus_Plus(f, 40, c, n, 2, 16, 0.3, 0.3, 1, 0.5).to(cuda),
+              sngnn_amd.SNGNN_Plus(f, 32, c, n, 3, 2, 0.0, 0, 0.2, True).to(cuda)]     # batch norm: the unfused sequence
+
+    def step(m):
+        out = m(data)
+        loss = F.nll_loss(out.index_select(0, idx), yi)
+        m.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    for m in models:
+        m.train()
+        for _ in range(3):
+            step(m)
+    torch.cuda.synchronize()
+    hints = [l._filt_hint for m in models for l in m.lins if getattr(l, "_filt_hint", None) is not None]
+    assert hints
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for m in models:
+            for l in m.lins:
+                h = getattr(l, "_filt_hint", None)
+                if h is not None:
+                    h._calls = h.EVERY                # the next forward's probe is due
+            losses = [step(m) for _ in range(3)]
+            m.eval()
+            with torch.no_grad():
+                m(data)
+            m.train()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(l)) for l in losses)
+    # the probes were enqueued under the debug mode and their verdicts arrive without a wait
+    assert any(h._flag is not None for h in hints)
+
+
+def test_fused_hidden_epilogue_refuses_a_second_consumer(cuda):
+    """ops.HiddenEpilogue's backward hand-over (the next lin's store pre-masks the gradient) is only right
+    when the activated tensor has ONE consumer; a second one (here: the loss also reads the hidden
+    activations) must raise, not return a silently wrong gradient - and the unfused sequence handles it."""
+    import sngnn_amd
+    from sngnn_amd import models as M
+    from sngnn_amd import synth
+    n, f = 6000, 48
+    d = synth.make_dataset("actor", with_features=False)
+    ei = d.edge_index[:, (d.edge_index[0] < n) & (d.edge_index[1] < n)].to(cuda)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, f, generator=gen).to(cuda)
+    y = torch.randint(0, 6, (n,), generator=gen).to(cuda)
+    data = sngnn_amd.Data(x=x, edge_index=ei, y=y)
+
+    def loss_with_two_consumers(fuse):
+        M.FUSE_HIDDEN = fuse
+        try:
+            torch.manual_seed(11)
+            m = sngnn_amd.SNGNN_Plus(f, 32, 6, n, 2, 4, 0.0, 1, 0.0).to(cuda).train()
+            seen = []
+            m.lins[0].register_forward_hook(lambda mod, a, out: seen.append(out))
+            out = m(data)
+            hidden = seen[0]
+            if not fuse:                      # (the hook saw the conv's raw output: apply the wrapper's relu)
+                hidden = torch.relu(hidden)
+            loss = F.nll_loss(out, y) + 0.1 * hidden.sum()
+            loss.backward()
+            return {k: v.grad.clone() for k, v in m.named_parameters()}
+        finally:
+            M.FUSE_HIDDEN = True
+
+    with pytest.raises(RuntimeError, match="exactly one consumer"):
+        loss_with_two_consumers(True)
+    grads = loss_with_two_consumers(False)
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())

@@ -340,6 +340,10 @@ def test_sparse_statistics_never_form_the_product(cuda):
     want = torch.from_numpy(m.T @ m) / (torch.bincount(y, minlength=3).double()[:, None] *
                                         torch.bincount(y, minlength=3).double()[None, :])
     assert (cm.double() - want).abs().max() <= 1e-5 * want.abs().max()
+    # fixed-order sums (no float atomics): a second run gives the same BITS - column norms and class sums
+    sp1, sp2 = T._SparseCols(adj, cuda), T._SparseCols(adj, cuda)
+    assert torch.equal(sp1.vals, sp2.vals)
+    assert torch.equal(cm, T.class_similarity_sparse(adj, y, device=cuda).cpu())
     with pytest.raises(ValueError, match="does not fit"):
         T.cosine_similarity_sparse(adj, device=cuda)
 
