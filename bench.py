@@ -554,7 +554,7 @@ def main():
         except Exception as ex:      # noqa: BLE001  (a secondary figure: never fail the line for it)
             result["fwd_bwd_graphed_ms"] = None
             result["fwd_bwd_graphed_note"] = repr(ex)[:200]
-        result["roofline_bwd"] = backward_roofline(ops, graph, h_local, gout, args.top_k, args.thr, e_prime, n, c)
+        result["roofline_bwd"] = backward_roofline(ops, graph, h_local, gout, args.top_k, args.thr, e_prime, n, c, args.workload)
         if not args.no_epoch:
             from sngnn_amd.train import epoch_time_ms
             # reference-style eager loop (train.py:73-143) and the same epoch replayed from a HIP
@@ -599,7 +599,7 @@ def main():
         dist.destroy_process_group()
 
 
-def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
+def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c, workload="arxiv"):
     """SURVEY.md 8d's B_bwd over the device time of the backward's launches: torch events on the
     launch stream around batches of 10 back-to-back backward calls, nothing subtracted."""
     _, wsel, *_ = ops.aggregate_forward(graph, h, top_k, thr, save_for_backward=True)
@@ -624,9 +624,9 @@ def backward_roofline(ops, graph, h, gout, top_k, thr, e_prime, n, c):
     bwd_ms = float(np.median(bw[2:]))          # (median of six batches of ten: robust against a stall of the box)
     b_bwd = backward_bytes(e_prime, n_sel, n, c)
     traffic = None
-    try:       # counter bytes per backward call of the committed PMC passes (arxiv, k 16 only)
-        if (e_prime, n, c, top_k) == (1163820, 169343, 40, 16):
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("arxiv_k16_bwd")
+    try:       # counter bytes per backward call of the committed PMC passes (the full-size default workloads only)
+        if (e_prime, n, c, top_k) in ((1163820, 169343, 40, 16), (123506252, 2449029, 48, 16)):
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{workload}_k{top_k}_bwd")
     except Exception:
         traffic = None
     return {"bound": "hbm", "kernels": ("k_bwd_w (node-centric, one launch: the kept bits come from the training forward itself)" if bits else
@@ -673,7 +673,7 @@ def products_training(ops, graph, R, args, e_prime, n, c):
              "adam_bytes": int(w.numel()) * 4 * 7,       # read w, grad, m, v; write w, m, v
              "adam_gbs": int(w.numel()) * 4 * 7 / (adam_ms * 1e-3) / 1e9,
              "train_step_ms": fb_ms + adam_ms,
-             "roofline_bwd": backward_roofline(ops, graph, R["h_local"], gout, args.top_k, args.thr, e_prime, n, c)}
+             "roofline_bwd": backward_roofline(ops, graph, R["h_local"], gout, args.top_k, args.thr, e_prime, n, c, "products")}
     return extra
 
 

@@ -178,7 +178,9 @@ int sngnn_normalize_rows(const float *h, int64_t rows, int C, float *n, float *n
  * (filt == NULL: they are built inside the workspace by one more pass over n).
  * sngnn_filter_enable(mode): 0 = never, 1 = when it is expected to pay (default: a selective
  * threshold, thr >= 0.25; round 3 also switched it on for top_k <= 8: re-measured, it no longer pays there),
- * 2 = whenever it applies.  Results do not depend on it.
+ * 2 = whenever it applies (the small rows' two-phase form too), 3 = for the rows above the small class
+ * (wave rows, split-row tasks) at any threshold (measurement: the regime where the unit-row table does not
+ * fit the Infinity Cache).  Results do not depend on it.
  */
 int64_t sngnn_filter_row_bytes(int C);
 int sngnn_normalize_rows_filter(const float *h, int64_t rows, int C, float *n, float *nrm,

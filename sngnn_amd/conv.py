@@ -128,7 +128,11 @@ class _FilterHint:
             self._event = None
 
     @torch.no_grad()
-    def probe(self, h: torch.Tensor, edge_index: torch.Tensor, thr: float) -> None:
+    def probe(self, h: torch.Tensor, edge_index: torch.Tensor, thr: float, k_prunes: bool = False) -> None:
+        """``k_prunes``: the library uses the filter on this graph whatever the threshold (top_k itself prunes
+        its long rows: ``ops.filter_wanted(graph, C, top_k, 0.0)``) - then edges passing the threshold are no
+        reason to switch it off; rows whose cosines do not SPREAD (the approximate scores cannot separate
+        them: every edge is a candidate) are, in either case."""
         e = edge_index.size(1)
         if e == 0 or h.size(0) == 0 or self._event is not None:
             return
@@ -140,7 +144,11 @@ class _FilterHint:
         hs = h.index_select(0, src.clamp_max(h.size(0) - 1))
         hd = h.index_select(0, dst.clamp_max(h.size(0) - 1))
         s = F.cosine_similarity(hs, hd, dim=1)
-        verdict = (((s >= thr - 1.1e-3) & ok).float().mean() > 0.5).to(torch.uint8).reshape(1)
+        passing = ((s >= thr - 1.1e-3) & ok).float().mean() > 0.5
+        srt = torch.sort(s).values                                  # (10th .. 90th percentile: static indices, no sync)
+        m = srt.numel()
+        flat = (srt[(9 * m) // 10 - (1 if m >= 10 else 0)] - srt[m // 10]) < 16 * 1.1e-3
+        verdict = (flat if k_prunes else (flat | passing)).to(torch.uint8).reshape(1)
         if self._flag is None:
             self._flag = torch.zeros(1, dtype=torch.uint8).pin_memory()
         self._flag.copy_(verdict, non_blocking=True)
@@ -296,7 +304,7 @@ class SNConv_plus(nn.Module):
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
-            hint.probe(h.detach(), edge_index, float(self.thr))
+            hint.probe(h.detach(), edge_index, float(self.thr), ops.filter_wanted(graph, h.size(1), int(self.top_k), 0.0))
         if _fuse_head(head, graph, h, c, shard, int(self.top_k)):
             return ops.aggregate(h, graph, int(self.top_k), float(self.thr), unit, None, self.bias, head)
         if _fuse_epilogue(epilogue, h, c, shard):
@@ -472,7 +480,7 @@ class SNConv_plus_plus(nn.Module):
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
         h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
-            hint.probe(h.detach(), edge_index, float(self.thr))
+            hint.probe(h.detach(), edge_index, float(self.thr), ops.filter_wanted(graph, h.size(1), int(self.top_k), 0.0))
         if part is None:
             out_0 = ops.adj_linear(self.w.weight, self.w.bias, graph)
         else:

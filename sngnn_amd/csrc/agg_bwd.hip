@@ -8,7 +8,7 @@ using namespace sngnn;
 // measurement / test aid)
 static int g_bwd_mode = 0, g_bwd_roles = 3;
 int sngnn::set_bwd_mode(int v) { g_bwd_mode = (v == 1 || v == 2) ? v : 0; return SNGNN_OK; }
-int sngnn::set_bwd_roles(int v) { g_bwd_roles = v & 3; return SNGNN_OK; }
+int sngnn::set_bwd_roles(int v) { g_bwd_roles = v & 7; return SNGNN_OK; }
 
 extern "C" int sngnn_agg_backward(const sngnn_graph_t *g, const float *h, int C,
                                   const float *grad_out, const float *wsel, float *grad_h,

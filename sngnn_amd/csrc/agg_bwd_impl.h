@@ -453,7 +453,7 @@ __device__ __forceinline__ void s_role_small(const BwdArgs &a, int blk, int *lds
             s_edge_rows<VEC, G, R>(x0, g0, w0, ds0, msg, dns);
             s_edge_rows<VEC, G, R>(x1, g1, two ? w1 : 0.f, two ? ds1 : 0.f, msg, dns);
         } else {
-            const float d0 = a.inv_deg[i0], d1 = a.inv_deg[i1];       // travel with the rows
+            const float d0 = a.inv_deg[(a.role_mask & 4) ? 0 : i0], d1 = a.inv_deg[(a.role_mask & 4) ? 0 : i1];       // travel with the rows (bit 2 of the role mask: timing experiment - one address)
             s_edge_recompute<VEC, G, R>(x0, g0, fin.hv, invv, d0, 1.0f, msg, dns);
             s_edge_recompute<VEC, G, R>(x1, g1, fin.hv, invv, d1, two ? 1.0f : 0.0f, msg, dns);
         }
@@ -854,7 +854,7 @@ __device__ __forceinline__ void s_role_wave(const BwdArgs &a, int blk, int *lds_
             s_edge_rows<VEC, G, R>(xa, ga, ra.x, ra.y, msg, dns);
             s_edge_rows<VEC, G, R>(xb, gb, rb.x, rb.y, msg, dns);
         } else {
-            const float da = a.inv_deg[ia], db = a.inv_deg[ib];       // travel with the rows
+            const float da = a.inv_deg[(a.role_mask & 4) ? 0 : ia], db = a.inv_deg[(a.role_mask & 4) ? 0 : ib];       // travel with the rows
             s_edge_recompute<VEC, G, R>(xa, ga, hv, invv, da, la ? 1.0f : 0.0f, msg, dns);
             s_edge_recompute<VEC, G, R>(xb, gb, hv, invv, db, lb ? 1.0f : 0.0f, msg, dns);
         }

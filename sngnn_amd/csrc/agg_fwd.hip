@@ -55,7 +55,12 @@ static int normalize_dispatch(const RowCfg &cfg, const float *h, int64_t rows, i
     }
 }
 
-// fp16 filter: 0 = never, 1 = when it is expected to pay (default), 2 = whenever it applies
+// wave rows shorter than this score their fp32 rows directly: two dependent round trips for a short row cost more than
+// the second lines they save (uniform in-degree 24, top_k 4: 213 us unfiltered, 273 filtered, 223 with this cut)
+constexpr int FILT_MIN_DEG = 32;
+constexpr double FILT_PRUNABLE_SHARE = 0.62;
+// fp16 filter: 0 = never, 1 = when it is expected to pay (default), 2 = whenever it applies (small rows too),
+// 3 = the rows above the small class (wave rows, split-row tasks) whenever it applies, at any threshold
 static int g_filter_mode = 1;
 // measurement aids: the fp16 filter can be switched off (the selections are the same either
 // way); sngnn_tuning_set(0, mask) runs only some row classes of the main kernel (bit 0 split-row
@@ -67,10 +72,13 @@ static int g_role_mask = 7;
 // exact re-scoring of the candidates, 72.2 against 73.5 us at top_k 16 / thr 0), 1 = table
 // always, 2 = on the fly always (same selections, bit for bit)
 static int g_table_mode = 0;
+// (sngnn_tuning_set(8, d): wave rows with fewer than d in-edges skip the fp16 filter; -1 = the library's rule)
+static int g_filt_min_deg = -1;
 bool sngnn::fwd_scores_on_the_fly_forced() { return g_table_mode == 2; }
 extern "C" int sngnn_tuning_set(int which, int value)
 {
-    SN_REQUIRE(which == 0 || (which >= 2 && which <= 7), SNGNN_EINVAL, "unknown tuning knob");
+    SN_REQUIRE(which == 0 || (which >= 2 && which <= 8), SNGNN_EINVAL, "unknown tuning knob");
+    if (which == 8) { g_filt_min_deg = value; return SNGNN_OK; }
     if (which == 7) return sngnn::set_cosine_split(value);
     if (which == 6) return sngnn::set_knn_route(value);
     if (which == 5) return sngnn::set_lin_mode(value);
@@ -83,7 +91,8 @@ extern "C" int sngnn_tuning_set(int which, int value)
 
 extern "C" int sngnn_filter_enable(int mode)
 {
-    SN_REQUIRE(mode >= 0 && mode <= 2, SNGNN_EINVAL, "filter mode must be 0 (off), 1 (auto) or 2 (always)");
+    SN_REQUIRE(mode >= 0 && mode <= 3, SNGNN_EINVAL,
+               "filter mode must be 0 (off), 1 (auto), 2 (always) or 3 (wave rows and tasks always)");
     g_filter_mode = mode;
     return SNGNN_OK;
 }
@@ -171,6 +180,8 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     // (sngnn_filter_enable(2) forces it at any threshold: the tests' and the fuzz runs' way in)
     // (top_k >= 4: at top_k 1 the small-row form gains 1.5 us where it prunes - 39.3 -> 37.6-38.8 us at thr
     // 0.99 - and costs 13.6 us per call where it does not: the reference scripts' own knobs)
+    // (a pruning threshold: every ranking row takes the filter, as before; by the graph's prunable share: long rows only)
+    a.filt_min_deg = g_filt_min_deg >= 0 ? g_filt_min_deg : (thr >= 0.25f ? 0 : FILT_MIN_DEG);
     a.filt_small = (a.filt != nullptr && top_k >= 0 && g_filter_mode != 0 &&
                     ((thr >= 0.25f && top_k >= 4) || g_filter_mode == 2)) ? 1 : 0;
     // OTF (nrm == NULL, n = raw rows): bound on |fast cosine - reference-order cosine|.  Either
@@ -289,7 +300,18 @@ static bool use_filter(const sngnn_graph_t *g, int C, int top_k, float thr)
     if (g_filter_mode == 0 || top_k < 0 || filter_row_bytes(C) == 0) return false;
     // a pruning threshold: the small rows read the table too (FwdArgs::filt_small) - any graph
     if ((thr >= 0.25f && top_k >= 4) || g_filter_mode == 2) return true;
-    if (thr >= 0.25f) return g->rows_gt(std::max(top_k, SMALL_T)) != 0;
+    if (thr >= 0.25f || g_filter_mode == 3) return g->rows_gt(std::max(top_k, SMALL_T)) != 0;
+    // No threshold to prune with, but top_k itself prunes: a row of `deg` in-edges keeps at most top_k of them, yet
+    // the unfiltered pass fetches the fp32 unit row (two lines for C in 36 .. 60) of every in-edge.  Measured in round
+    // 5 (tools/filter_gate_sweep.py, profiles/r05_filter_gate.txt): with the filter on the rows above the small
+    // class at thr 0 the forward takes 0.73-0.92 of its time on products' degree law at every size tried (unit-row
+    // table 23 MiB .. 470 MB: 5.54 -> 4.16 ms main kernel at full size), 0.79-0.84 at uniform in-degree 50, 0.89-0.93 on
+    // arxiv's law at 4x its edges - and 1.01-1.03 at arxiv's own size (the extra table costs the normalisation pass
+    // 3 us, the main kernel gains 1).  The rule is the graph's PRUNABLE share: edges beyond top_k in rows of at
+    // least FILT_MIN_DEG in-edges (shorter rows skip the filter: FwdArgs::filt_min_deg), over E', at top_k 16 / 4:
+    // products 0.72 / 0.77, uniform 50 0.68 / 0.92, arxiv x4 0.64 / 0.69, arxiv x2 0.58 / 0.62 (0.98 / 0.97 of its time)
+    // | arxiv 0.53 / 0.57.
+    if (g->Ep > 0 && (double)g->prunable_edges(top_k, FILT_MIN_DEG) >= FILT_PRUNABLE_SHARE * (double)g->Ep) return true;
     // No threshold to prune with: the filter could still skip, in rows much longer than top_k, the edges
     // far below the k-th - round 3's rule was "on for top_k <= 8" (-7 us per forward at top_k 1 then).
     // Re-measured in round 4 (same box, arxiv size, C = 40, thr 0; filter on / off): top_k 1: 70.7 / 69.5

@@ -60,6 +60,8 @@ struct FwdArgs {
                           // kernel 40.4 -> 36.2 us); with thr 0 it is a second dependent round trip per set for
                           // rows that keep something anyway (top_k 1: 49.3 -> 61.3 us), so the launcher sets it
                           // for thr >= 0.25 (and top_k >= 4) only
+    int filt_min_deg;     // wave rows below this in-degree score their fp32 rows directly (two dependent round trips
+                          // for a short row cost more than the second lines they save): launcher, agg_fwd.hip
     int C, N;             // N = owned target rows
     int row_off;          // row i's own feature row is n[row_off + i] (node-range partition)
     const int32_t *rowptr, *col, *rperm;
@@ -1137,7 +1139,7 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
     acc.zero();
     // two-precision selection: the filter for ranking rows; OTF whenever scores are kept (ranks
     // asked for on a streaming row included: their order needs exact scores too)
-    const bool banded = OTF ? need_sc : (FILT && rank);
+    const bool banded = OTF ? need_sc : (FILT && rank && deg >= a.filt_min_deg);
     if (!banded)
         score_edges<VEC, G, R, OTF>(a, self, rs, 0, deg, ni, inv_i, !rank, need_sc ? s_sc : nullptr, 0, acc,
                                     rank ? s_ids : nullptr);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -139,6 +140,7 @@ struct sngnn_graph {
     int32_t *ssplit_task0 = nullptr;  // [n_ssplit+1]
     // host copies
     std::vector<int32_t> rdeg;   // in-degrees, descending  (rdeg[p] = deg(rperm[p]))
+    std::vector<int64_t> rdeg_wave_psum;   // prefix sums of rdeg over the rows ABOVE the small class (rows_gt(SMALL_T) + 1 entries)
     std::vector<int32_t> sdeg;   // out-degrees, descending
     int64_t max_in_deg = 0, max_out_deg = 0, src_min = 0;
     int n_split = 0, n_tasks = 0;
@@ -152,6 +154,15 @@ struct sngnn_graph {
         int lo = 0, hi = (int)rdeg.size();
         while (lo < hi) { int m = (lo + hi) / 2; if (rdeg[m] > t) lo = m + 1; else hi = m; }
         return lo;
+    }
+    // edges a top_k selection can PRUNE in rows of at least min_deg in-edges: sum of (deg - top_k) over the rows with
+    // deg >= min_deg and deg > top_k (those rows rank) - the fp16 filter's rule (agg_fwd.hip:use_filter)
+    int64_t prunable_edges(int top_k, int min_deg) const
+    {
+        const int64_t t = std::max<int64_t>(std::max<int64_t>(top_k, (int64_t)min_deg - 1), (int64_t)sngnn::SMALL_T);
+        const int m = rows_gt(t);
+        if (m <= 0 || (size_t)m >= rdeg_wave_psum.size()) return 0;
+        return rdeg_wave_psum[(size_t)m] - (int64_t)std::max(top_k, 0) * m;
     }
     int srcs_gt(int64_t t) const
     {

@@ -14,7 +14,7 @@
 
 using namespace sngnn;
 
-namespace {
+namespace sngnn {
 
 constexpr int GF_U = 4;          // rows in flight per lane group (the forward's own depth)
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_floor(const float *__restrict_
     if (lane == 0) sink[wave] = s;
 }
 
-}  // namespace
+}  // namespace sngnn
 
 extern "C" int64_t sngnn_gather_floor_workspace_bytes(void)
 {

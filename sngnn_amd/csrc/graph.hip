@@ -381,6 +381,11 @@ static int build(sngnn_graph *g, const int64_t *ei, int64_t E, int64_t Ntot, int
         SN_HIP(hipMemcpy(g->rdeg.data(), deg_sorted.p, (size_t)N * 4, hipMemcpyDeviceToHost));
     }
     g->max_in_deg = N ? g->rdeg[0] : 0;
+    {   // prefix sums over the rows above the small class (host; the filter's rule reads them per call)
+        const int m = g->rows_gt(SMALL_T);
+        g->rdeg_wave_psum.assign((size_t)m + 1, 0);
+        for (int p = 0; p < m; ++p) g->rdeg_wave_psum[(size_t)p + 1] = g->rdeg_wave_psum[(size_t)p] + g->rdeg[(size_t)p];
+    }
     // descriptors + slot-ordered column ids of a row order (perm, its degrees in slot order)
     auto describe = [&](const int32_t *perm, const std::vector<int32_t> &deg_slot, int4 **desc, int32_t **col_s) -> int {
         int rc2;

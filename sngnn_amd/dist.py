@@ -294,6 +294,19 @@ def halo_exchange(rows_local: torch.Tensor, plan: HaloPlan, table: Optional[torc
     return _HaloExchange.apply(rows_local.contiguous(), _TableRef(table), plan)
 
 
+# tests: a list - ``_HaloAggregate.forward`` then appends (label, HIP event recorded on the launch stream)
+# at the four points that define the overlap: exchange issued, interior rows' kernels enqueued, exchange
+# waited for, boundary rows' kernels enqueued (tests/test_dist_overlap_gpu.py)
+TRACE = None
+
+
+def _mark(label: str, t: torch.Tensor) -> None:
+    if TRACE is not None and t.is_cuda:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(t.device))
+        TRACE.append((label, ev))
+
+
 class _HaloAggregate(torch.autograd.Function):
     """Exchange + fused aggregation of one rank, overlapped: the rank's INTERIOR rows (every
     source local) are normalised and aggregated while the halo rows are on the wire, the
@@ -309,6 +322,7 @@ class _HaloAggregate(torch.autograd.Function):
         if rows_local.data_ptr() != table.data_ptr():
             table[:n_loc].copy_(rows_local)
         pending = start_halo_exchange(table, plan)
+        _mark("exchange_issued", table)
         need_grad = ctx.needs_input_grad[0]
         dev = table.device
         out = torch.empty((n_loc, c), dtype=torch.float32, device=dev)
@@ -325,11 +339,14 @@ class _HaloAggregate(torch.autograd.Function):
             ops.normalize_rows_into(table[:n_loc], unit[:n_loc], nrm[:n_loc], None if filt is None else filt[:n_loc])
         if plan.n_boundary < n_loc:
             ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 0, out, wsel, inv)
+        _mark("interior_enqueued", table)
         pending.wait()
+        _mark("exchange_waited", table)
         if plan.n_halo and not on_the_fly:
             ops.normalize_rows_into(table[n_loc:], unit[n_loc:], nrm[n_loc:], None if filt is None else filt[n_loc:])
         if plan.n_boundary:
             ops.aggregate_forward_rows(graph, unit, nrm, filt, top_k, thr, plan.row_boundary, 1, out, wsel, inv)
+        _mark("boundary_enqueued", table)
         if need_grad:
             ctx.plan, ctx.graph, ctx.top_k = plan, graph, top_k
             ctx.save_for_backward(table, wsel)

@@ -57,8 +57,11 @@ def pytest_terminal_summary(terminalreporter):
         tot = sum(d for _, d, _ in helpers.DEEP_OPERATOR_LOG)
         rows = sum(r for _, _, r in helpers.DEEP_OPERATOR_LOG)
         mx = max(helpers.DEEP_OPERATOR_GAPS, default=0.0)
+        mx64 = max(helpers.DEEP_EXACT_GAPS, default=0.0)
         tr.write_line(f"second-layer operator level (the oracle's own layer input on both sides): {tot} of {rows} rows, "
-                      f"largest gap {mx:.3e} = {mx / helpers.ULP32:.2f} ulp (gate {helpers.DEEP_GATE_ULPS} ulp)")
+                      f"largest gap in EXACT (float64) cosines of the same unit rows {mx64:.3e} = {mx64 / helpers.ULP32:.2f} ulp "
+                      f"(gate {helpers.TIE_ULPS} ulp: the kernel's own rounding); in the oracle's fp32 scores "
+                      f"{mx:.3e} = {mx / helpers.ULP32:.2f} ulp (gate {helpers.DEEP_GATE_ULPS} ulp: + the oracle's)")
         for label, d, r in helpers.DEEP_OPERATOR_LOG:
             tr.write_line(f"  {label}: {d} of {r}")
     if helpers.NEAR_TIE_LOG:

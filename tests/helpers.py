@@ -45,7 +45,8 @@ def log_operator_rows(differ, rows, label=None):
     OPERATOR_TIE_LOG.append((label, differ, rows))
 
 
-def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie_ulps=None, gaps=None):
+def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie_ulps=None, gaps=None,
+                    exact_gate_ulps=None, exact_gaps=None):
     """Compare the GPU's per-row selection with the oracle's.
 
     Rows that agree exactly pass.  A row that differs is accepted only when the
@@ -53,7 +54,11 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie
     other or of thr) - and never when ``strict``.  With ``h`` (the operator's input rows) a
     differing row must not involve a structural exact tie either.  Returns the number of rows
     that needed the near-tie rule.  ``tie_ulps``: the gate in ulps of 1.0 (default TIE_ULPS);
-    ``gaps``: the list the needed gaps are appended to (default NEAR_TIE_GAPS)."""
+    ``gaps``: the list the needed gaps are appended to (default NEAR_TIE_GAPS).
+    ``exact_gate_ulps`` (needs ``h``): a differing row is ALSO judged on the EXACT cosines of the operands -
+    float64 dot products of the same fp32 unit rows both sides dot - where only the kernel's own rounding
+    can put two edges out of order (the oracle's fp32 scores carry the oracle's summation error too): the
+    gap the row needs there must be <= this many ulps; appended to ``exact_gaps``."""
     tol = (TIE_ULPS if tie_ulps is None else float(tie_ulps)) * ULP32
     gaps = NEAR_TIE_GAPS if gaps is None else gaps
     unit = None
@@ -116,22 +121,35 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie
         # the smallest tolerance that explains this row: how far below thr a kept edge is in the
         # oracle's scores, how far out of rank order the kept list is, and how much better than the
         # worst kept edge (list full) or than thr (room left) an edge that was NOT kept is
-        need = 0.0
-        if picked.size:
-            need = max(need, float(thr32 - picked.min()))
-            if picked.size > 1:
-                need = max(need, float(np.diff(picked).max()))
-        rest = sc[~used]
-        if rest.size and top_k > 0:
-            if picked.size == top_k:
-                need = max(need, float(rest.max() - picked.min()))
-            else:
-                elig = rest[rest >= thr32]
-                if elig.size:
-                    need = max(need, float(elig.max() - thr32))
+        def needed(scores, thr_v):
+            kept_s = scores[picked_edges]
+            need = 0.0
+            if kept_s.size:
+                need = max(need, float(thr_v - kept_s.min()))
+                if kept_s.size > 1:
+                    need = max(need, float(np.diff(kept_s).max()))
+            rest = scores[~used]
+            if rest.size and top_k > 0:
+                if kept_s.size == top_k:
+                    need = max(need, float(rest.max() - kept_s.min()))
+                else:
+                    elig = rest[rest >= thr_v]
+                    if elig.size:
+                        need = max(need, float(elig.max() - thr_v))
+            return need
+        need = needed(sc, thr32)
         assert need <= tol, (f"row {i}: selection differs by more than a near tie: needs {need:.3e} "
                              f"= {need / ULP32:.2f} ulp (gate {tol / ULP32:.1f} ulp); kept {picked.tolist()}")
         gaps.append(need)
+        if exact_gate_ulps is not None:
+            assert unit is not None, "exact_gate_ulps needs h"
+            s64 = (unit[i].astype(np.float64)[None, :] * unit[srcs].astype(np.float64)).sum(axis=1)
+            need64 = needed(s64, np.float64(thr32))
+            assert need64 <= exact_gate_ulps * ULP32, (
+                f"row {i}: in EXACT cosines of the same unit rows the selection needs {need64:.3e} = "
+                f"{need64 / ULP32:.2f} ulp (gate {exact_gate_ulps} ulp): the kernel's own rounding is off")
+            if exact_gaps is not None:
+                exact_gaps.append(need64)
     return int(diff_rows.size)
 
 
@@ -163,10 +181,17 @@ OPERATOR_TIE_LOG = []   # the same at operator level (same inputs on both sides)
 MODEL_TIE_ULPS = 3.0
 MODEL_TIE_GAPS = []
 # second and later layers at OPERATOR level: the oracle's own layer input fed to both sides (gate TIE_ULPS)
+# A deep layer's rows are nearly parallel (arxiv 2-layer model: every cosine within 1.3e-5 of 1): all C
+# products are positive and the partial sums run up to 1, so BOTH sides' fp32 summations carry ~1 ulp of
+# their own, and a gap read off the ORACLE's scores measures the oracle's rounding as much as the kernel's
+# (measured: 2.50 ulp at most, 151 of 189 097 rows).  The kernel is therefore held to the operator gate
+# (TIE_ULPS = 2) on the EXACT cosines - float64 dot products of the same fp32 unit rows - where only its own
+# rounding can reorder two edges; the gap in the oracle's fp32 scores is gated one ulp wider (3) and printed.
 DEEP_OPERATOR_LOG = []
 DEEP_OPERATOR_GAPS = []
+DEEP_EXACT_GAPS = []
 # (SNGNN_DEEP_GATE_ULPS: a measurement aid - run with a wide gate to read the largest gap off the summary)
-DEEP_GATE_ULPS = float(__import__("os").environ.get("SNGNN_DEEP_GATE_ULPS", TIE_ULPS))
+DEEP_GATE_ULPS = float(__import__("os").environ.get("SNGNN_DEEP_GATE_ULPS", TIE_ULPS + 1.0))
 
 
 def model_selection_report(ours, ref, data_cpu, data_gpu, label):
@@ -215,7 +240,8 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
             h_same = h_r.to(h_g.device).contiguous()
             _, _, _, s2, w2 = ops.aggregate_forward(g, h_same, int(k), float(cr.thr), want_selection=True)
             d2 = check_selection(res, s2, w2, int(k), float(cr.thr), strict=False, h=h_r,
-                                 tie_ulps=DEEP_GATE_ULPS, gaps=DEEP_OPERATOR_GAPS)
+                                 tie_ulps=DEEP_GATE_ULPS, gaps=DEEP_OPERATOR_GAPS,
+                                 exact_gate_ulps=TIE_ULPS, exact_gaps=DEEP_EXACT_GAPS)
             DEEP_OPERATOR_LOG.append((f"{label}, layer {li + 1}", d2, h_r.size(0)))
     NEAR_TIE_LOG.append((label, differ, rows))
     return differ, rows

@@ -199,3 +199,43 @@ def test_layer_level_filter_hint(cuda):
         o = conv(xg, ei)
         o.square().sum().backward()
         assert torch.equal(o.detach(), out1) and torch.isfinite(xg.grad).all()
+
+
+def test_filter_by_the_graphs_prunable_share_at_thr_zero(cuda):
+    """Round 5's rule (agg_fwd.hip:use_filter): with NO pruning threshold the filter is still used for the rows
+    above the small class when top_k itself prunes most of the graph's edges (sum of (in-degree - top_k) over the
+    rows of >= 32 in-edges is >= 0.62 E': products' degree law, dense uniform graphs; not arxiv's).  Same bits as
+    with the filter off - outputs, selections, the kept bits a training forward writes and the gradient - and
+    rows shorter than 32 in-edges skip it."""
+    from sngnn_amd import _lib, ops, synth
+    from sngnn_amd.graph import Graph
+    lib = _lib.load()
+    k, thr, c = 16, 0.0, 48
+    rng = np.random.default_rng(3)
+    dense = torch.from_numpy(synth.make_edges(rng, 12000, 600000, 0, uniform=True)).to(cuda)        # in-degree 50
+    law = torch.from_numpy(synth.make_edges(rng, 30000, 30000 * 50, 4000)).to(cuda)                  # products' law
+    sparse = torch.from_numpy(synth.make_edges(rng, 30000, 30000 * 7, 4000)).to(cuda)                # arxiv's
+    short = torch.from_numpy(synth.make_edges(rng, 12000, 12000 * 24, 0, uniform=True)).to(cuda)    # in-degree 24
+    for ei, n, want in ((dense, 12000, True), (law, 30000, True), (sparse, 30000, False), (short, 12000, False)):
+        g = Graph(ei, n, True, True)
+        assert ops.filter_wanted(g, c, k, thr) is want, (n, ei.size(1))
+        assert ops.filter_wanted(g, c, k, 0.9)                 # (a pruning threshold: as before)
+        assert not ops.filter_wanted(g, 32, k, thr)            # (no filter rows for one-line unit rows)
+        if not want:
+            continue
+        h = _rows(n, c, 7, "normal").to(cuda)
+        gout = torch.randn(n, c, generator=torch.Generator().manual_seed(2)).to(cuda)
+        res = {}
+        for mode in (0, 1):
+            lib.sngnn_filter_enable(mode)
+            try:
+                out, wsel, inv, sel_src, sel_w = ops.aggregate_forward(g, h, k, thr, save_for_backward=True,
+                                                                       want_selection=True)
+                hg = h.clone().requires_grad_(True)
+                o2 = ops.aggregate(hg, g, k, thr)                # the training forward (kept bits where supported)
+                o2.backward(gout)
+                res[mode] = (out, wsel, inv, sel_src, sel_w, o2.detach(), hg.grad)
+            finally:
+                lib.sngnn_filter_enable(1)
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)

@@ -9,7 +9,7 @@ from collections import defaultdict
 root = sys.argv[1]
 # which kernels the PMC table lists: the aggregation's by default, the matrix-core ones with "mfma"
 KEEP = ("mfma", "linear_rows", "knn", "cosine") if len(sys.argv) > 2 and sys.argv[2] == "mfma" else \
-    ("agg", "adj", "bwd", "normalize", "pack_kept")
+    ("agg", "adj", "bwd", "normalize", "pack_kept", "gather_floor", "blend", "clear_words")
 
 
 def find(pattern):

@@ -19,9 +19,9 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 workload = sys.argv[1] if len(sys.argv) > 1 else "arxiv"
 channels = int(sys.argv[2]) if len(sys.argv) > 2 else None
-n, c, ei, x, h, lin = bench.make_rank_inputs(workload, 0, 1, 1234, dev, channels)
+n, c, ei, x, h, lin = bench.make_rank_inputs(workload, 0, 1, 1234, dev, channels, scale=float(os.environ.get("SCALE", 1.0)))
 g = Graph(ei, n, True, True)
-print(f"workload {workload} C={c} E'={g.num_edges}")
+print(f"workload {workload} C={c} N={n} E'={g.num_edges} unit-row table {n * c * 4 / 2**20:.0f} MiB")
 m, f, z, e0 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
 if os.environ.get("MODE") == "normalized":      # the caller holds the unit rows: no normalisation pass
     un, unrm = ops.normalize_rows(h)
@@ -30,7 +30,10 @@ else:
     call = lambda k, thr: ops.aggregate_forward(g, h, k, thr)
 if os.environ.get("FILTER") is not None:          # A/B of the fp16 filter (csrc/agg_fwd_filter.h)
     lib.sngnn_filter_enable(int(os.environ["FILTER"]))
-    print("filter mode", os.environ["FILTER"], "(0 never, 1 auto, 2 always)")
+    print("filter mode", os.environ["FILTER"], "(0 never, 1 auto, 2 always, 3 wave rows and tasks always)")
+if os.environ.get("MIN_DEG") is not None:         # wave rows below this in-degree skip the filter (knob 8)
+    lib.sngnn_tuning_set(8, int(os.environ["MIN_DEG"]))
+    print("filter only for wave rows with in-degree >=", os.environ["MIN_DEG"])
 if os.environ.get("ROLES") is not None:           # only some row classes of the main kernel (timing only)
     lib.sngnn_tuning_set(0, int(os.environ["ROLES"]))
     print("role mask", os.environ["ROLES"], "(1 tasks, 2 wave rows, 4 small rows)")
