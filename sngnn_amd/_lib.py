@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsngnn_hip.so")
+# (SNGNN_LIB_PATH: an experimental build of the same library for an A/B measurement; the product is the in-tree file)
+LIB_PATH = os.environ.get("SNGNN_LIB_PATH") or os.path.join(_HERE, "libsngnn_hip.so")
 
 OK, EINVAL, ERANGE, EHIP, ENOMEM = 0, -1, -2, -3, -4
 UNSELECTED = -4.0

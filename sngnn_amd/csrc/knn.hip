@@ -86,17 +86,21 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
 {
     static_assert(!BF3 || FH > 0, "the bf16 form is the register-operand path's");
     __shared__ float sA[FH > 0 ? 1 : KN_M * KN_LD];
-    __shared__ __align__(16) float sB[BF3 ? 3 * KN_M * KN_PS / 4 : KN_M * KN_LD];
+    __shared__ __align__(16) float sB[(FH > 0 ? 2 : 1) * (BF3 ? 3 * KN_M * KN_PS / 4 : KN_M * KN_LD)];   // FH > 0: two buffers
     __shared__ unsigned long long s_list[4][32][KNN_MAX_K];     // running top-k keys per row
     __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
     __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
+    __shared__ float s_ts[4][32];                               // the fast reject's threshold on acc * icol (see the selection)
     __shared__ int s_pend[4][32];                               // candidates parked in list[k .. KNN_MAX_K)
     __shared__ unsigned long long s_cand[4][2][128];            // candidates of the two rows of a register
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
     const int64_t row0 = (int64_t)blockIdx.x * KN_M;
     for (int q = lane; q < 32 * KNN_MAX_K; q += 64) s_list[wave][q / KNN_MAX_K][q % KNN_MAX_K] = 0ull;
-    if (lane < 32) { s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; s_pend[wave][lane] = 0; }
+    if (lane < 32) {
+        s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; s_pend[wave][lane] = 0;
+        s_ts[wave][lane] = (row0 + wave * 32 + lane < N) ? -INFINITY : INFINITY;      // (rows beyond N: never a candidate)
+    }
     const int cap = KNN_MAX_K - k;                               // spare slots behind a row's list
     const int sc = tid & 31, sr = tid >> 5;
     const int64_t ncol_tiles = (N + KN_M - 1) / KN_M;
@@ -132,6 +136,16 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        // the tile's column ids and inverse norms (for the selection): requested here, they travel under the products
+        float icol[4];
+        int64_t jcol[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            jcol[b] = col0 + b * 32 + l32;
+            icol[b] = inv[min(jcol[b], N - 1)];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) icol[b] = jcol[b] < N ? icol[b] : 0.f;
         if constexpr (FH > 0) {
             // k-step = 16 steps of each half: columns [s0, s0 + 16) and [FH + s0, FH + s0 + 16) of
             // the column block's rows, as 16-byte vectors: thread t owns vector (t & 7) - four
@@ -140,8 +154,21 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             // cosines go through the selection below.  (Named registers: see toolbox.hip,
             // k_cosine_mfma - a private array that lives across the tile loop's back edge goes
             // to scratch memory and its loads are waited for at once.)
-            const int seg = tid & 7, pr = tid >> 3;
+            // Round 5: the column panel is DOUBLE-BUFFERED - step L's products read buffer L & 1 while the
+            // panel of step L + 1 (requested a step earlier, split here) is written into the other one and the
+            // panel of step L + 2 is requested: ONE workgroup barrier per step instead of two, and the staging's
+            // vector work (the bf16 split: ~100 instructions per step and thread) sits in the same block as the
+            // step's 64 matrix instructions, where the wave issues it beside them (one wave per SIMD: nobody
+            // else would).  The steps run on across tile boundaries (the next tile's first panel is staged
+            // under this tile's last products and waits in LDS during the selection).
+            // Staging map: 16 consecutive lanes write rows r and r + 4 (not r and r + 1): with the 80-byte
+            // plane rows their 8-byte stores cover all 32 banks once - adjacent rows overlapped in four
+            // (SQ_LDS_BANK_CONFLICT 777 M cycles at arxiv size, 1.24 per LDS instruction, all from these stores).
+            const int seg = tid & 7, slot = tid >> 3;
+            const int pr = (slot & ~7) | ((slot & 7) >> 1) | ((slot & 1) << 2);
             const int kseg = seg < 4 ? 4 * seg : FH + 4 * (seg - 4);
+            constexpr int NS = FH / 16;                                   // steps per tile
+            constexpr int PANEL = BF3 ? 3 * KN_M * KN_PS : KN_M * KN_LD * 4;   // bytes of one buffer
 #define SN_KNN_FETCH(COL0, S0)                                                                            \
             {                                                                                             \
                 const float *g_ = x + (S0) + kseg;                                                        \
@@ -150,22 +177,18 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                 rb2 = *(const knn_f4 *)(g_ + min((COL0) + pr + 64, N - 1) * F);                           \
                 rb3 = *(const knn_f4 *)(g_ + min((COL0) + pr + 96, N - 1) * F);                           \
             }
-            if (ct == ct_begin) SN_KNN_FETCH(col0, 0)
-            float *wb = sB + pr * KN_LD + 4 * seg;
-            const float *pb = sB + l32 * KN_LD + half * 16;
+            unsigned char *sBb = reinterpret_cast<unsigned char *>(sB);
             // BF3: plane p of column row r at byte (p * KN_M + r) * KN_PS; its 32 k-slots are the
             // step's 16 of half 0 followed by the 16 of half 1 (seg 0..3 | 4..7, 8 bytes each)
-            unsigned char *wb3 = reinterpret_cast<unsigned char *>(sB) + pr * KN_PS + 8 * seg;
-            const unsigned char *pb3 = reinterpret_cast<const unsigned char *>(sB) + l32 * KN_PS + 32 * half;
-#pragma unroll
-            for (int s0 = 0; s0 < FH; s0 += 16) {
-                __syncthreads();
+            auto stage = [&](int boff) {
                 if constexpr (!BF3) {
+                    float *wb = reinterpret_cast<float *>(sBb + boff) + pr * KN_LD + 4 * seg;
                     *(knn_f4 *)(wb) = rb0;
                     *(knn_f4 *)(wb + 32 * KN_LD) = rb1;
                     *(knn_f4 *)(wb + 64 * KN_LD) = rb2;
                     *(knn_f4 *)(wb + 96 * KN_LD) = rb3;
                 } else {
+                    unsigned char *wb3 = sBb + boff + pr * KN_PS + 8 * seg;
                     auto put = [&](int u, const knn_f4 &v) {
                         const float vv[4] = {v[0], v[1], v[2], v[3]};
                         sn_u32x2 p1, p2, p3;
@@ -177,9 +200,28 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     };
                     put(0, rb0); put(1, rb1); put(2, rb2); put(3, rb3);
                 }
+            };
+            // linear step L = (ct - ct_begin) NS + s0 / 16 lives in buffer L & 1
+            auto fetch_step = [&](int64_t L) {
+                const int64_t t_ = ct_begin + L / NS;
+                const int st_ = (int)(L % NS) * 16;
+                if (t_ < ct_end) SN_KNN_FETCH(t_ * KN_M, st_)
+            };
+            if (ct == ct_begin) {
+                fetch_step(0);
+                stage(0);
+                fetch_step(1);
                 __syncthreads();
-                if (s0 + 16 < FH) SN_KNN_FETCH(col0, s0 + 16)
-                else if (ct + 1 < ct_end) SN_KNN_FETCH(col0 + KN_M, 0)
+            }
+            const int64_t L0 = (ct - ct_begin) * NS;
+#pragma unroll
+            for (int s0 = 0; s0 < FH; s0 += 16) {
+                const int64_t L = L0 + s0 / 16;
+                const int cur = (int)(L & 1) * PANEL;
+                if (s0 + 16 < FH || ct + 1 < ct_end) stage(cur ^ PANEL);      // step L + 1's panel (in the registers)
+                fetch_step(L + 2);
+                const float *pb = reinterpret_cast<const float *>(sBb + cur) + l32 * KN_LD + half * 16;
+                const unsigned char *pb3 = sBb + cur + l32 * KN_PS + 32 * half;
                 if constexpr (BF3) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {          // 8 k-slots of each half per MFMA
@@ -190,9 +232,15 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                             const sn_u32x4 b1 = *(const sn_u32x4 *)(r_);
                             const sn_u32x4 b2 = *(const sn_u32x4 *)(r_ + KN_M * KN_PS);
                             const sn_u32x4 b3 = *(const sn_u32x4 *)(r_ + 2 * KN_M * KN_PS);
+#if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 2        // timing experiment: one product of eight
+#define SN_KNN_M3(PA, PB) asm volatile("" ::"v"(PA), "v"(PB));
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sn_bf16x8, ap1[aq]),
+                                                                             __builtin_bit_cast(sn_bf16x8, b1), acc[b], 0, 0, 0);
+#else
 #define SN_KNN_M3(PA, PB)                                                                                   \
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sn_bf16x8, PA), \
                                                                              __builtin_bit_cast(sn_bf16x8, PB), acc[b], 0, 0, 0);
+#endif
                             SN_KNN_M3(ap3[aq], b2) SN_KNN_M3(ap2[aq], b3) SN_KNN_M3(ap3[aq], b1) SN_KNN_M3(ap2[aq], b2)
                             SN_KNN_M3(ap1[aq], b3) SN_KNN_M3(ap2[aq], b1) SN_KNN_M3(ap1[aq], b2) SN_KNN_M3(ap1[aq], b1)
 #undef SN_KNN_M3
@@ -211,6 +259,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     SN_KNN_MFMA(x, 0) SN_KNN_MFMA(y, 1) SN_KNN_MFMA(z, 2) SN_KNN_MFMA(w, 3)
 #undef SN_KNN_MFMA
                 }
+                __syncthreads();       // step L's reads are done, step L + 1's panel is complete
             }
 #undef SN_KNN_FETCH
         } else {
@@ -246,16 +295,41 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             }
         }
         }   // FH == 0
-        // ---- selection: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-        float icol[4];
-        int64_t jcol[4];
+#if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 1        // timing experiment: no selection at all
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            jcol[b] = col0 + b * 32 + l32;
-            icol[b] = jcol[b] < N ? inv[jcol[b]] : 0.f;
-        }
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[b][r]));
+        continue;
+#endif
+        // ---- selection: C/D layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        // Round 5: the fast reject of ALL sixteen registers first, from thresholds fetched together.  Register r
+        // holds two rows of the wave's 32 (one per half-wave), each row sits in exactly one register, so the
+        // sixteen thresholds of a tile can be read up front: one LDS round trip instead of sixteen serial ones,
+        // and no read of the rows' inverse norms at all - s_ts[row] is the row's k-th cosine DIVIDED by its
+        // inverse norm, lowered by a relative 1e-6 (a superset test: `acc * icol >= ts` holds whenever the exact
+        // `acc * (irow * icol) >= thrf` below does; the exact rule still decides).  Before, every register cost a
+        // dependent LDS read and a global read of inv[i]: the selection was 34 of the kernel's 88 ms at arxiv
+        // size (a build without any selection: 54 ms), 26 of 80 now.  What is left are the ~3.6 registers per tile
+        // and wave that do hold a candidate (k ln(N / k) insertions per row over the scan) and their LDS round
+        // trips, which nothing hides at one wave per SIMD.  Measured and dropped: the candidates appended by their
+        // lanes to a wave-private LDS queue (LDS atomic) and worked off one by one - 85.6 ms against 80.0 (64
+        // divergent tests per tile cost more than 16 ballots; an entry still costs three dependent LDS reads).
+        float tsr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tsr[r] = s_ts[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
+        unsigned hot16 = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            bool m_ = false;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m_ |= acc[b][r] * icol[b] >= tsr[r];
+            if (__ballot(m_) != 0ull) hot16 |= 1u << r;
+        }
+        if (hot16 != 0u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (!((hot16 >> r) & 1u)) continue;                          // (wave-uniform)
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;          // this lane's row within the wave's 32
             const int64_t i = row0 + wave * 32 + lr;
             const float irow = i < N ? inv[i] : 0.f;
@@ -326,7 +400,11 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     s_pend[wave][rowh] = 0;
                     s_thr[wave][rowh] = T;
                     const unsigned u = (unsigned)(T >> 32);
-                    s_thrf[wave][rowh] = T ? __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) : -INFINITY;
+                    const float tf = T ? __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) : -INFINITY;
+                    s_thrf[wave][rowh] = tf;
+                    // (rows beyond N never get here: their lists take no key)
+                    const float tq = tf / inv[min(row0 + wave * 32 + rowh, N - 1)];
+                    s_ts[wave][rowh] = tq - (fabsf(tq) * 1e-6f + 1e-30f);
                 }
             }
             wave_lds_sync();

@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void k_cosine_mfma(const float *__restrict__ x
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // staging: thread t owns the 16-byte vector (t & 7) of rows (t >> 3) + 32 u, u = 0..3
-    const int kq = tid & 7, r0 = tid >> 3;
+    // (16 consecutive lanes stage rows r and r + 4, not r and r + 1: with the bf16 planes' 80-byte rows their 8-byte
+    // stores then cover all 32 banks once - adjacent rows overlapped in four banks, 2.4 conflict cycles per LDS
+    // instruction in round 4's counters, all from these stores; the fp32 panels' 16-byte stores do not care)
+    const int kq = tid & 7, slot_ = tid >> 3, r0 = (slot_ & ~7) | ((slot_ & 7) >> 1) | ((slot_ & 1) << 2);
     f4 va0, va1, va2, va3, vb0, vb1, vb2, vb3;
     const float *ga0 = x + min(row0 + r0, N - 1) * ld + 4 * kq, *ga1 = x + min(row0 + r0 + 32, N - 1) * ld + 4 * kq;
     const float *ga2 = x + min(row0 + r0 + 64, N - 1) * ld + 4 * kq, *ga3 = x + min(row0 + r0 + 96, N - 1) * ld + 4 * kq;
