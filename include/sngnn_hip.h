@@ -414,6 +414,20 @@ int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table, const floa
                           int C, float *out, void *workspace, void *stream);
 int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, float *out,
                            void *workspace, void *stream);
+/*
+ * Replaces: GGCNlayer_SP's plain propagation `torch.sparse.mm(adj * sc, Wh)` (models.py:1544-1549,
+ * use_sign=False) and its autograd - the same two gather-sums with one WEIGHT per entry:
+ *   out[i]  = sum_{q in CSR row i} w_csr[q] * table[col_q]          (weights in the graph's CSR order)
+ *   out[j]  = sum_{q in CSC row j} w_csc[q] * vals[dst_q]           (the transpose; weights in CSC order)
+ * (value * row rounded, then added: a sparse mm's arithmetic; fixed order, no atomics), and the weights'
+ * gradient out[p] = <a_rows[idx_a[p]], b_rows[idx_b[p]]> per entry (idx_*: dev i32 [n_pairs]).
+ */
+int sngnn_weighted_gather_sum_rows(const sngnn_graph_t *g, const float *table, const float *w_csr, int C,
+                                   float *out, void *workspace, void *stream);
+int sngnn_weighted_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, const float *w_csc, int C,
+                                    float *out, void *workspace, void *stream);
+int sngnn_pair_dot_rows(const float *a_rows, const int32_t *idx_a, const float *b_rows, const int32_t *idx_b,
+                        int64_t n_pairs, int C, float *out, void *stream);
 
 /*
  * Measurement aid (no reference counterpart): while enabled, sngnn_agg_forward

@@ -73,6 +73,9 @@ SIGNATURES = {
     "sngnn_knn_graph": (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sngnn_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sngnn_scatter_sum_rows": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_weighted_gather_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_weighted_scatter_sum_rows": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sngnn_pair_dot_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "sngnn_profile_enable": (_i32, [_i32]),
     "sngnn_profile_last_forward": (_i32, [C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_f32)]),
     "sngnn_gather_floor_workspace_bytes": (_i64, []),

@@ -26,7 +26,7 @@ extern "C" int sngnn_adj_linear_forward(const sngnn_graph_t *g, const float *wt,
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
                "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
     AdjArgs a;
-    a.table = wt; a.bias = bias; a.out = out0; a.partial = (float *)workspace;
+    a.table = wt; a.w = nullptr; a.bias = bias; a.out = out0; a.partial = (float *)workspace;
     a.C = C; a.N = (int)g->N;
     a.ptr = g->cscptr; a.idx = g->csc_dst; a.perm = g->sperm;
     a.seg_shift = (int)g->src_min;        // out row i <- CSC row i + src_min (models.py:125)
@@ -49,7 +49,7 @@ extern "C" int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
                "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
     AdjArgs a;
-    a.table = g0; a.bias = nullptr; a.out = dwt; a.partial = (float *)workspace;
+    a.table = g0; a.w = nullptr; a.bias = nullptr; a.out = dwt; a.partial = (float *)workspace;
     a.C = C; a.N = (int)g->N;
     a.ptr = g->rowptr; a.idx = g->col; a.perm = g->rperm;
     a.seg_shift = 0;
@@ -65,8 +65,21 @@ extern "C" int sngnn_adj_linear_backward(const sngnn_graph_t *g, const float *g0
 // the adjacency branch of a rank runs on the partition of the FLIPPED edge list,
 // whose "targets" are the rank's own source nodes).
 // ---------------------------------------------------------------------------
+static int gather_sum_impl(const sngnn_graph_t *g, const float *table, const float *w, const float *bias, int C,
+                           float *out, void *workspace, void *stream);
 extern "C" int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table, const float *bias,
                                      int C, float *out, void *workspace, void *stream)
+{
+    return gather_sum_impl(g, table, nullptr, bias, C, out, workspace, stream);
+}
+extern "C" int sngnn_weighted_gather_sum_rows(const sngnn_graph_t *g, const float *table, const float *w_csr, int C,
+                                              float *out, void *workspace, void *stream)
+{
+    SN_REQUIRE(g == nullptr || g->Ep == 0 || w_csr != nullptr, SNGNN_EINVAL, "w_csr is NULL");
+    return gather_sum_impl(g, table, w_csr, nullptr, C, out, workspace, stream);
+}
+static int gather_sum_impl(const sngnn_graph_t *g, const float *table, const float *w, const float *bias, int C,
+                           float *out, void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
     if (g->N == 0) return SNGNN_OK;
@@ -76,7 +89,7 @@ extern "C" int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table,
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
                "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
     AdjArgs a;
-    a.table = table; a.bias = bias; a.out = out; a.partial = (float *)workspace;
+    a.table = table; a.w = w; a.bias = bias; a.out = out; a.partial = (float *)workspace;
     a.C = C; a.N = (int)g->N;                    // one segment per owned CSR row
     a.ptr = g->rowptr; a.idx = g->col; a.perm = g->rperm;
     a.seg_shift = 0; a.idx_shift = 0;
@@ -86,8 +99,47 @@ extern "C" int sngnn_gather_sum_rows(const sngnn_graph_t *g, const float *table,
     return dispatch_adj(cfg, a, (hipStream_t)stream);
 }
 
+static int scatter_sum_impl(const sngnn_graph_t *g, const float *vals, const float *w, int C, float *out,
+                            void *workspace, void *stream);
 extern "C" int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, int C, float *out,
                                       void *workspace, void *stream)
+{
+    return scatter_sum_impl(g, vals, nullptr, C, out, workspace, stream);
+}
+extern "C" int sngnn_weighted_scatter_sum_rows(const sngnn_graph_t *g, const float *vals, const float *w_csc, int C,
+                                               float *out, void *workspace, void *stream)
+{
+    SN_REQUIRE(g == nullptr || g->Ep == 0 || w_csc != nullptr, SNGNN_EINVAL, "w_csc is NULL");
+    return scatter_sum_impl(g, vals, w_csc, C, out, workspace, stream);
+}
+// out[p] = <a_rows[idx_a[p]], b_rows[idx_b[p]]> for p in [0, n_pairs): the gradient of a weighted gather-sum with
+// respect to its per-entry weights (a_rows = the output's gradient by target, b_rows = the gathered table by source)
+namespace sngnn {
+static int dispatch_pair_dot(const RowCfg &cfg, const float *A, const int32_t *ia, const float *B, const int32_t *ib,
+                             int64_t E, int C, float *out, hipStream_t st)
+{
+    switch (cfg.vec) {
+    case 1: SNGNN_DISPATCH_GR(launch_pair_dot, 1, cfg, A, ia, B, ib, E, C, out, st)
+    case 2: SNGNN_DISPATCH_GR(launch_pair_dot, 2, cfg, A, ia, B, ib, E, C, out, st)
+    default: SNGNN_DISPATCH_GR(launch_pair_dot, 4, cfg, A, ia, B, ib, E, C, out, st)
+    }
+}
+}  // namespace sngnn
+extern "C" int sngnn_pair_dot_rows(const float *a_rows, const int32_t *idx_a, const float *b_rows, const int32_t *idx_b,
+                                   int64_t n_pairs, int C, float *out, void *stream)
+{
+    SN_REQUIRE(n_pairs >= 0, SNGNN_EINVAL, "negative pair count");
+    if (n_pairs == 0) return SNGNN_OK;
+    SN_REQUIRE(a_rows && b_rows && idx_a && idx_b && out, SNGNN_EINVAL, "NULL argument");
+    RowCfg cfg;
+    SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL, "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
+    const uintptr_t al = (uintptr_t)cfg.vec * 4;
+    SN_REQUIRE((uintptr_t)a_rows % al == 0 && (uintptr_t)b_rows % al == 0, SNGNN_EINVAL,
+               "rows must be aligned to the row vector width");
+    return dispatch_pair_dot(cfg, a_rows, idx_a, b_rows, idx_b, n_pairs, C, out, (hipStream_t)stream);
+}
+static int scatter_sum_impl(const sngnn_graph_t *g, const float *vals, const float *w, int C, float *out,
+                            void *workspace, void *stream)
 {
     SN_REQUIRE(g != nullptr, SNGNN_EINVAL, "graph is NULL");
     if (g->Ntot == 0) return SNGNN_OK;
@@ -97,7 +149,7 @@ extern "C" int sngnn_scatter_sum_rows(const sngnn_graph_t *g, const float *vals,
     SN_REQUIRE(row_cfg(C, cfg), SNGNN_EINVAL,
                "C must be in [1, " + std::to_string(SNGNN_MAX_CHANNELS) + "]");
     AdjArgs a;
-    a.table = vals; a.bias = nullptr; a.out = out; a.partial = (float *)workspace;
+    a.table = vals; a.w = w; a.bias = nullptr; a.out = out; a.partial = (float *)workspace;
     a.C = C; a.N = (int)g->Ntot;                 // one segment per source node (CSC row)
     a.ptr = g->cscptr; a.idx = g->csc_dst; a.perm = g->sperm;
     a.seg_shift = 0; a.idx_shift = 0;

@@ -12,6 +12,8 @@ namespace sngnn {
 
 struct AdjArgs {
     const float *table;         // rows to gather  [N, C]
+    const float *w;             // per-entry weights in SEGMENT order (w[ptr[seg] + t]) or nullptr = 1 (weighted gather-sum:
+                                // GGCNlayer_SP's plain propagation, models.py:1544-1549)
     const float *bias;          // [C] or nullptr
     float *out;                 // [N, C]
     float *partial;             // [n_tasks, C]
@@ -33,16 +35,21 @@ __device__ __forceinline__ void adj_gather(const AdjArgs &a, int qs, int e0, int
     for (int base = e0 + first; base < e1; base += stride * U) {
         RowT x[U];
         bool act[U];
+        float wv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = base + u * stride;
             act[u] = t < e1;
             const int row = act[u] ? a.idx[qs + t] + a.idx_shift : 0;
+            wv[u] = (a.w && act[u]) ? a.w[qs + t] : 1.0f;         // (uniform pointer test; travels with the row)
             x[u].load(a.table + (size_t)row * a.C, a.C, lg);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (act[u]) acc.add(x[u]);
+            if (act[u]) {
+                if (a.w) acc.axpy(wv[u], x[u]);                    // value * row rounded, then added (a sparse mm's order)
+                else acc.add(x[u]);
+            }
     }
 }
 
@@ -142,6 +149,42 @@ static __global__ void k_adj_tail(const AdjArgs a, int first_row)
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (int64_t)gridDim.x * blockDim.x)
         a.out[(size_t)first_row * a.C + t] = a.bias ? a.bias[t % a.C] : 0.f;
+}
+
+// out[e] = <A[ia[e]], B[ib[e]]> for e in [0, E): one lane group per entry, two entries per group in flight
+template <int VEC, int G, int R>
+__global__ __launch_bounds__(BLOCK) void k_pair_dot(const float *__restrict__ A, const int32_t *__restrict__ ia,
+                                                    const float *__restrict__ B, const int32_t *__restrict__ ib,
+                                                    int64_t E, int C, float *__restrict__ out)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G;
+    const int lane = lane_id(), gid = lane / G, lg = lane % G;
+    const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nw = (int64_t)gridDim.x * WAVES;
+    for (int64_t base = wave * 2 * NG; base < E; base += nw * 2 * NG) {
+        const int64_t e0 = base + gid, e1 = base + NG + gid;
+        const int64_t c0 = e0 < E ? e0 : E - 1, c1 = e1 < E ? e1 : E - 1;
+        RowT a0, b0, a1, b1;
+        a0.load(A + (size_t)ia[c0] * C, C, lg);
+        b0.load(B + (size_t)ib[c0] * C, C, lg);
+        a1.load(A + (size_t)ia[c1] * C, C, lg);
+        b1.load(B + (size_t)ib[c1] * C, C, lg);
+        const float d0 = group_sum<G>(a0.dot_partial(b0)), d1 = group_sum<G>(a1.dot_partial(b1));
+        if (lg == 0) {
+            if (e0 < E) out[e0] = d0;
+            if (e1 < E) out[e1] = d1;
+        }
+    }
+}
+template <int VEC, int G, int R>
+int launch_pair_dot(const float *A, const int32_t *ia, const float *B, const int32_t *ib, int64_t E, int C, float *out,
+                    hipStream_t st)
+{
+    if (E == 0) return SNGNN_OK;
+    const int grid = (int)std::min<int64_t>(ceil_div(E, (int64_t)2 * (64 / G) * WAVES), 256 * 8);
+    k_pair_dot<VEC, G, R><<<grid, BLOCK, 0, st>>>(A, ia, B, ib, E, C, out);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
 }
 
 template <int VEC, int G, int R> int launch_adj(const AdjArgs &a0, hipStream_t st)

@@ -58,6 +58,23 @@ class _AdjStructure:
         off_diag = torch.nonzero(idx[0] != idx[1]).flatten()
         eid = torch.from_numpy(self.graph.array("eid").astype("int64")).to(idx.device)
         self.perm = off_diag[eid]
+        self._ei, self._n = ei, n
+        self._full = None
+
+    def full(self):
+        """The structure of ALL entries of adj, diagonal included (the plain propagation of use_sign=False,
+        models.py:1544-1549): (graph, perm with ``coef_csr = coef_entries[perm]``, (csc_eid, tgt, src) of
+        ``ops.weighted_propagate``).  Built on first use."""
+        if self._full is None:
+            g = Graph(self._ei, self._n, False, False)
+            dev = self._ei.device
+            perm = torch.from_numpy(g.array("eid").astype("int64")).to(dev)
+            src = torch.from_numpy(g.array("col")).to(dev)                       # int32 [E'] source of each CSR entry
+            rowptr = torch.from_numpy(g.array("rowptr").astype("int64")).to(dev)
+            tgt = torch.repeat_interleave(torch.arange(self._n, device=dev, dtype=torch.int32), rowptr[1:] - rowptr[:-1])
+            csc_eid = torch.from_numpy(g.array("csc_eid").astype("int64")).to(dev)
+            self._full = (g, perm, (csc_eid, tgt.contiguous(), src.contiguous()))
+        return self._full
 
 
 class GGCNlayer_SP(nn.Module):
@@ -108,8 +125,11 @@ class GGCNlayer_SP(nn.Module):
             coef = val * F.softplus(self.deg_coeff[0] * dv + self.deg_coeff[1])       # adj * sc (:1508-1510)
         wh = ops.linear(h, self.fcn)
         if not self.use_sign:
-            # :1544-1549: a plain weighted sparse product (diagonal included), no cosine: the library's SpMM
-            return torch.sparse.mm(torch.sparse_coo_tensor(adj._indices(), coef, adj.size()), wh)
+            # :1544-1549: a plain weighted sparse product (diagonal included), no cosine - the same gather-sum
+            # kernels as SNGNN++'s adjacency branch, with one weight per entry (no torch.sparse.mm: fixed order,
+            # no atomics, autograd through Wh and through the degree coefficients)
+            graph, perm, aux = self._adj(adj).full()
+            return ops.weighted_propagate(wh, coef[perm], graph, aux)
         st = self._adj(adj)
         c = F.softmax(self.coeff, dim=-1)
         scale = F.softplus(self.scale)

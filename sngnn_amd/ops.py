@@ -569,6 +569,60 @@ def signed_propagate(wh: torch.Tensor, coef: torch.Tensor, c2: torch.Tensor, gra
     return _SignedPropagate.apply(wh, coef, c2, graph)
 
 
+class _WeightedPropagate(torch.autograd.Function):
+    """``torch.sparse.mm(A, X)`` for a sparse ``A`` whose pattern is a device graph (GGCNlayer_SP's plain
+    propagation, models.py:1544-1549): ``out[i] = sum_e w_e X[src_e]`` over the in-edges of i, with autograd
+    through X (the transpose gather-sum) and through the per-entry weights (``<G_i, X_j>`` per entry) -
+    ``sngnn_weighted_gather_sum_rows`` / ``_scatter_sum_rows`` / ``sngnn_pair_dot_rows``: gathers with a fixed
+    order, no atomics.  ``w_csr`` [E'] in the graph's CSR order; ``aux`` = (csc_eid int64 [E'], tgt int32 [E'],
+    src int32 [E']) - the graph's CSC -> CSR map and the CSR entries' rows and columns, built once per graph."""
+
+    @staticmethod
+    def forward(ctx, x, w_csr, graph, aux):
+        lib = _lib.load()
+        x = _check_rows(x, graph.num_total_nodes, "x")
+        c = x.size(1)
+        if w_csr.dtype != torch.float32 or w_csr.numel() != graph.num_edges or not w_csr.is_cuda:
+            raise ValueError("w_csr must be a float32 GPU tensor with one entry per edge of the graph")
+        w_csr = w_csr.contiguous()
+        out = torch.empty((graph.num_nodes, c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.sngnn_weighted_gather_sum_rows(graph.handle, x.data_ptr(), w_csr.data_ptr(), c, out.data_ptr(),
+                                                    graph.workspace(c).data_ptr(), _stream(x.device))
+        _lib.check(rc, "sngnn_weighted_gather_sum_rows")
+        ctx.graph, ctx.aux = graph, aux
+        ctx.save_for_backward(x, w_csr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_csr = ctx.saved_tensors
+        graph = ctx.graph
+        csc_eid, tgt, src = ctx.aux
+        lib = _lib.load()
+        g = _check_rows(g.contiguous(), graph.num_nodes, "grad_out")
+        c = x.size(1)
+        gx = gw = None
+        with torch.cuda.device(x.device):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                w_csc = w_csr.index_select(0, csc_eid)
+                rc = lib.sngnn_weighted_scatter_sum_rows(graph.handle, g.data_ptr(), w_csc.data_ptr(), c, gx.data_ptr(),
+                                                         graph.workspace(c).data_ptr(), _stream(x.device))
+                _lib.check(rc, "sngnn_weighted_scatter_sum_rows")
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(w_csr)
+                rc = lib.sngnn_pair_dot_rows(g.data_ptr(), tgt.data_ptr(), x.data_ptr(), src.data_ptr(), w_csr.numel(), c,
+                                             gw.data_ptr(), _stream(x.device))
+                _lib.check(rc, "sngnn_pair_dot_rows")
+        return gx, gw, None, None
+
+
+def weighted_propagate(x: torch.Tensor, w_csr: torch.Tensor, graph: Graph, aux) -> torch.Tensor:
+    """Differentiable weighted gather-sum over a graph's in-edges (see ``_WeightedPropagate``)."""
+    return _WeightedPropagate.apply(x, w_csr, graph, aux)
+
+
 def adj_linear_forward(graph: Graph, wt: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     lib = _lib.load()
     wt = _check_rows(wt, graph.num_nodes, "wt")

@@ -46,7 +46,7 @@ def log_operator_rows(differ, rows, label=None):
 
 
 def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie_ulps=None, gaps=None,
-                    exact_gate_ulps=None, exact_gaps=None):
+                    exact_gate_ulps=None, exact_gaps=None, exact_unit=None):
     """Compare the GPU's per-row selection with the oracle's.
 
     Rows that agree exactly pass.  A row that differs is accepted only when the
@@ -58,7 +58,10 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie
     ``exact_gate_ulps`` (needs ``h``): a differing row is ALSO judged on the EXACT cosines of the operands -
     float64 dot products of the same fp32 unit rows both sides dot - where only the kernel's own rounding
     can put two edges out of order (the oracle's fp32 scores carry the oracle's summation error too): the
-    gap the row needs there must be <= this many ulps; appended to ``exact_gaps``."""
+    gap the row needs there must be <= this many ulps; appended to ``exact_gaps``.  ``exact_unit``: the unit rows
+    the KERNEL dots (``ops.normalize_rows`` of the same h: its sum of squares is added in another order than the
+    CPU's, so a row's norm - and with it every element - can differ from F.normalize's by an ulp; the kernel's
+    own rounding is judged on ITS operands)."""
     tol = (TIE_ULPS if tie_ulps is None else float(tie_ulps)) * ULP32
     gaps = NEAR_TIE_GAPS if gaps is None else gaps
     unit = None
@@ -143,7 +146,8 @@ def check_selection(res, sel_src_gpu, sel_w_gpu, top_k, thr, strict, h=None, tie
         gaps.append(need)
         if exact_gate_ulps is not None:
             assert unit is not None, "exact_gate_ulps needs h"
-            s64 = (unit[i].astype(np.float64)[None, :] * unit[srcs].astype(np.float64)).sum(axis=1)
+            eu = unit if exact_unit is None else exact_unit
+            s64 = (eu[i].astype(np.float64)[None, :] * eu[srcs].astype(np.float64)).sum(axis=1)
             need64 = needed(s64, np.float64(thr32))
             assert need64 <= exact_gate_ulps * ULP32, (
                 f"row {i}: in EXACT cosines of the same unit rows the selection needs {need64:.3e} = "
@@ -186,7 +190,9 @@ MODEL_TIE_GAPS = []
 # their own, and a gap read off the ORACLE's scores measures the oracle's rounding as much as the kernel's
 # (measured: 2.50 ulp at most, 151 of 189 097 rows).  The kernel is therefore held to the operator gate
 # (TIE_ULPS = 2) on the EXACT cosines - float64 dot products of the same fp32 unit rows - where only its own
-# rounding can reorder two edges; the gap in the oracle's fp32 scores is gated one ulp wider (3) and printed.
+# rounding can reorder two edges (the KERNEL's unit rows: its sum of squares runs in another order than the CPU's,
+# so a row's norm can differ from F.normalize's by an ulp); the gap in the oracle's fp32 scores, which also holds that
+# normalisation difference, is gated one ulp wider (3) and printed.
 DEEP_OPERATOR_LOG = []
 DEEP_OPERATOR_GAPS = []
 DEEP_EXACT_GAPS = []
@@ -239,9 +245,11 @@ def model_selection_report(ours, ref, data_cpu, data_gpu, label):
             # gate (TIE_ULPS), where the end-to-end comparison above allows one more ulp per layer
             h_same = h_r.to(h_g.device).contiguous()
             _, _, _, s2, w2 = ops.aggregate_forward(g, h_same, int(k), float(cr.thr), want_selection=True)
+            un_gpu, _ = ops.normalize_rows(h_same)               # the unit rows the kernel dots
             d2 = check_selection(res, s2, w2, int(k), float(cr.thr), strict=False, h=h_r,
                                  tie_ulps=DEEP_GATE_ULPS, gaps=DEEP_OPERATOR_GAPS,
-                                 exact_gate_ulps=TIE_ULPS, exact_gaps=DEEP_EXACT_GAPS)
+                                 exact_gate_ulps=TIE_ULPS, exact_gaps=DEEP_EXACT_GAPS,
+                                 exact_unit=un_gpu.cpu().numpy())
             DEEP_OPERATOR_LOG.append((f"{label}, layer {li + 1}", d2, h_r.size(0)))
     NEAR_TIE_LOG.append((label, differ, rows))
     return differ, rows
