@@ -508,6 +508,19 @@ int sngnn_head_nll2(const float *logits, const int64_t *y, const unsigned char *
                     int64_t N, int C, int64_t n_a, int64_t n_b, float *out4, void *workspace,
                     void *stream);
 /*
+ * Replaces: SNGNN++'s last line `beta * out_0 + (1 - beta) * out_1` (models.py:134) followed by the wrapper's
+ * log_softmax and the harness' nll_loss / accuracy (models.py:86; train.py:81-84, 98-102, 112-116) in ONE pass:
+ * sngnn_head_nll / _nll2 on the blend of two tensors, which is formed in registers with sngnn_blend_forward's
+ * rounding and never stored unless logits_out is given.  sets = 1: sel != 0 marks the split's rows, metrics[2];
+ * sets = 2: bit 0 / bit 1, metrics[4].  grad_logits (sets == 1, or NULL): d (mean NLL) / d logits, zero rows
+ * outside the split - the tensor sngnn_blend_backward starts from.  C % 4 == 0, C <= 64
+ * (sngnn_head_nll_blend_supported); workspace: sngnn_head_workspace_bytes(N).
+ */
+int sngnn_head_nll_blend_supported(int C);
+int sngnn_head_nll_blend(const float *out0, const float *out1, const float *beta, const int64_t *y,
+                         const unsigned char *sel, int64_t N, int C, int sets, int64_t n_a, int64_t n_b,
+                         float *grad_logits, float *logits_out, float *metrics, void *workspace, void *stream);
+/*
  * Replaces: autograd of self.lin w.r.t. its parameters (models.py:121,237,324):
  *   grad_weight [C, F] = grad_out^T [C, N] . x [N, F],  grad_bias [C] = sum_i grad_out[i]
  * (grad_bias may be NULL).  workspace: sngnn_linear_wgrad_workspace_bytes(N, C, F).

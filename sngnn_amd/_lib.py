@@ -85,6 +85,8 @@ SIGNATURES = {
     "sngnn_head_workspace_bytes": (_i64, [_i64]),
     "sngnn_head_nll": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "sngnn_head_nll2": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "sngnn_head_nll_blend_supported": (_i32, [_i32]),
+    "sngnn_head_nll_blend": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_linear_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "sngnn_linear_forward_masked": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _f32, _vp, _vp]),
     "sngnn_epilogue_backward": (_i32, [_vp, _vp, _f32, _i64, _vp, _vp]),

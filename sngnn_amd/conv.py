@@ -73,7 +73,34 @@ def _graph_for(x: torch.Tensor, edge_index: torch.Tensor, add_loops: bool, remov
     return shard.graph, shard
 
 
-def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None, act_in=None):
+class LinFold:
+    """An affine map of the layer's INPUT channels folded into ``lin``: ``lin(x * scale + shift)`` computed as
+    ``x (W diag(scale))^T + (W shift + b)`` - how an evaluation-mode BatchNorm1d in front of a conv layer
+    (models.py:207-208: relu -> bn -> dropout -> next conv) costs no pass over [N, C] at all: its running
+    statistics are constants, so it is a per-channel scale and shift, and those belong to the next ``lin``'s
+    weights.  (Training-mode batch norm needs the batch's statistics and stays a kernel of its own.)"""
+
+    def __init__(self, scale: torch.Tensor, shift: torch.Tensor):
+        self.scale, self.shift = scale, shift
+
+    @staticmethod
+    def of_batch_norm(bn: nn.BatchNorm1d) -> "LinFold":
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = inv if bn.weight is None else bn.weight * inv
+        shift = -bn.running_mean * scale
+        if bn.bias is not None:
+            shift = shift + bn.bias
+        return LinFold(scale, shift)
+
+    def apply(self, lin: nn.Linear):
+        w = lin.weight * self.scale.unsqueeze(0)
+        b = torch.mv(lin.weight, self.shift)
+        if lin.bias is not None:
+            b = b + lin.bias
+        return w, b
+
+
+def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None, act_in=None, fold: "Optional[LinFold]" = None):
     """``h = lin(x)`` with the channel count rounded up to a multiple of 4 by zero
     weights (returns h, the true width and the rank's feature table or None).  Rows of 4k
     floats are 16-byte aligned, so the kernels read them with 16-byte lane loads (2.5x faster
@@ -84,15 +111,16 @@ def _lin_aligned(x: torch.Tensor, lin: nn.Linear, shard=None, unit=None, act_in=
     c = lin.out_features
     cp = (c + 3) // 4 * 4
     pad = None if (cp == c or c < 16 or not x.is_cuda) else cp
+    weight, bias = (lin.weight, lin.bias) if fold is None else fold.apply(lin)
     if shard is None or shard.plan is None or not x.is_cuda or x.dtype != torch.float32:
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and lin.weight.dtype == torch.float32):
-            return lin(x), c, None
+            return F.linear(x, weight, bias), c, None
         # ``unit`` (single GPU): F.normalize of h from the same launch, for the aggregation that follows
-        return ops._Linear.apply(x, lin.weight, lin.bias, pad, None, unit if shard is None else None,
+        return ops._Linear.apply(x, weight, bias, pad, None, unit if shard is None else None,
                                  act_in if shard is None else None), c, None
     table = sn_dist.new_table(shard.plan, pad or c, x)
     head = table[:shard.plan.n_local]
-    return ops._Linear.apply(x, lin.weight, lin.bias, pad, ops.OutBuffer(head), None, None), c, table
+    return ops._Linear.apply(x, weight, bias, pad, ops.OutBuffer(head), None, None), c, table
 
 
 class _FilterHint:
@@ -223,14 +251,15 @@ class SNConv(nn.Module):
         if self.bias is not None:        # PyG inits.zeros(None) is a no-op
             self.bias.data.fill_(0)
 
-    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None):
+    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None, fold=None):
         """``epilogue`` / ``act_in`` (both optional, the model wrappers' business): fuse the relu +
         dropout that follow this layer into its stores / tell ``lin`` that ``x`` is such an output
         (ops.HiddenEpilogue).  ``epilogue.applied`` says whether the layer did.  ``head`` (the LAST
-        layer): the classification head inside the aggregation's launches (ops.HeadEpilogue; ``head.applied``)."""
+        layer): the classification head inside the aggregation's launches (ops.HeadEpilogue; ``head.applied``).
+        ``fold``: a ``LinFold`` - an evaluation-mode batch norm in front of this layer, folded into ``lin``."""
         graph, shard = _graph_for(x, edge_index, True, False)
         # (no selection: the aggregation scores straight from h - no unit rows wanted from lin)
-        h, c, table = _lin_aligned(x, self.lin, shard, None, act_in)
+        h, c, table = _lin_aligned(x, self.lin, shard, None, act_in, fold)
         if _fuse_head(head, graph, h, c, shard, None):
             return ops.aggregate(h, graph, None, 0.0, None, None, self.bias, head)
         if _fuse_epilogue(epilogue, h, c, shard):
@@ -296,13 +325,13 @@ class SNConv_plus(nn.Module):
             hint = self._filt_hint = _FilterHint()
         return hint
 
-    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None):
-        """``epilogue`` / ``act_in`` / ``head``: see SNConv.forward."""
+    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None, fold=None):
+        """``epilogue`` / ``act_in`` / ``head`` / ``fold``: see SNConv.forward."""
         graph, shard = _graph_for(x, edge_index, True, bool(self.is_remove_self_loops))
         hint = self._filter_hint()
         hint.poll()
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
-        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in, fold)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
             hint.probe(h.detach(), edge_index, float(self.thr), ops.filter_wanted(graph, h.size(1), int(self.top_k), 0.0))
         if _fuse_head(head, graph, h, c, shard, int(self.top_k)):
@@ -463,11 +492,14 @@ class SNConv_plus_plus(nn.Module):
 
     _filter_hint = SNConv_plus._filter_hint
 
-    def forward(self, x, edge_index, epilogue=None, act_in=None):
-        """``epilogue`` / ``act_in``: see SNConv.forward; here the BLEND is the layer's last kernel and
-        takes the epilogue (one GPU, no conv bias - i.e. no batch norm flag, models.py:52-53)."""
+    def forward(self, x, edge_index, epilogue=None, act_in=None, head=None, fold=None):
+        """``epilogue`` / ``act_in`` / ``head`` / ``fold``: see SNConv.forward; here the BLEND is the layer's last
+        kernel and takes the epilogue or the head (one GPU, no conv bias - i.e. no batch norm flag,
+        models.py:52-53)."""
         if epilogue is not None:
             epilogue.applied = False
+        if head is not None:
+            head.applied = False
         part = sn_dist.current_partition()
         if part is None and x.size(0) != self.num_nodes:
             raise ValueError(f"built for {self.num_nodes} nodes, got {x.size(0)} "
@@ -478,7 +510,7 @@ class SNConv_plus_plus(nn.Module):
         hint = self._filter_hint()
         hint.poll()
         unit = _unit_for(self.lin, graph, self.top_k, self.thr, hint)
-        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in)
+        h, c, table = _lin_aligned(x, self.lin, shard, unit, act_in, fold)
         if shard is None and (unit.want_filter or unit.no_filter) and hint.due():
             hint.probe(h.detach(), edge_index, float(self.thr), ops.filter_wanted(graph, h.size(1), int(self.top_k), 0.0))
         if part is None:
@@ -507,6 +539,10 @@ class SNConv_plus_plus(nn.Module):
                                              row_range=(part.row_begin, part.row_end))
                 out_0 = ops.adj_linear_partition(self.w.weight, self.w.bias, graph_out)
         out_1 = _true_width(_aggregate(h, graph, shard, int(self.top_k), float(self.thr), table, unit), c)
+        if head is not None and part is None and self.bias is None:
+            fused = ops.blend_head(out_0, out_1, self.beta, head)        # the head in the blend's own pass
+            if fused is not None:
+                return fused
         if epilogue is not None and part is None and self.bias is None:
             return ops.blend(out_0, out_1, self.beta, epilogue)
         out = ops.blend(out_0, out_1, self.beta)

@@ -146,11 +146,16 @@ __global__ __launch_bounds__(256) void k_head_rows(const float *__restrict__ z, 
 // reductions inside the group (no LDS, no shuffles).  Two rows per group in flight.
 // Same per-row arithmetic up to the order of the exp sum (a fixed tree here).
 // (the per-row arithmetic: head_row.h)
+// BLEND (z1 != nullptr; round 5): the logits are SNGNN++'s blend of two tensors, z = beta z + (1 - beta) z1
+// (models.py:134 in front of :86), formed here with sngnn_blend_forward's own rounding (two products and their
+// sum, each rounded) instead of by a pass of its own; zout (optional) receives them.
 template <int G, bool TWO>
 __global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z, const int64_t *__restrict__ y,
                                                      const unsigned char *__restrict__ sel, int64_t N, int C,
                                                      float scale, float *__restrict__ grad,
-                                                     float *__restrict__ part)
+                                                     float *__restrict__ part, const float *__restrict__ z1 = nullptr,
+                                                     const float *__restrict__ beta = nullptr,
+                                                     float *__restrict__ zout = nullptr)
 {
     constexpr int RPW = 64 / G, U = 2;
     __shared__ float s_loss[4], s_corr[4], s_lossb[4], s_corrb[4];
@@ -171,6 +176,17 @@ __global__ __launch_bounds__(256) void k_head_groups(const float *__restrict__ z
             sv[u] = i < N ? sel[ic] : (unsigned char)0;
             t[u] = *reinterpret_cast<const float4 *>(z + ic * C + c0);
             yi[u] = (int)y[ic];
+        }
+        if (z1 != nullptr) {                                      // (uniform) the blend, then the head on it
+            const float b = beta[0], nb_ = 1.0f - b;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = base + u * RPW + gid;
+                const int64_t ic = i < N ? i : N - 1;
+                const float4 o1 = *reinterpret_cast<const float4 *>(z1 + ic * C + c0);
+                t[u] = make_float4(b * t[u].x + nb_ * o1.x, b * t[u].y + nb_ * o1.y, b * t[u].z + nb_ * o1.z, b * t[u].w + nb_ * o1.w);
+                if (zout != nullptr && i < N && in) *reinterpret_cast<float4 *>(zout + i * C + c0) = t[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -465,6 +481,34 @@ extern "C" int sngnn_head_nll2(const float *logits, const int64_t *y, const unsi
     else if (nb > 0)
         k_head_rows<false, true><<<nb, 256, 0, st>>>(logits, y, row_sets, N, C, 0.f, nullptr, (float *)workspace);
     k_head_reduce<<<2, 256, 0, st>>>((const float *)workspace, nb, sa, sb, 4, out4);
+    SN_HIP(hipGetLastError());
+    return SNGNN_OK;
+}
+
+extern "C" int sngnn_head_nll_blend_supported(int C) { return (C >= 4 && C <= 64 && C % 4 == 0) ? 1 : 0; }
+
+extern "C" int sngnn_head_nll_blend(const float *out0, const float *out1, const float *beta, const int64_t *y,
+                                    const unsigned char *sel, int64_t N, int C, int sets, int64_t n_a, int64_t n_b,
+                                    float *grad_logits, float *logits_out, float *metrics, void *workspace, void *stream)
+{
+    SN_REQUIRE(N >= 0 && sngnn_head_nll_blend_supported(C), SNGNN_EINVAL, "sngnn_head_nll_blend needs C % 4 == 0, C <= 64");
+    SN_REQUIRE(sets == 1 || sets == 2, SNGNN_EINVAL, "sets must be 1 or 2");
+    SN_REQUIRE(grad_logits == nullptr || sets == 1, SNGNN_EINVAL, "the gradient is one split's");
+    SN_REQUIRE(out0 && out1 && beta && y && sel && metrics && workspace, SNGNN_EINVAL, "NULL argument");
+    SN_REQUIRE(((uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)grad_logits | (uintptr_t)logits_out) % 16 == 0, SNGNN_EINVAL,
+               "rows must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)std::min<int64_t>((N + 31) / 32, HEAD_MAX_BLOCKS);
+    const float sa = 1.0f / (float)(n_a > 0 ? n_a : 1), sb = 1.0f / (float)(n_b > 0 ? n_b : 1);
+    float *part = (float *)workspace;
+    if (nb > 0 && sets == 2) {
+        if (C <= 32) k_head_groups<8, true><<<nb, 256, 0, st>>>(out0, y, sel, N, C, 0.f, nullptr, part, out1, beta, logits_out);
+        else k_head_groups<16, true><<<nb, 256, 0, st>>>(out0, y, sel, N, C, 0.f, nullptr, part, out1, beta, logits_out);
+    } else if (nb > 0) {
+        if (C <= 32) k_head_groups<8, false><<<nb, 256, 0, st>>>(out0, y, sel, N, C, sa, grad_logits, part, out1, beta, logits_out);
+        else k_head_groups<16, false><<<nb, 256, 0, st>>>(out0, y, sel, N, C, sa, grad_logits, part, out1, beta, logits_out);
+    }
+    k_head_reduce<<<sets, 256, 0, st>>>(part, nb, sa, sb, 2 * sets, metrics);
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }

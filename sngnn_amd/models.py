@@ -31,8 +31,9 @@ class _Stack(nn.Module):
     def forward_head(self, data, head):
         """:meth:`forward_logits` with the classification head (``ops.HeadEpilogue``: log_softmax, the NLL
         of a split, its accuracy count and, training, d loss / d logits) run inside the LAST layer's
-        own launches where that layer can (SNConv / SNConv_plus on one GPU, at most 64 classes in rows
-        of 16-byte vectors): ``head.applied`` says whether it did - the result is then what the head
+        own launches where that layer can (SNConv / SNConv_plus: in the aggregation's finalize launch;
+        SNConv_plus_plus: in the blend's pass - on one GPU, at most 64 classes in rows of 16-byte vectors):
+        ``head.applied`` says whether it did - the result is then what the head
         was asked to leave (the gradient, or the logits) and ``head.metrics`` are written; otherwise
         the result is the logits and the caller runs the head itself."""
         return self.forward_logits(data, head)
@@ -43,13 +44,20 @@ class _Stack(nn.Module):
         x, edge_index = data.x, data.edge_index
         if head is not None:
             head.applied = False
-        takes_head = head is not None and isinstance(self.lins[-1], (SNConv, SNConv_plus))
+        takes_head = head is not None and isinstance(self.lins[-1], (SNConv, SNConv_plus, SNConv_plus_plus))
         # relu + dropout between two conv layers as the store epilogue of the aggregation that
         # produces their operand, and backward as the store epilogue of the next ``lin``'s input
         # gradient (ops.HiddenEpilogue) - without batch norm in between, on one GPU, for the layers
         # that take it (SNConv, SNConv_plus); everything else runs the reference's op sequence
         fusable = (FUSE_HIDDEN and not self.bn and sn_dist.current_partition() is None and x.is_cuda
                    and isinstance(self.lins[0], (SNConv, SNConv_plus, SNConv_plus_plus)))
+        # EVALUATION with batch norm (models.py:207-208): the running statistics are constants, so the norm is a
+        # per-channel scale and shift - folded into the NEXT conv's ``lin`` (conv.LinFold) - and the conv's bias
+        # + relu in front of it go into the aggregation's store epilogue: no elementwise pass is left between two
+        # conv layers.  (Training-mode batch norm needs the batch's statistics: the op sequence below.)
+        if (FUSE_HIDDEN and self.bn and not self.training and sn_dist.current_partition() is None and x.is_cuda
+                and isinstance(self.lins[0], (SNConv, SNConv_plus))):
+            return self._forward_logits_bn_eval(x, edge_index, head)
         act = None
         seeds = self._dropout_seeds(x.device) if (fusable and len(self.lins) > 1 and self.training
                                                    and self.dropout.p > 0.0) else None
@@ -74,6 +82,19 @@ class _Stack(nn.Module):
         if fusable and act is not None:
             return self.lins[-1](x, edge_index, None, act)
         return self.lins[-1](x, edge_index)
+
+    def _forward_logits_bn_eval(self, x, edge_index, head):
+        from .conv import LinFold
+        fold = None
+        for i, lin in enumerate(self.lins[:-1]):
+            epi = ops.HiddenEpilogue(True, 0.0, False)                   # conv bias + relu in the stores
+            y = lin(x, edge_index, epi, None, None, fold)
+            if epi.applied:
+                x, fold = y, LinFold.of_batch_norm(self.bns[i])          # the norm rides in the next lin
+            else:                                                        # (a shape the epilogue does not take)
+                x, fold = self.bns[i](F.relu(y, inplace=True)), None
+        takes_head = head is not None and isinstance(self.lins[-1], (SNConv, SNConv_plus))
+        return self.lins[-1](x, edge_index, None, None, head if takes_head else None, fold)
 
     def forward(self, data):
         return F.log_softmax(self.forward_logits(data), dim=1)

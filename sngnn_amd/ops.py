@@ -971,6 +971,56 @@ class _Blend(torch.autograd.Function):
         return g0, g1, gbeta, None
 
 
+class _BlendHead(torch.autograd.Function):
+    """The LAST SNGNN++ layer's blend (models.py:134) with the classification head behind it
+    (``HeadEpilogue``) in one pass: the blended logits are formed in registers (the blend kernel's own
+    rounding) and go straight through log_softmax / NLL / accuracy - ``sngnn_head_nll_blend``.  The result is
+    what the head was asked to leave: d loss / d logits (training; ``G.backward(G.detach())`` is then the
+    backward of ``loss.backward()``: this node's backward is the blend's) or the logits."""
+
+    @staticmethod
+    def forward(ctx, out0, out1, beta, head):
+        lib = _lib.load()
+        n, c = out0.shape
+        out = torch.empty_like(out0)
+        ws = _workspace("head", lib.sngnn_head_workspace_bytes(n), out0.device)
+        with torch.cuda.device(out0.device):
+            rc = lib.sngnn_head_nll_blend(out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), head.y.data_ptr(),
+                                          head.sel.data_ptr(), n, c, head.sets, head.n_a, head.n_b,
+                                          out.data_ptr() if head.grad else None, None if head.grad else out.data_ptr(),
+                                          head.metrics.data_ptr(), ws.data_ptr(), _stream(out0.device))
+        _lib.check(rc, "sngnn_head_nll_blend")
+        ctx.save_for_backward(out0, out1, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out0, out1, beta = ctx.saved_tensors
+        lib = _lib.load()
+        g = g.contiguous()
+        g0, g1 = torch.empty_like(g), torch.empty_like(g)
+        gbeta = torch.empty_like(beta)
+        ws = _workspace("blend", lib.sngnn_blend_workspace_bytes(), g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.sngnn_blend_backward(g.data_ptr(), out0.data_ptr(), out1.data_ptr(), beta.data_ptr(), g.numel(),
+                                          g0.data_ptr(), g1.data_ptr(), gbeta.data_ptr(), ws.data_ptr(), _stream(g.device))
+        _lib.check(rc, "sngnn_blend_backward")
+        return g0, g1, gbeta, None
+
+
+def blend_head(out0: torch.Tensor, out1: torch.Tensor, beta: torch.Tensor, head: "HeadEpilogue") -> Optional[torch.Tensor]:
+    """The blend with the head behind it (``_BlendHead``) where the shapes allow - contiguous fp32 [N, C] rows of
+    16-byte vectors, C <= 64, labels and split flags for every row; ``head.applied`` says whether it ran
+    (None is returned when it did not: the caller blends and runs the head itself)."""
+    ok = (out0.is_cuda and out0.dtype == torch.float32 and out1.dtype == torch.float32 and out0.shape == out1.shape
+          and out0.dim() == 2 and out0.is_contiguous() and out1.is_contiguous() and beta.numel() == 1
+          and beta.dtype == torch.float32 and beta.is_cuda and head.y.numel() == out0.size(0)
+          and head.sel.numel() == out0.size(0) and head.y.device == out0.device
+          and bool(_lib.load().sngnn_head_nll_blend_supported(out0.size(1))))
+    head.applied = ok
+    return _BlendHead.apply(out0, out1, beta, head) if ok else None
+
+
 def blend(out0: torch.Tensor, out1: torch.Tensor, beta: torch.Tensor,
           epilogue: Optional["HiddenEpilogue"] = None) -> torch.Tensor:
     """SNGNN++'s ``beta * out_0 + (1 - beta) * out_1``; fused for contiguous fp32 GPU tensors of

@@ -126,7 +126,8 @@ def test_head_epilogue_argument_checks(cuda):
     ("SNGNN_Plus", (24, 16, 8, None, 1, 4, 0.0, 1, 0.5)),
     ("SNGNN_Plus", (24, 16, 8, None, 2, 2, 0.0, 1, 0.0)),
     ("SNGNN", (24, 16, 8, 1)),
-    ("SNGNN_Plus_Plus", (24, 16, 8, None, 1, 4, 0.0, 0.3, 1, 0.5)),     # blend last: falls back
+    ("SNGNN_Plus_Plus", (24, 16, 8, None, 1, 4, 0.0, 0.3, 1, 0.5)),     # blend last: the head in the blend's pass
+    ("SNGNN_Plus_Plus", (24, 16, 8, None, 2, 4, 0.0, 0.3, 1, 0.0)),
 ])
 def test_graphed_epoch_with_the_head_in_the_launches_equals_without(cuda, kind, args, monkeypatch):
     import sngnn_amd
@@ -152,3 +153,48 @@ def test_graphed_epoch_with_the_head_in_the_launches_equals_without(cuda, kind, 
     for a, b in zip(runs["1"], runs["0"]):
         for key in a:
             assert abs(a[key] - b[key]) <= 2e-5 * max(1.0, abs(b[key])), (key, a[key], b[key])
+
+
+@pytest.mark.parametrize("n,c", [(300, 8), (5000, 40), (5000, 64), (777, 4)])
+def test_blend_with_the_head_behind_it_equals_blend_then_head(cuda, n, c):
+    """ops.blend_head (sngnn_head_nll_blend): SNGNN++'s last blend (models.py:134) and the classification head in
+    one pass, against ops.blend followed by the stand-alone head: the same gradient BITS (the blend is formed with
+    the blend kernel's rounding, the per-row arithmetic is head_row.h's), metrics up to the order of the row sum;
+    its backward is the blend's backward on that gradient; the two-split evaluation form likewise."""
+    from sngnn_amd import ops
+    gen = torch.Generator().manual_seed(n + c)
+    o0 = torch.randn(n, c, generator=gen).to(cuda).requires_grad_(True)
+    o1 = torch.randn(n, c, generator=gen).to(cuda).requires_grad_(True)
+    beta = torch.tensor([0.3], device=cuda, requires_grad=True)
+    y = torch.randint(0, c, (n,), generator=gen).to(cuda)
+    r = torch.rand(n, generator=gen)
+    m_train = (r < 0.6).to(torch.uint8).to(cuda)
+    sets = (((r >= 0.6) & (r < 0.8)).to(torch.uint8) + 2 * (r >= 0.8).to(torch.uint8)).to(cuda)
+    n_tr, n_a, n_b = int(m_train.sum()), int((sets & 1).ne(0).sum()), int((sets & 2).ne(0).sum())
+    # reference: blend, then the head on the stored logits
+    z = ops.blend(o0, o1, beta)
+    (loss_ref, corr_ref), grad_ref = ops.head_nll_with_grad(z, y, m_train, n_tr)
+    z.backward(grad_ref)
+    want = [t.grad.clone() for t in (o0, o1, beta)]
+    for t in (o0, o1, beta):
+        t.grad = None
+    # fused, training form
+    met = torch.zeros(2, device=cuda)
+    head = ops.HeadEpilogue(y, m_train, met, n_tr, grad=True)
+    g = ops.blend_head(o0, o1, beta, head)
+    assert head.applied and torch.equal(g.detach(), grad_ref)
+    assert abs(float(met[0]) - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref))) and float(met[1]) == float(corr_ref)
+    g.backward(g.detach())
+    for got, w in zip((o0.grad, o1.grad, beta.grad), want):
+        assert torch.equal(got, w)
+    # fused, evaluation form: both splits' metrics, the logits as the result
+    met4 = torch.zeros(4, device=cuda)
+    head2 = ops.HeadEpilogue(y, sets, met4, n_a, n_b)
+    with torch.no_grad():
+        logits = ops.blend_head(o0, o1, beta, head2)
+        ref4 = ops.head_nll2(z.detach(), y, sets, n_a, n_b)
+    assert head2.applied and torch.equal(logits, z.detach())
+    assert float((met4 - ref4).abs().max()) <= 2e-6 * max(1.0, float(ref4.abs().max()))
+    # shapes the fused form does not take: the caller is told
+    head3 = ops.HeadEpilogue(y, m_train, met, n_tr, grad=True)
+    assert ops.blend_head(o0[:, :c - 1], o1[:, :c - 1], beta, head3) is None and not head3.applied

@@ -550,3 +550,58 @@ def test_fused_hidden_epilogue_refuses_a_second_consumer(cuda):
         loss_with_two_consumers(True)
     grads = loss_with_two_consumers(False)
     assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+
+
+@pytest.mark.parametrize("kind", ["SNGNN_Plus", "SNGNN"])
+def test_eval_mode_batch_norm_folds_into_the_next_lin(cuda, kind):
+    """models.py:207-208 in EVALUATION: BatchNorm1d on its running statistics is a per-channel scale and shift;
+    the wrappers fold it into the next conv's ``lin`` (conv.LinFold) and put the conv's bias + relu into the
+    aggregation's stores - no elementwise pass between two conv layers.  Equal to the op sequence
+    (models.FUSE_HIDDEN = False) to fp32 rounding, with running statistics and affine parameters that matter;
+    training mode keeps the op sequence (batch statistics) and is untouched."""
+    import sngnn_amd
+    from sngnn_amd import models as M
+    from sngnn_amd import synth
+    n, f = 6000, 48
+    d = synth.make_dataset("actor", with_features=False)
+    ei = d.edge_index[:, (d.edge_index[0] < n) & (d.edge_index[1] < n)].to(cuda)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, f, generator=gen).to(cuda)
+    data = sngnn_amd.Data(x=x, edge_index=ei)
+    torch.manual_seed(3)
+    if kind == "SNGNN_Plus":
+        m = sngnn_amd.SNGNN_Plus(f, 32, 7, n, 3, 4, 0.0, 1, 0.3, True).to(cuda)
+    else:
+        m = sngnn_amd.SNGNN(f, 24, 7, 3, True).to(cuda)
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.uniform_(-0.3, 0.3)
+            bn.running_var.uniform_(0.5, 2.0)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.2, 0.2)
+        for c in m.lins:
+            c.bias.uniform_(-0.1, 0.1)
+    m.eval()
+    seen = {}
+    from sngnn_amd import conv as CV
+    orig = CV.LinFold.apply
+
+    def spy(self, lin):
+        seen["folds"] = seen.get("folds", 0) + 1
+        return orig(self, lin)
+    CV.LinFold.apply = spy
+    try:
+        with torch.no_grad():
+            fused = m(data)
+            M.FUSE_HIDDEN = False
+            plain = m(data)
+    finally:
+        M.FUSE_HIDDEN = True
+        CV.LinFold.apply = orig
+    assert seen.get("folds", 0) == 2                                   # both hidden layers' norms were folded
+    assert float((fused - plain).abs().max()) <= 2e-5 * max(1.0, float(plain.abs().max()))
+    # the running statistics are untouched by an evaluation forward, and training still normalises by the batch
+    m.train()
+    rm = m.bns[0].running_mean.clone()
+    out = m(data)
+    assert not torch.equal(rm, m.bns[0].running_mean) and bool(torch.isfinite(out).all())

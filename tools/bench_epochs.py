@@ -20,7 +20,7 @@ y = torch.randint(0, c, (n,), generator=gen).to(dev)
 r = torch.rand(n, generator=gen)
 data = Data(x=x, edge_index=ei, y=y, train_mask=(r < 0.6).to(dev), val_mask=((r >= 0.6) & (r < 0.8)).to(dev),
             test_mask=(r >= 0.8).to(dev))
-only = sys.argv[1] if len(sys.argv) > 1 else None
+only = sys.argv[1].split(",") if len(sys.argv) > 1 else None          # e.g. plus_2layer_h32_bn,plusplus_1layer
 MODELS = {
     "plus_1layer": lambda: sngnn_amd.SNGNN_Plus(128, 32, c, n, 1, 16, 0.0, 1, 0.5),
     "plus_2layer_h32": lambda: sngnn_amd.SNGNN_Plus(128, 32, c, n, 2, 16, 0.0, 1, 0.5),
@@ -32,12 +32,14 @@ MODELS = {
     "plus_2layer_h64_k1_thr0.99": lambda: sngnn_amd.SNGNN_Plus(128, 64, c, n, 2, 1, 0.99, 1, 0.5),
     "plusplus_2layer_h64_k1_thr0.99": lambda: sngnn_amd.SNGNN_Plus_Plus(128, 64, c, n, 2, 1, 0.99, 0.5, 1, 0.5),
     "plusplus_1layer": lambda: sngnn_amd.SNGNN_Plus_Plus(128, 32, c, n, 1, 16, 0.0, 0.3, 1, 0.5),
+    "plusplus_2layer_h32": lambda: sngnn_amd.SNGNN_Plus_Plus(128, 32, c, n, 2, 16, 0.0, 0.3, 1, 0.5),
+    "sngnn_2layer_h32_bn": lambda: sngnn_amd.SNGNN(128, 32, c, 2, True),
     "sngnn_1layer": lambda: sngnn_amd.SNGNN(128, 32, c, 1),
     "agnn_1layer": lambda: sngnn_amd.AGNN(128, 32, c, 1),
     "agnn_2layer_h32": lambda: sngnn_amd.AGNN(128, 32, c, 2),
 }
 for name, make in MODELS.items():
-    if only and name != only:
+    if only and name not in only:
         continue
     torch.manual_seed(0)
     model = make().to(dev)
