@@ -26,6 +26,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int KN_M = 128, KN_K = 32, KN_LD = KN_K + 4, KN_LOADS = KN_M * KN_K / 256;   // (stride 36: 16-byte rows, conflict-free b128 reads)
 typedef float knn_f4 __attribute__((ext_vector_type(4)));
 constexpr int KNN_MAX_K = 32;
+#if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 4            // measurement build: event counters of the selection
+__device__ unsigned long long g_knn_dbg[8];
+#define SN_KNN_COUNT(i, v) do { if (lane_id() == 0) atomicAdd(&g_knn_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define SN_KNN_COUNT(i, v) do { } while (0)
+#endif
 
 // k-th largest of the (unique, non-zero) keys held two per lane; at least k keys are set
 __device__ __forceinline__ unsigned long long kth_largest(unsigned long long key0, unsigned long long key1, int k)
@@ -39,8 +45,25 @@ __device__ __forceinline__ unsigned long long kth_largest(unsigned long long key
     return T;
 }
 
+// smallest of the wave's 64-bit values (all lanes get it)
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
 // Merge the row's list (k slots, 0 = empty) with cnt candidates (cnt + k <= 128); returns
 // the row's new threshold key (k-th largest, or 0 while the list is not full).
+// Round 5: the k largest by the aggregation's early-exit search (wave_topk_keys_n: it walks the cosine word
+// and stops at the first prefix that separates exactly k keys - ~15 ballot steps for unrelated cosines) instead
+// of a 64-step search for the k-th key; the threshold is then the smallest kept key.  A scan at arxiv size
+// makes 1.65 M merges (9.7 per row), and a merge in one wave holds the workgroup's other three at the step's
+// barrier.
 __device__ __forceinline__ unsigned long long merge_row(unsigned long long *list, const unsigned long long *cand,
                                                         int cnt, int k)
 {
@@ -49,16 +72,17 @@ __device__ __forceinline__ unsigned long long merge_row(unsigned long long *list
     auto pick = [&](int q) -> unsigned long long {
         return q < k ? list[q] : (q - k < cnt ? cand[q - k] : 0ull);
     };
-    const unsigned long long key0 = pick(q0), key1 = pick(q1);
-    const int total = __popcll(__ballot(key0 != 0ull)) + __popcll(__ballot(key1 != 0ull));
-    unsigned long long T = 0ull;
-    if (total >= k) T = kth_largest(key0, key1, k);
-    const bool k0 = key0 != 0ull && key0 >= T, k1 = key1 != 0ull && key1 >= T;
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    const unsigned long long key[2] = {pick(q0), pick(q1)};
+    const int total = __popcll(__ballot(key[0] != 0ull)) + __popcll(__ballot(key[1] != 0ull));
+    bool kept[2];
+    wave_topk_keys_n<2>(key, k, 31, kept);               // (low word = ~node id: 31 bits can differ)
+    const unsigned long long m0 = __ballot(kept[0]), m1 = __ballot(kept[1]);
     const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+    unsigned long long T = 0ull;
+    if (total >= k) T = wave_min_u64(min(kept[0] ? key[0] : ~0ull, kept[1] ? key[1] : ~0ull));
     wave_lds_sync();                       // every lane has read the old list
-    if (k0) list[prefix_popc(m0)] = key0;
-    if (k1) list[n0 + prefix_popc(m1)] = key1;
+    if (kept[0]) list[prefix_popc(m0)] = key[0];
+    if (kept[1]) list[n0 + prefix_popc(m1)] = key[1];
     if (lane >= ns && lane < k) list[lane] = 0ull;
     wave_lds_sync();
     return T;
@@ -91,6 +115,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
     __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
     __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
     __shared__ float s_ts[4][32];                               // the fast reject's threshold on acc * icol (see the selection)
+    __shared__ float s_irow[4][32];                             // the rows' inverse norms (a hot register reads LDS, not memory)
     __shared__ int s_pend[4][32];                               // candidates parked in list[k .. KNN_MAX_K)
     __shared__ unsigned long long s_cand[4][2][128];            // candidates of the two rows of a register
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,6 +125,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
     if (lane < 32) {
         s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; s_pend[wave][lane] = 0;
         s_ts[wave][lane] = (row0 + wave * 32 + lane < N) ? -INFINITY : INFINITY;      // (rows beyond N: never a candidate)
+        s_irow[wave][lane] = (row0 + wave * 32 + lane < N) ? inv[row0 + wave * 32 + lane] : 0.f;
     }
     const int cap = KNN_MAX_K - k;                               // spare slots behind a row's list
     const int sc = tid & 31, sr = tid >> 5;
@@ -326,13 +352,31 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             for (int b = 0; b < 4; ++b) m_ |= acc[b][r] * icol[b] >= tsr[r];
             if (__ballot(m_) != 0ull) hot16 |= 1u << r;
         }
-        if (hot16 != 0u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (!((hot16 >> r) & 1u)) continue;                          // (wave-uniform)
+        SN_KNN_COUNT(0, 1);                                             // tiles x waves
+        SN_KNN_COUNT(1, __popc(hot16));                                 // registers that pass the superset test
+        // ONE copy of the hot path's code, looped over the set bits: unrolled per register it was sixteen copies of
+        // ~700 instructions each (the merges inlined) - far more than the instruction cache holds, and the ~2 hot
+        // registers of a tile jump to different copies every time.  Only the four accumulator values are fetched
+        // per register (a switch of sixteen four-move cases: accumulator indices must be literals).
+        unsigned hm_ = hot16;
+#if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 5        // timing experiment: the fast test of every register, no hot path
+        asm volatile("" ::"s"(hm_));
+        hm_ = 0u;
+#endif
+        while (hm_ != 0u) {
+            const int r = __builtin_ctz(hm_);                            // (wave-uniform)
+            hm_ &= hm_ - 1u;
+            float ar[4];
+            switch (r) {
+#define SN_KNN_PICK(R) case R: ar[0] = acc[0][R]; ar[1] = acc[1][R]; ar[2] = acc[2][R]; ar[3] = acc[3][R]; break;
+            SN_KNN_PICK(0) SN_KNN_PICK(1) SN_KNN_PICK(2) SN_KNN_PICK(3) SN_KNN_PICK(4) SN_KNN_PICK(5) SN_KNN_PICK(6) SN_KNN_PICK(7)
+            SN_KNN_PICK(8) SN_KNN_PICK(9) SN_KNN_PICK(10) SN_KNN_PICK(11) SN_KNN_PICK(12) SN_KNN_PICK(13) SN_KNN_PICK(14)
+            default: ar[0] = acc[0][15]; ar[1] = acc[1][15]; ar[2] = acc[2][15]; ar[3] = acc[3][15]; break;
+#undef SN_KNN_PICK
+            }
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;          // this lane's row within the wave's 32
             const int64_t i = row0 + wave * 32 + lr;
-            const float irow = i < N ? inv[i] : 0.f;
+            const float irow = s_irow[wave][lr];
             // fast reject on the cosine alone: nothing of this register reaches its row's
             // k-th value - the common case once the lists have warmed up
             const float thrf = s_thrf[wave][lr];
@@ -340,7 +384,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             bool maybe = false;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                sv[b] = acc[b][r] * (irow * icol[b]) + 0.0f;
+                sv[b] = ar[b] * (irow * icol[b]) + 0.0f;
                 maybe |= sv[b] >= thrf;
             }
             if (__ballot(maybe) == 0ull) continue;
@@ -356,6 +400,29 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             }
             const unsigned long long hot = __ballot(any);
             if (hot == 0ull) continue;
+            SN_KNN_COUNT(2, 1);                                         // registers with a real candidate
+            // The common hot register after warm-up holds ONE candidate in the whole wave: its lane parks it behind
+            // its row's list by itself - no ballots, no compaction through LDS, no per-half hand-off (a full
+            // spare area falls through to the general path below, which merges).
+            if (__popcll(hot) == 1) {
+                const int nk_ = (key[0] != 0ull) + (key[1] != 0ull) + (key[2] != 0ull) + (key[3] != 0ull);
+                if (__builtin_amdgcn_readlane(nk_, __ffsll((long long)hot) - 1) == 1) {
+                    bool parked = false;
+                    if (any) {
+                        const int pc_ = s_pend[wave][lr];
+                        if (pc_ < cap) {
+                            s_list[wave][lr][k + pc_] = key[0] | key[1] | key[2] | key[3];
+                            s_pend[wave][lr] = pc_ + 1;
+                            parked = true;
+                        }
+                    }
+                    if (__ballot(parked) != 0ull) {
+                        SN_KNN_COUNT(3, 1);                             // ... parked by their one lane
+                        wave_lds_sync();
+                        continue;
+                    }
+                }
+            }
             // compact the candidates of the two rows (one per half-wave) into LDS
             int cnt = 0;                                                 // per half
 #pragma unroll
@@ -396,6 +463,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                 if (lane < pc) cand[c + lane] = list[k + lane];        // the parked ones join
                 wave_lds_sync();
                 const unsigned long long T = merge_row(list, cand, c + pc, k);
+                SN_KNN_COUNT(4, 1);                                     // merges
                 if (lane == 0) {
                     s_pend[wave][rowh] = 0;
                     s_thr[wave][rowh] = T;
@@ -403,7 +471,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     const float tf = T ? __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u) : -INFINITY;
                     s_thrf[wave][rowh] = tf;
                     // (rows beyond N never get here: their lists take no key)
-                    const float tq = tf / inv[min(row0 + wave * 32 + rowh, N - 1)];
+                    const float tq = tf / s_irow[wave][rowh];
                     s_ts[wave][rowh] = tq - (fabsf(tq) * 1e-6f + 1e-30f);
                 }
             }
@@ -684,3 +752,13 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     SN_HIP(hipGetLastError());
     return SNGNN_OK;
 }
+
+#if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 4
+extern "C" int sngnn_knn_debug_counters(unsigned long long *out8, int reset)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (out8) SN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(sngnn::g_knn_dbg), sizeof(z)));
+    if (reset) SN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sngnn::g_knn_dbg), z, sizeof(z)));
+    return SNGNN_OK;
+}
+#endif
