@@ -102,25 +102,33 @@ __device__ __forceinline__ unsigned long long merge_row(unsigned long long *list
 // bf16 planes, rows of 64 + 16 bytes); a step of 16 k-slots per half is 2 x 8
 // `v_mfma_f32_32x32x16_bf16` per column block instead of 16 fp32 MFMAs.
 constexpr int KN_PS = 80;                      // bytes per row of a bf16 plane of the column panel
-template <int FH, bool BF3>
-__global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, int64_t N, int64_t F,
+// NWV waves per workgroup (32 rows each), CB column blocks of 32 per tile.  <4, 4>: 128 x 128 tiles, one wave per
+// SIMD (64 accumulator registers).  <8, 2> (round 5, F = 128): 256 rows x 64-column tiles - 32 accumulator registers,
+// the kernel fits the 256-register budget of TWO waves per SIMD, so one wave's selection, staging and barrier waits
+// run under the other's products (at one wave per SIMD nothing overlapped them: products ~24-35 ms, everything else
+// ~45 of the 76 ms at arxiv size).
+template <int FH, bool BF3, int NWV = 4, int CB = 4>
+__global__ __launch_bounds__(64 * NWV) void k_knn_mfma(const float *__restrict__ x, int64_t N, int64_t F,
                                                   const float *__restrict__ inv, int k, int exclude_self,
                                                   int tiles_per_split, unsigned long long *__restrict__ part,
                                                   int32_t *__restrict__ out_idx, float *__restrict__ out_sim)
 {
     static_assert(!BF3 || FH > 0, "the bf16 form is the register-operand path's");
+    static_assert((NWV == 4 && CB == 4) || (BF3 && FH > 0), "other tile shapes: the bf16 register-operand path only");
+    static_assert((4 * CB) % NWV == 0 && 4 * CB / NWV >= 1 && 4 * CB / NWV <= 4, "staging: 1..4 vectors per thread and step");
+    constexpr int KR = 32 * NWV, KC = 32 * CB;                  // rows per workgroup, columns per tile
     __shared__ float sA[FH > 0 ? 1 : KN_M * KN_LD];
-    __shared__ __align__(16) float sB[(FH > 0 ? 2 : 1) * (BF3 ? 3 * KN_M * KN_PS / 4 : KN_M * KN_LD)];   // FH > 0: two buffers
-    __shared__ unsigned long long s_list[4][32][KNN_MAX_K];     // running top-k keys per row
-    __shared__ unsigned long long s_thr[4][32];                 // k-th key per row (0: list not full)
-    __shared__ float s_thrf[4][32];                             // its cosine (-inf: list not full)
-    __shared__ float s_ts[4][32];                               // the fast reject's threshold on acc * icol (see the selection)
-    __shared__ float s_irow[4][32];                             // the rows' inverse norms (a hot register reads LDS, not memory)
-    __shared__ int s_pend[4][32];                               // candidates parked in list[k .. KNN_MAX_K)
-    __shared__ unsigned long long s_cand[4][2][128];            // candidates of the two rows of a register
+    __shared__ __align__(16) float sB[(FH > 0 ? 2 : 1) * (BF3 ? 3 * KC * KN_PS / 4 : KC * KN_LD)];   // FH > 0: two buffers
+    __shared__ unsigned long long s_list[NWV][32][KNN_MAX_K];   // running top-k keys per row
+    __shared__ unsigned long long s_thr[NWV][32];               // k-th key per row (0: list not full)
+    __shared__ float s_thrf[NWV][32];                           // its cosine (-inf: list not full)
+    __shared__ float s_ts[NWV][32];                             // the fast reject's threshold on acc * icol (see the selection)
+    __shared__ float s_irow[NWV][32];                           // the rows' inverse norms (a hot register reads LDS, not memory)
+    __shared__ int s_pend[NWV][32];                             // candidates parked in list[k .. KNN_MAX_K)
+    __shared__ unsigned long long s_cand[NWV][2][128];          // candidates of the two rows of a register
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
-    const int64_t row0 = (int64_t)blockIdx.x * KN_M;
+    const int64_t row0 = (int64_t)blockIdx.x * KR;
     for (int q = lane; q < 32 * KNN_MAX_K; q += 64) s_list[wave][q / KNN_MAX_K][q % KNN_MAX_K] = 0ull;
     if (lane < 32) {
         s_thr[wave][lane] = 0ull; s_thrf[wave][lane] = -INFINITY; s_pend[wave][lane] = 0;
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
     }
     const int cap = KNN_MAX_K - k;                               // spare slots behind a row's list
     const int sc = tid & 31, sr = tid >> 5;
-    const int64_t ncol_tiles = (N + KN_M - 1) / KN_M;
+    const int64_t ncol_tiles = (N + KC - 1) / KC;
     const int64_t ct_begin = (int64_t)blockIdx.y * tiles_per_split;
     const int64_t ct_end = min(ncol_tiles, ct_begin + tiles_per_split);
 
@@ -156,22 +164,22 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
 
     knn_f4 rb0 = {0.f, 0.f, 0.f, 0.f}, rb1 = rb0, rb2 = rb0, rb3 = rb0;      // the column panel in flight (FH > 0)
     for (int64_t ct = ct_begin; ct < ct_end; ++ct) {
-        const int64_t col0 = ct * KN_M;
-        f32x16 acc[4];
+        const int64_t col0 = ct * KC;
+        f32x16 acc[CB];
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         // the tile's column ids and inverse norms (for the selection): requested here, they travel under the products
-        float icol[4];
-        int64_t jcol[4];
+        float icol[CB];
+        int64_t jcol[CB];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < CB; ++b) {
             jcol[b] = col0 + b * 32 + l32;
             icol[b] = inv[min(jcol[b], N - 1)];
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) icol[b] = jcol[b] < N ? icol[b] : 0.f;
+        for (int b = 0; b < CB; ++b) icol[b] = jcol[b] < N ? icol[b] : 0.f;
         if constexpr (FH > 0) {
             // k-step = 16 steps of each half: columns [s0, s0 + 16) and [FH + s0, FH + s0 + 16) of
             // the column block's rows, as 16-byte vectors: thread t owns vector (t & 7) - four
@@ -194,14 +202,15 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             const int pr = (slot & ~7) | ((slot & 7) >> 1) | ((slot & 1) << 2);
             const int kseg = seg < 4 ? 4 * seg : FH + 4 * (seg - 4);
             constexpr int NS = FH / 16;                                   // steps per tile
-            constexpr int PANEL = BF3 ? 3 * KN_M * KN_PS : KN_M * KN_LD * 4;   // bytes of one buffer
+            constexpr int PANEL = BF3 ? 3 * KC * KN_PS : KC * KN_LD * 4;     // bytes of one buffer
+            constexpr int SROWS = 8 * NWV, UV = KC / SROWS;               // rows staged per vector slot, vectors per thread
 #define SN_KNN_FETCH(COL0, S0)                                                                            \
             {                                                                                             \
                 const float *g_ = x + (S0) + kseg;                                                        \
                 rb0 = *(const knn_f4 *)(g_ + min((COL0) + pr, N - 1) * F);                                \
-                rb1 = *(const knn_f4 *)(g_ + min((COL0) + pr + 32, N - 1) * F);                           \
-                rb2 = *(const knn_f4 *)(g_ + min((COL0) + pr + 64, N - 1) * F);                           \
-                rb3 = *(const knn_f4 *)(g_ + min((COL0) + pr + 96, N - 1) * F);                           \
+                if constexpr (UV > 1) rb1 = *(const knn_f4 *)(g_ + min((COL0) + pr + SROWS, N - 1) * F);  \
+                if constexpr (UV > 2) rb2 = *(const knn_f4 *)(g_ + min((COL0) + pr + 2 * SROWS, N - 1) * F); \
+                if constexpr (UV > 3) rb3 = *(const knn_f4 *)(g_ + min((COL0) + pr + 3 * SROWS, N - 1) * F); \
             }
             unsigned char *sBb = reinterpret_cast<unsigned char *>(sB);
             // BF3: plane p of column row r at byte (p * KN_M + r) * KN_PS; its 32 k-slots are the
@@ -210,28 +219,31 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                 if constexpr (!BF3) {
                     float *wb = reinterpret_cast<float *>(sBb + boff) + pr * KN_LD + 4 * seg;
                     *(knn_f4 *)(wb) = rb0;
-                    *(knn_f4 *)(wb + 32 * KN_LD) = rb1;
-                    *(knn_f4 *)(wb + 64 * KN_LD) = rb2;
-                    *(knn_f4 *)(wb + 96 * KN_LD) = rb3;
+                    if constexpr (UV > 1) *(knn_f4 *)(wb + SROWS * KN_LD) = rb1;
+                    if constexpr (UV > 2) *(knn_f4 *)(wb + 2 * SROWS * KN_LD) = rb2;
+                    if constexpr (UV > 3) *(knn_f4 *)(wb + 3 * SROWS * KN_LD) = rb3;
                 } else {
                     unsigned char *wb3 = sBb + boff + pr * KN_PS + 8 * seg;
                     auto put = [&](int u, const knn_f4 &v) {
                         const float vv[4] = {v[0], v[1], v[2], v[3]};
                         sn_u32x2 p1, p2, p3;
                         split_bf16x4(vv, p1, p2, p3);
-                        unsigned char *d_ = wb3 + 32 * u * KN_PS;
+                        unsigned char *d_ = wb3 + SROWS * u * KN_PS;
                         *(sn_u32x2 *)(d_) = p1;
-                        *(sn_u32x2 *)(d_ + KN_M * KN_PS) = p2;
-                        *(sn_u32x2 *)(d_ + 2 * KN_M * KN_PS) = p3;
+                        *(sn_u32x2 *)(d_ + KC * KN_PS) = p2;
+                        *(sn_u32x2 *)(d_ + 2 * KC * KN_PS) = p3;
                     };
-                    put(0, rb0); put(1, rb1); put(2, rb2); put(3, rb3);
+                    put(0, rb0);
+                    if constexpr (UV > 1) put(1, rb1);
+                    if constexpr (UV > 2) put(2, rb2);
+                    if constexpr (UV > 3) put(3, rb3);
                 }
             };
             // linear step L = (ct - ct_begin) NS + s0 / 16 lives in buffer L & 1
             auto fetch_step = [&](int64_t L) {
                 const int64_t t_ = ct_begin + L / NS;
                 const int st_ = (int)(L % NS) * 16;
-                if (t_ < ct_end) SN_KNN_FETCH(t_ * KN_M, st_)
+                if (t_ < ct_end) SN_KNN_FETCH(t_ * KC, st_)
             };
             if (ct == ct_begin) {
                 fetch_step(0);
@@ -253,11 +265,11 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
                     for (int g = 0; g < 2; ++g) {          // 8 k-slots of each half per MFMA
                         const int aq = s0 / 8 + g;
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
+                        for (int b = 0; b < CB; ++b) {
                             const unsigned char *r_ = pb3 + 32 * b * KN_PS + 16 * g;
                             const sn_u32x4 b1 = *(const sn_u32x4 *)(r_);
-                            const sn_u32x4 b2 = *(const sn_u32x4 *)(r_ + KN_M * KN_PS);
-                            const sn_u32x4 b3 = *(const sn_u32x4 *)(r_ + 2 * KN_M * KN_PS);
+                            const sn_u32x4 b2 = *(const sn_u32x4 *)(r_ + KC * KN_PS);
+                            const sn_u32x4 b3 = *(const sn_u32x4 *)(r_ + 2 * KC * KN_PS);
 #if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 2        // timing experiment: one product of eight
 #define SN_KNN_M3(PA, PB) asm volatile("" ::"v"(PA), "v"(PB));
                             acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sn_bf16x8, ap1[aq]),
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         }   // FH == 0
 #if defined(SNGNN_KNN_EXP) && SNGNN_KNN_EXP == 1        // timing experiment: no selection at all
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < CB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[b][r]));
         continue;
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         for (int r = 0; r < 16; ++r) {
             bool m_ = false;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) m_ |= acc[b][r] * icol[b] >= tsr[r];
+            for (int b = 0; b < CB; ++b) m_ |= acc[b][r] * icol[b] >= tsr[r];
             if (__ballot(m_) != 0ull) hot16 |= 1u << r;
         }
         SN_KNN_COUNT(0, 1);                                             // tiles x waves
@@ -366,12 +378,12 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
         while (hm_ != 0u) {
             const int r = __builtin_ctz(hm_);                            // (wave-uniform)
             hm_ &= hm_ - 1u;
-            float ar[4];
+            float ar[CB];
             switch (r) {
-#define SN_KNN_PICK(R) case R: ar[0] = acc[0][R]; ar[1] = acc[1][R]; ar[2] = acc[2][R]; ar[3] = acc[3][R]; break;
+#define SN_KNN_PICK(R) case R: _Pragma("unroll") for (int b_ = 0; b_ < CB; ++b_) ar[b_] = acc[b_][R]; break;
             SN_KNN_PICK(0) SN_KNN_PICK(1) SN_KNN_PICK(2) SN_KNN_PICK(3) SN_KNN_PICK(4) SN_KNN_PICK(5) SN_KNN_PICK(6) SN_KNN_PICK(7)
             SN_KNN_PICK(8) SN_KNN_PICK(9) SN_KNN_PICK(10) SN_KNN_PICK(11) SN_KNN_PICK(12) SN_KNN_PICK(13) SN_KNN_PICK(14)
-            default: ar[0] = acc[0][15]; ar[1] = acc[1][15]; ar[2] = acc[2][15]; ar[3] = acc[3][15]; break;
+            default: _Pragma("unroll") for (int b_ = 0; b_ < CB; ++b_) ar[b_] = acc[b_][15]; break;
 #undef SN_KNN_PICK
             }
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * half;          // this lane's row within the wave's 32
@@ -380,19 +392,19 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             // fast reject on the cosine alone: nothing of this register reaches its row's
             // k-th value - the common case once the lists have warmed up
             const float thrf = s_thrf[wave][lr];
-            float sv[4];
+            float sv[CB];
             bool maybe = false;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < CB; ++b) {
                 sv[b] = ar[b] * (irow * icol[b]) + 0.0f;
                 maybe |= sv[b] >= thrf;
             }
             if (__ballot(maybe) == 0ull) continue;
             const unsigned long long thr = s_thr[wave][lr];
-            unsigned long long key[4];
+            unsigned long long key[CB];
             bool any = false;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < CB; ++b) {
                 const bool ok = i < N && jcol[b] < N && !(exclude_self && jcol[b] == i);
                 key[b] = ok ? sel_key(sv[b], (unsigned)jcol[b]) : 0ull;
                 if (key[b] <= thr) key[b] = 0ull;                        // cannot enter the list
@@ -405,13 +417,16 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             // its row's list by itself - no ballots, no compaction through LDS, no per-half hand-off (a full
             // spare area falls through to the general path below, which merges).
             if (__popcll(hot) == 1) {
-                const int nk_ = (key[0] != 0ull) + (key[1] != 0ull) + (key[2] != 0ull) + (key[3] != 0ull);
+                int nk_ = 0;
+                unsigned long long kor_ = 0ull;
+#pragma unroll
+                for (int b = 0; b < CB; ++b) { nk_ += key[b] != 0ull; kor_ |= key[b]; }
                 if (__builtin_amdgcn_readlane(nk_, __ffsll((long long)hot) - 1) == 1) {
                     bool parked = false;
                     if (any) {
                         const int pc_ = s_pend[wave][lr];
                         if (pc_ < cap) {
-                            s_list[wave][lr][k + pc_] = key[0] | key[1] | key[2] | key[3];
+                            s_list[wave][lr][k + pc_] = kor_;
                             s_pend[wave][lr] = pc_ + 1;
                             parked = true;
                         }
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(256) void k_knn_mfma(const float *__restrict__ x, i
             // compact the candidates of the two rows (one per half-wave) into LDS
             int cnt = 0;                                                 // per half
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < CB; ++b) {
                 const unsigned long long m = __ballot(key[b] != 0ull);
                 const unsigned mh = half ? (unsigned)(m >> 32) : (unsigned)m;
                 if (key[b] != 0ull) s_cand[wave][half][cnt + __popc(mh & ((1u << l32) - 1u))] = key[b];
@@ -682,20 +697,35 @@ __global__ __launch_bounds__(256) void k_knn_inv_norm(const float *__restrict__ 
 using namespace sngnn;
 
 // 0 = by shape (default), 1 = the fused scan always, 2 = materialise + select always (measurement: sngnn_tuning_set(6, v))
-static int g_knn_route = 0;
-namespace sngnn { int set_knn_route(int v) { if (v < 0 || v > 2) return SNGNN_EINVAL; g_knn_route = v; return SNGNN_OK; } }
+// (value 3 / 4 - measurement: the fused scan with the 128 x 128 / the 256 x 64 tile shape whatever the width allows)
+static int g_knn_route = 0, g_knn_shape = 0;
+namespace sngnn {
+int set_knn_route(int v)
+{
+    if (v < 0 || v > 4) return SNGNN_EINVAL;
+    g_knn_shape = v == 3 ? 1 : 0;            // 1: never the <8, 2> shape
+    g_knn_route = v >= 3 ? 1 : v;
+    return SNGNN_OK;
+}
+}
 
 // column splits: enough workgroups to fill the chip when there are few row blocks
-static int knn_splits(int64_t N)
+// (F in {32, 64, 96, 128} with 16-byte rows, bf16 products: the <8, 2> shape - 256 rows per workgroup, 64-column tiles,
+// two waves per SIMD: 76 -> 58 ms at arxiv size)
+static bool knn_wide(int64_t F, const float *x)
 {
-    const int64_t nrb = (N + KN_M - 1) / KN_M;
+    return (F == 128 || F == 96 || F == 64 || F == 32) && (uintptr_t)x % 16 == 0 && !sngnn::fp32_mfma_only() && g_knn_shape != 1;
+}
+static int knn_splits(int64_t N, int rows_per_wg = KN_M)
+{
+    const int64_t nrb = (N + rows_per_wg - 1) / rows_per_wg;
     // (every split warms its lists up from empty: only as many as it takes to occupy the CUs)
     return (int)std::max<int64_t>(1, std::min<int64_t>(nrb, (320 + nrb - 1) / nrb));
 }
 
 extern "C" int64_t sngnn_knn_workspace_bytes(int64_t N, int k)
 {
-    const int ns = knn_splits(N);
+    const int ns = std::max(knn_splits(N), knn_splits(N, 256));       // (either tile shape)
     return (N + 63) / 64 * 256 + (ns > 1 ? (int64_t)ns * N * k * 8 : 0) + 256;
 }
 
@@ -734,16 +764,22 @@ extern "C" int sngnn_knn_graph(const float *x, int64_t N, int64_t F, int k, int 
     }
     float *inv = (float *)workspace;
     unsigned long long *part = (unsigned long long *)((char *)workspace + (N + 63) / 64 * 256);
-    const int ns = knn_splits(N);
-    const int64_t nrb = (N + KN_M - 1) / KN_M;
-    const int tps = (int)((nrb + ns - 1) / ns);
-    const int ns_used = (int)((nrb + tps - 1) / tps);
+    const bool wide = knn_wide(F, x);
+    const int rows_wg = wide ? 256 : KN_M, cols_tile = wide ? 64 : KN_M;
+    const int ns = knn_splits(N, rows_wg);
+    const int64_t nrb = (N + rows_wg - 1) / rows_wg, nct = (N + cols_tile - 1) / cols_tile;
+    const int tps = (int)((nct + ns - 1) / ns);          // column tiles per split
+    const int ns_used = (int)((nct + tps - 1) / tps);
     k_knn_inv_norm<<<(unsigned)((N + 3) / 4), 256, 0, st>>>(x, N, F, inv);
     dim3 grid((unsigned)nrb, (unsigned)ns_used);
     unsigned long long *pp = ns_used > 1 ? part : nullptr;
     const bool areg = (uintptr_t)x % 16 == 0;
     const bool bf3 = !sngnn::fp32_mfma_only();          // sngnn_tuning_set(5, 1): fp32 MFMAs
-    if (areg && F == 128) { if (bf3) k_knn_mfma<64, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<64, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
+    if (wide && F == 128) k_knn_mfma<64, true, 8, 2><<<grid, 512, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (wide && F == 96) k_knn_mfma<48, true, 8, 2><<<grid, 512, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (wide && F == 64) k_knn_mfma<32, true, 8, 2><<<grid, 512, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (wide) k_knn_mfma<16, true, 8, 2><<<grid, 512, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim);
+    else if (areg && F == 128) { if (bf3) k_knn_mfma<64, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<64, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
     else if (areg && F == 96) { if (bf3) k_knn_mfma<48, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<48, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
     else if (areg && F == 64) { if (bf3) k_knn_mfma<32, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<32, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
     else if (areg && F == 32) { if (bf3) k_knn_mfma<16, true><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); else k_knn_mfma<16, false><<<grid, 256, 0, st>>>(x, N, F, inv, k, exclude_self, tps, pp, nbr_idx, nbr_sim); }
