@@ -24,24 +24,37 @@ pytestmark = pytest.mark.gpu
 
 
 def _check(cuda, kind, args, data, label, train_modes=(False,), lin_is_blas=None):
+    from tests import helpers
     ours, ref = build_pair(kind, args)
     ours = ours.to(cuda)
     d = data.to(cuda)
+    worst_out = 0.0
     for train in train_modes:
         ours.train(train), ref.train(train)
         out_ref = ref(data)
         out = ours(d)
         assert out.shape == out_ref.shape
-        assert_close(out, out_ref, what=f"{label} log-probs", rtol=1e-4, atol=2e-5)
+        # the north star's own gate (1e-5 rtol, + the 2e-6 absolute floor of tests/helpers.py) at MODEL level too -
+        # although the two sides' ``lin`` ran on different devices and a near-tie flip moves whole rows: measured at
+        # most 0.54x of it over configs 1-4 at full size (round 5; the gate was 1e-4 / 2e-5 before)
+        assert_close(out, out_ref, what=f"{label} log-probs", rtol=1e-5, atol=2e-6)
+        worst_out = max(worst_out, float(((out.detach().cpu() - out_ref.detach()).abs() /
+                                          (2e-6 + 1e-5 * out_ref.detach().abs())).max()))
     ours.zero_grad(), ref.zero_grad()
     F.nll_loss(ref(data)[data.train_mask], data.y[data.train_mask]).backward()
     F.nll_loss(ours(d)[d.train_mask], d.y[d.train_mask]).backward()
+    worst_g = 0.0
     for (name, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
         assert p.grad is not None, name
         gq = q.grad.to_dense() if q.grad.is_sparse else q.grad
         scale = gq.abs().max().clamp_min(1e-12)
         err = (p.grad.cpu() - gq).abs().max()
-        assert err <= 2e-4 * scale + 1e-7, f"{label}.{name}: err {err.item():.3e} scale {scale.item():.3e}"
+        # (2e-5 of the gradient's max-norm - measured 2.5e-7 .. 8.2e-6 - plus an absolute floor for the parameters
+        # whose whole gradient is ~1e-4: there a second layer's near-tie flips, counted above, are the error)
+        assert err <= 2e-5 * scale + 2e-7, f"{label}.{name}: err {err.item():.3e} scale {scale.item():.3e}"
+        worst_g = max(worst_g, float(err / scale))
+    helpers.REPORT_LINES.append(f"{label}: log-probs at {worst_out:.2f}x the operator gate (1e-5 rtol + 2e-6), "
+                                f"worst parameter gradient {worst_g:.2e} of its max-norm (gates: 1e-5 + 2e-6; 2e-5 + 2e-7 abs)")
     return model_selection_report(ours, ref, data, d, label)
 
 
@@ -52,19 +65,19 @@ def test_config1_cora_sngnn_full_size(cuda):
     ours, ref = build_pair("SNGNN", (f, 32, 7, 1))
     ours, d = ours.to(cuda), data.to(cuda)
     ours.eval(), ref.eval()                      # SNGNN's dropout is hard-wired to 0.5 (models.py:283)
-    assert_close(ours(d), ref(data), what="cora SNGNN log-probs", rtol=1e-4, atol=2e-5)
+    assert_close(ours(d), ref(data), what="cora SNGNN log-probs", rtol=1e-5, atol=2e-6)
     ours.dropout.p = ref.dropout.p = 0.0
     ours.train(), ref.train()
     F.nll_loss(ref(data)[data.train_mask], data.y[data.train_mask]).backward()
     F.nll_loss(ours(d)[d.train_mask], d.y[d.train_mask]).backward()
     for (name, p), (_, q) in zip(ours.named_parameters(), ref.named_parameters()):
         scale = q.grad.abs().max().clamp_min(1e-12)
-        assert (p.grad.cpu() - q.grad).abs().max() <= 2e-4 * scale + 1e-7, name
+        assert (p.grad.cpu() - q.grad).abs().max() <= 2e-5 * scale + 2e-7, name
     # two layers: the hidden conv at C = 32, dropout off
     ours, ref = build_pair("SNGNN", (f, 32, 7, 2))
     ours = ours.to(cuda)
     ours.eval(), ref.eval()
-    assert_close(ours(d), ref(data), what="cora SNGNN 2-layer log-probs", rtol=1e-4, atol=2e-5)
+    assert_close(ours(d), ref(data), what="cora SNGNN 2-layer log-probs", rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("layers", [1, 2])
