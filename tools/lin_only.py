@@ -7,6 +7,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sngnn_amd import ops  # noqa: E402
+from sngnn_amd._lib import load  # noqa: E402
+
+if os.environ.get("LIN_MODE"):      # 1 = fp32 matrix instructions instead of the bf16 split
+    load().sngnn_tuning_set(5, int(os.environ["LIN_MODE"]))
 
 dev = torch.device("cuda:0")
 f, c = int(os.environ.get("F", 128)), int(os.environ.get("C", 40))
