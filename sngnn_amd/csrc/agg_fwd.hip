@@ -1,4 +1,5 @@
 // C-ABI entries of the fused aggregation forward (see agg_fwd_impl.h for the kernels).
+#include <atomic>
 #include "agg_fwd_impl.h"
 
 using namespace sngnn;
@@ -74,10 +75,18 @@ static int g_role_mask = 7;
 static int g_table_mode = 0;
 // (sngnn_tuning_set(8, d): wave rows with fewer than d in-edges skip the fp16 filter; -1 = the library's rule)
 static int g_filt_min_deg = -1;
+int sngnn::g_fin_inline = 1;
+// a value no earlier call of this process has used (role_fin: the tasks' done words)
+unsigned long long sngnn::next_fin_nonce()
+{
+    static std::atomic<unsigned long long> counter{0};
+    return 0xF1A0000000000000ull + counter.fetch_add(1) + 1;
+}
 bool sngnn::fwd_scores_on_the_fly_forced() { return g_table_mode == 2; }
 extern "C" int sngnn_tuning_set(int which, int value)
 {
-    SN_REQUIRE(which == 0 || (which >= 2 && which <= 8), SNGNN_EINVAL, "unknown tuning knob");
+    SN_REQUIRE(which == 0 || (which >= 2 && which <= 9), SNGNN_EINVAL, "unknown tuning knob");
+    if (which == 9) { sngnn::g_fin_inline = value < 0 ? 0 : value; return SNGNN_OK; }
     if (which == 8) { g_filt_min_deg = value; return SNGNN_OK; }
     if (which == 7) return sngnn::set_cosine_split(value);
     if (which == 6) return sngnn::set_knn_route(value);
@@ -248,6 +257,9 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
     a.cand_key = a.partial ? (unsigned long long *)(a.partial + ((size_t)g->n_tasks * C + 3) / 4 * 4)
                            : nullptr;
     a.cand_src = a.cand_key ? (int32_t *)(a.cand_key + (size_t)g->n_tasks * CAND_MAX_K) : nullptr;
+    a.fin_done = a.cand_src ? (unsigned long long *)(a.cand_src + (size_t)g->n_tasks * CAND_MAX_K) : nullptr;   // 8-byte aligned
+    a.fin_nonce = 0ull; a.main_blocks = 0;
+    a.k_magic = top_k >= 2 ? (unsigned)(0xFFFFFFFFu / (unsigned)top_k + 1u) : 0u;
     const int max_split = g->n_split ? g->rdeg[0] : 0;
     a.use_cand = fwd_use_candidates(a.k, C, max_split) ? 1 : 0;
     SN_REQUIRE(a.kbits == nullptr || a.use_cand, SNGNN_EINVAL,

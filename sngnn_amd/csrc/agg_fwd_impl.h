@@ -82,6 +82,13 @@ struct FwdArgs {
     int use_cand;                   // split rows keep chunk-local candidates (k <= CAND_MAX_K and they fit LDS)
     int lowbits;                    // bits needed for a row-local edge index
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
+    // The split rows' finalize INSIDE the main launch (round 5; role_fin below): workgroups [main_blocks, gridDim.x)
+    // take no work items - their waves finalize split rows, each as soon as the row's tasks have published their
+    // candidates (fin_done[task] == fin_nonce).  main_blocks == gridDim.x: the finalize is the next launch.
+    int main_blocks;
+    unsigned long long *fin_done;   // [n_tasks] workspace; left zero by the wave that consumed them
+    unsigned long long fin_nonce;   // this call's own value (never 0, never an earlier call's)
+    unsigned k_magic;               // ceil(2^32 / k) for k >= 2: q / k = __umulhi(q, k_magic) for q < 2^32 / k (fin_slot)
     int role_mask;              // measurement aid (sngnn_tuning_set): bit 0 tasks, 1 wave rows, 2 small rows
     // row filter (sngnn_agg_forward_rows): only the target rows i with row_flag[i] == row_want are
     // computed and written; nullptr = all rows.  (A rank's interior rows - all sources local - run
@@ -299,7 +306,8 @@ template <int R> struct Unroll { static constexpr int U = (R == 1) ? 4 : (R == 2
 template <int G> struct WaveLds {
     static constexpr int RPW = 64 / G;
     static constexpr int SETW = (RPW * SMALL_T > 128) ? RPW * SMALL_T : 128;
-    static constexpr int WORDS = 4 * SETW;
+    //   finalize role (fin_group_batch): 96 words per row, one row per lane group
+    static constexpr int WORDS = 4 * SETW > RPW * 96 ? 4 * SETW : RPW * 96;
 };
 
 // ---------------------------------------------------------------------------
@@ -1271,27 +1279,335 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             wave_lds_sync();
             ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
         }
+        // (agent-scope stores: the row's finalize may run in another workgroup of THIS launch - role_fin - on
+        // another XCD; what it reads, and what it overwrites, must be in memory before the task says "done")
         unsigned long long *ck = a.cand_key + (size_t)tq * CAND_MAX_K;
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
         const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-        if (ws.kept0) ck[prefix_popc(m0)] = ws.key0;
-        if (ws.kept1) ck[n0 + prefix_popc(m1)] = ws.key1;
-        if (lane >= nsel && lane < a.k) ck[lane] = 0ull;          // empty slots (k <= 32 < 64)
+        if (ws.kept0) st_agent(ck + prefix_popc(m0), ws.key0);
+        if (ws.kept1) st_agent(ck + n0 + prefix_popc(m1), ws.key1);
+        if (lane >= nsel && lane < a.k) st_agent(ck + lane, 0ull);          // empty slots (k <= 32 < 64)
         int32_t *cs = a.cand_src + (size_t)tq * CAND_MAX_K;       // saves the finalize a dependent load
-        if (ws.kept0) cs[prefix_popc(m0)] = a.col[rs + e0 + lane];
-        if (ws.kept1) cs[n0 + prefix_popc(m1)] = a.col[rs + e0 + 64 + lane];
+        if (ws.kept0) st_agent(cs + prefix_popc(m0), a.col[rs + e0 + lane]);
+        if (ws.kept1) st_agent(cs + n0 + prefix_popc(m1), a.col[rs + e0 + 64 + lane]);
         if (a.wsel) {     // the finalize overwrites the kept edges of the row
             float *w = a.wsel + rs + e0;
-            if (lane < e1 - e0) w[lane] = SNGNN_UNSELECTED;
-            if (lane + 64 < e1 - e0) w[lane + 64] = SNGNN_UNSELECTED;
+            if (lane < e1 - e0) st_agent(w + lane, SNGNN_UNSELECTED);
+            if (lane + 64 < e1 - e0) st_agent(w + lane + 64, SNGNN_UNSELECTED);
         }
         if constexpr (!OTF)
-            if (a.kbits && lane < 4) a.kbits[a.kb_tbase + 4 * tq + lane] = 0u;      // the finalize sets the winners' bits
+            if (a.kbits && lane < 4) st_agent(a.kbits + a.kb_tbase + 4 * tq + lane, 0u);      // the finalize sets the winners' bits
+        if (a.main_blocks < (int)gridDim.x) {                     // (uniform) publish
+            wave_vmem_drain();
+            if (lane == 0) st_agent(a.fin_done + tq, a.fin_nonce);
+        }
     } else if (!rank) {
         acc.reduce_across_groups();
         if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
     }
     wave_lds_sync();            // the wave's LDS scratch is reused by its next item
+}
+
+// ---------------------------------------------------------------------------
+// The split rows' finalize inside the main launch (round 5).  As a launch of its own it was 7.4 us of a 70 us
+// step at arxiv size - a dependency chain (candidates -> selection -> 16 rows -> store) of 825 rows on an
+// otherwise idle chip, behind a launch boundary - although its inputs exist ~5 us into the main kernel: the tasks
+// are every wave's FIRST work item.  So the LAST workgroups of the launch (FwdArgs::main_blocks ..) take no work
+// items: they finalize the split rows, each as soon as the row's tasks have published their candidates, while the
+// other workgroups stream the wave rows and small rows.  What bounds the role is round trips, not work (an
+// agent-scope load comes from memory: 2-3 us under the main roles' traffic), so both forms below keep as many
+// rows' loads in flight as the registers hold:
+//   * rows of more than 128 candidates (arxiv size: 94, up to 1 584 candidates): one WORKGROUP per row - every wave
+//     selects among a quarter of the candidates (512 keys per round, eight per lane, all loads of a round in flight
+//     together), wave 0 among the four waves' winners.  (One wave per row, 96 new candidates per round: 17
+//     dependent round trips for the biggest row - the launch's critical path, 66 us against 48.)
+//   * the others: one lane GROUP per row, 64 / G rows per wave at once (fin_group_batch) - the accumulation runs in
+//     the order of the one-wave-per-row finalize launch (fin_wave_row), so the rows' bits are the same in both.
+//   Progress: a task never waits, and workgroups are dispatched in index order, so whenever a finalize workgroup is
+// resident every task's workgroup has been dispatched.  Should that ever not hold the wait is BOUNDED: a row whose
+// tasks have not shown up after FIN_SPIN_MAX polls (~1 s) is written as NaN and its waves stop waiting for the
+// rows behind it - a loud wrong answer, never a hung GPU.
+//   Visibility: tasks store what this role reads (candidate keys / sources) or overwrites (unselected marks, zeroed
+// kept-bit words) at agent scope and drain them before the done word; this role loads them at agent scope.
+// ---------------------------------------------------------------------------
+constexpr int FIN_SPIN_MAX = 1 << 19;
+constexpr int FIN_BLOCKS_MAX = 256;
+constexpr int FIN_GROUP_WORDS = 3 * CAND_MAX_K;      // LDS words of one row's winners: 32 keys (64 words) | 32 source ids
+
+template <int VEC, int G, int R, bool HEAD>
+__device__ __forceinline__ void fin_winners_row(const FwdArgs &a, int p, int i, int rs, int deg, int t0, int nsel,
+                                                const unsigned long long *s_key_w, const int *s_src_w, int head_yy,
+                                                unsigned head_sv);
+
+// candidate q of a row whose first task is t0 (task t0 + q / k, entry q % k of its CAND_MAX_K-slot record) without
+// the twenty-instruction division per candidate (eight per lane in flight: their temporaries were the role's spills)
+__device__ __forceinline__ unsigned fin_slot(const FwdArgs &a, int t0, int q)
+{
+    const int t = a.k == 1 ? q : (int)__umulhi((unsigned)q, a.k_magic);
+    return (unsigned)(t0 + t) * CAND_MAX_K + (unsigned)(q - t * a.k);       // (n_tasks * 32 < 2^31: int32 edge ids, CHUNK = 128)
+}
+
+// Top-k of the keys of ONE LANE GROUP (NK per lane, 0 = no key): wave_topk_keys_n's search with every count taken
+// over the group (the groups of a wave search different rows: no uniform early return - a group that is done
+// idles until the last one is).  The kept set is the k largest keys: the same set whichever routine picks it.
+template <int G, int NK>
+__device__ __forceinline__ void group_topk_keys_n(const unsigned long long (&key)[NK], int k, int lowbits,
+                                                  bool (&kept)[NK])
+{
+    const float fk = (float)k;                                // (counts <= 64 NK / (64 / G): exact in fp32)
+    float c0 = 0.f;
+#pragma unroll
+    for (int u = 0; u < NK; ++u) c0 += key[u] != 0ull ? 1.f : 0.f;
+    const bool fits = group_sum<G>(c0) <= fk;                 // everything that passed thr fits
+    unsigned hi[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) hi[u] = (unsigned)(key[u] >> 32);
+    bool done = fits, exact = false;
+    unsigned Th = 0;
+    for (int b = 31; b >= 0; --b) {
+        if (__all(done)) break;
+        const unsigned cand = Th | (1u << b);
+        float c = 0.f;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) c += hi[u] >= cand ? 1.f : 0.f;
+        c = group_sum<G>(c);
+        if (!done && c >= fk) {
+            Th = cand;
+            if (c == fk) { exact = true; done = true; }       // no further bit changes the set
+        }
+    }
+    unsigned long long T = ((unsigned long long)Th << 32) | (0xFFFFFFFFull & ~((1ull << lowbits) - 1ull));
+    for (int b = lowbits - 1; b >= 0; --b) {
+        if (__all(done)) break;
+        const unsigned long long cand = T | (1ull << b);
+        float c = 0.f;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) c += key[u] >= cand ? 1.f : 0.f;
+        c = group_sum<G>(c);
+        if (!done && c >= fk) {
+            T = cand;
+            if (c == fk) done = true;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) kept[u] = fits ? key[u] != 0ull : (exact ? hi[u] >= Th : key[u] >= T);
+}
+
+// Rows [pb, pb + 64 / G) of at most 128 candidates each, one per lane group.  seen (per group): the row's done
+// words were all read as done by the batch before (the look-ahead below); on return: whether row pb_next + gid's were.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void fin_group_batch(const FwdArgs &a, int pb, int pb_next, int *lds_wave, bool &dead,
+                                                bool &seen)
+{
+    using RowT = Row<VEC, G, R>;
+    constexpr int NG = 64 / G, NKG = 128 / G;
+    constexpr unsigned long long FULL = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+    const int lane = lane_id();
+    int gid = lane / G, lg = lane % G;
+    // (opaque per call: what depends on the lane only - eight slot offsets, masks, shuffle addresses - was hoisted
+    // out of the caller's loop over batches and held in ~50 registers across it: 131 against the kernel's 80)
+    asm volatile("" : "+v"(gid), "+v"(lg));
+    const int p = pb + gid;
+    const bool valid = p < a.n_split;
+    const int pc = valid ? p : a.n_split - 1;
+    const int4 d = a.rdesc[pc];
+    const int i = d.x, rs = d.y, deg = d.z;
+    const bool act = valid && !a.skip_row(i);                 // (group-uniform; a skipped row's tasks skipped it too)
+    const int t0 = a.split_task0[pc], t1 = a.split_task0[pc + 1];
+    unsigned long long *s_key = reinterpret_cast<unsigned long long *>(lds_wave + gid * FIN_GROUP_WORDS);
+    int *s_src = lds_wave + gid * FIN_GROUP_WORDS + 2 * CAND_MAX_K;
+    // wait for the rows' tasks
+    bool ready = seen || !act;
+    for (int spin = 0; !dead && spin < FIN_SPIN_MAX && !__all(ready); ++spin) {
+        bool mine = true;
+        for (int t = t0 + lg; t < t1; t += G) mine = mine && ld_agent(a.fin_done + t) == a.fin_nonce;
+        ready = ready || fwd_group_bits<G>(__ballot(mine), gid) == FULL;
+        if (!__all(ready)) __builtin_amdgcn_s_sleep(16);
+    }
+    if (!__all(ready)) dead = true;
+    const bool run = act && ready;
+    if (act && !ready)
+        for (int c = lg; c < a.C; c += G) a.out[(size_t)i * a.C + c] = __uint_as_float(0x7FC00000u);
+    if (run)
+        for (int t = t0 + lg; t < t1; t += G) st_agent(a.fin_done + t, 0ull);     // consumed (a replayed launch finds zeros)
+    // look ahead: the next batch's done words, in flight under this batch's round trips (by now its tasks are
+    // long done - one round trip less per batch; a "done" read early stays true: only this wave clears the words)
+    bool mine_next = pb_next + gid < a.n_split;
+    if (mine_next) {
+        const int u0 = a.split_task0[pb_next + gid], u1 = a.split_task0[pb_next + gid + 1];
+        for (int t = u0 + lg; t < u1; t += G) mine_next = mine_next && ld_agent(a.fin_done + t) == a.fin_nonce;
+    }
+    // candidates: slot q = lg + G u of the row
+    const int n = (t1 - t0) * a.k;                            // <= 128: the rows behind FwdArgs::n_split_gt_wave
+    auto slot = [&](int q) { return fin_slot(a, t0, q); };
+    unsigned long long key[NKG];
+    int src[NKG];                                             // (with the keys: one round trip, not two)
+#pragma unroll
+    for (int u = 0; u < NKG; ++u) {
+        const int q = lg + G * u;
+        const bool in = run && q < n;
+        key[u] = in ? ld_agent(a.cand_key + slot(q)) : 0ull;
+        src[u] = in ? ld_agent(a.cand_src + slot(q)) : 0;
+    }
+    bool kp[NKG];
+    group_topk_keys_n<G, NKG>(key, a.k, a.lowbits, kp);
+    int nsel = 0;                                             // winners in ascending slot order (fin_wave_row's order)
+#pragma unroll
+    for (int u = 0; u < NKG; ++u) {
+        const unsigned long long m = fwd_group_bits<G>(__ballot(kp[u]), gid);
+        if (kp[u]) {
+            const int o = nsel + __popcll(m & ((1ull << lg) - 1ull));
+            s_key[o] = key[u];
+            s_src[o] = src[u];
+        }
+        nsel += __popcll(m);
+    }
+    wave_lds_sync();
+    // the weighted sum, in the order of fin_winners_row: there lane group g adds the winners w = g (mod 64 / G) in
+    // ascending order and the groups' sums meet in a butterfly - here ONE group holds those 64 / G partial sums
+    RowT part[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) part[g].zero();
+    constexpr int STEP = R == 1 ? 8 : (R == 2 ? 4 : 2);      // rows in flight per group: a multiple of 64 / G
+    static_assert(STEP % NG == 0, "the partial sum of a winner must be a compile-time index");
+    const int nsel_max = wave_max_i(nsel);
+    for (int w0 = 0; w0 < nsel_max; w0 += STEP) {
+        RowT x[STEP];
+        float nj[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) {
+            const int j = nsel > 0 ? s_src[min(w0 + u, nsel - 1)] : 0;
+            x[u].load(a.n + (size_t)j * a.C, a.C, lg);
+            nj[u] = a.nrm ? a.nrm[j] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < STEP; ++u)
+            if (w0 + u < nsel) part[u % NG].axpy(key_score(s_key[w0 + u]) * nj[u], x[u]);
+    }
+    const bool emit = a.sel_src != nullptr;
+    for (int w = lg; w < nsel; w += G) {
+        const unsigned long long kq = s_key[w];
+        const float sq = key_score(kq);
+        if (a.wsel) a.wsel[rs + key_index(kq)] = sq;
+        if (a.kbits) atomicOr(a.kbits + a.kb_tbase + 4 * t0 + (key_index(kq) >> 5), 1u << (key_index(kq) & 31));
+        if (emit) {
+            int rk = 0;
+            for (int r = 0; r < nsel; ++r) rk += s_key[r] > kq;
+            a.sel_src[(size_t)i * a.k + rk] = s_src[w];
+            a.sel_w[(size_t)i * a.k + rk] = sq;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < NG; m <<= 1)
+#pragma unroll
+        for (int g = 0; g < NG; g += 2 * m) part[g].add(part[g + m]);
+    part[0].div((float)deg);
+    row_epilogue<VEC, G, R>(a, part[0], i, lg);
+    if (run) part[0].store(a.out + (size_t)i * a.C, a.C, lg);
+    seen = fwd_group_bits<G>(__ballot(mine_next), gid) == FULL;
+    wave_lds_sync();            // the wave's LDS scratch is reused by its next batch
+}
+
+// One row of more than 128 candidates, by the workgroup (called by all its waves; dead: workgroup-uniform).
+// LDS per wave: its winners' keys [0, 64) words | source ids [64, 96) | count [96] | ready flag [97].
+template <int VEC, int G, int R>
+__device__ __forceinline__ void fin_block_big(const FwdArgs &a, int p, int (*lds)[WaveLds<G>::WORDS], bool &dead)
+{
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));                          // (opaque per call: fin_group_batch's note)
+    const int wave = threadIdx.x >> 6;
+    int *lw = lds[wave];
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (workgroup-uniform; its tasks skipped it too)
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    unsigned long long *s_key_w = reinterpret_cast<unsigned long long *>(lw);
+    int *s_src_w = lw + 2 * CAND_MAX_K;
+    // every wave waits for all of the row's tasks, then the waves agree
+    bool ready = false;
+    for (int spin = 0; !dead && spin < FIN_SPIN_MAX; ++spin) {
+        bool mine = true;
+        for (int t = t0 + lane; t < t1; t += 64) mine = mine && ld_agent(a.fin_done + t) == a.fin_nonce;
+        if (__all(mine)) { ready = true; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (lane == 0) lw[97] = ready ? 1 : 0;
+    __syncthreads();
+    bool all_ready = true;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) all_ready = all_ready && lds[w][97] != 0;
+    if (!all_ready) {
+        dead = true;
+        if (wave == 0)
+            for (int c = lane; c < a.C; c += 64) a.out[(size_t)i * a.C + c] = __uint_as_float(0x7FC00000u);
+        __syncthreads();                                    // (the flags are read before anybody writes the next row's)
+        return;
+    }
+    if (wave == 0)
+        for (int t = t0 + lane; t < t1; t += 64) st_agent(a.fin_done + t, 0ull);      // consumed (every wave has seen them)
+    const int n = (t1 - t0) * a.k;
+    auto slot = [&](int q) { return fin_slot(a, t0, q); };
+    // this wave's quarter, in rounds of 512 keys: lanes [0, 32) of the first hold the running winners (k <=
+    // CAND_MAX_K = 32), the rest 480 new candidates; source ids: the winners' only, behind the selection
+    const int per = (n + WAVES - 1) / WAVES;
+    const int qlo = wave * per, qhi = min(n, qlo + per);
+    constexpr int NK = 8, NEW = 64 * NK - CAND_MAX_K;
+    int nsel = 0;
+    for (int q0 = qlo; q0 < qhi; q0 += NEW) {
+        unsigned long long key[NK];
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int q = q0 + u * 64 + lane - CAND_MAX_K;
+            const bool in = (u > 0 || lane >= CAND_MAX_K) && q < qhi;
+            key[u] = in ? ld_agent(a.cand_key + slot(q)) : 0ull;
+        }
+        int src_run = 0;
+        const bool had = lane < nsel;                      // key[0] is a running winner (its source id is known)
+        if (had) { key[0] = s_key_w[lane]; src_run = s_src_w[lane]; }
+        wave_lds_sync();                                   // the winners are in registers before their slots are reused
+        bool kp[NK];
+        wave_topk_keys_n<NK>(key, a.k, a.lowbits, kp);
+        int off = 0;
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const unsigned long long m = __ballot(kp[u]);
+            if (kp[u]) {
+                const int o = off + prefix_popc(m);
+                s_key_w[o] = key[u];
+                s_src_w[o] = (u == 0 && had) ? src_run : ld_agent(a.cand_src + slot(q0 + u * 64 + lane - CAND_MAX_K));
+            }
+            off += __popcll(m);
+        }
+        nsel = off;
+        wave_lds_sync();
+    }
+    if (lane == 0) lw[96] = nsel;
+    __syncthreads();
+    // wave 0: the four waves' winners (<= 32 each) -> one selection
+    unsigned long long key0 = 0ull, key1 = 0ull;
+    int src0 = 0, src1 = 0;
+    if (wave == 0) {
+        const int wa = lane >> 5, idx = lane & 31;          // key0: waves 0, 1; key1: waves 2, 3
+        if (idx < lds[wa][96]) {
+            key0 = reinterpret_cast<const unsigned long long *>(lds[wa])[idx];
+            src0 = lds[wa][2 * CAND_MAX_K + idx];
+        }
+        if (idx < lds[wa + 2][96]) {
+            key1 = reinterpret_cast<const unsigned long long *>(lds[wa + 2])[idx];
+            src1 = lds[wa + 2][2 * CAND_MAX_K + idx];
+        }
+    }
+    __syncthreads();                                        // (read before the other waves reuse their regions)
+    if (wave != 0) return;
+    bool k0, k1;
+    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    const int n0 = __popcll(m0), nfin = n0 + __popcll(m1);
+    if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
+    if (k1) { const int o = n0 + prefix_popc(m1); s_key_w[o] = key1; s_src_w[o] = src1; }
+    wave_lds_sync();
+    fin_winners_row<VEC, G, R, false>(a, p, i, rs, deg, t0, nfin, s_key_w, s_src_w, 0, 0u);
+    wave_lds_sync();
 }
 
 // Persistent waves: wave w of the grid takes work items w, w + n_waves, ... of the
@@ -1311,7 +1627,29 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     __shared__ __align__(16) int lds[WAVES][WaveLds<G>::WORDS];
     const int wave = threadIdx.x >> 6;
     int *lw = lds[wave];
-    const int nw = gridDim.x * WAVES;
+    constexpr int RPW = 64 / G;
+    const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
+    if ((int)blockIdx.x >= a.main_blocks) {                   // (workgroup-uniform) the finalize role
+        // Its arguments through the kernel-argument segment itself, behind an opaque pointer: read through `a`,
+        // the role's two dozen fields were loaded at the kernel's entry and held in scalar registers across the
+        // OTHER roles (55-72 spilled scalars, 6-8 spilled vector registers, 60 bytes of scratch per lane in
+        // every instantiation); this way they are loaded here, and the work-item roles compile as before.
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const FwdArgs &fa = *(const FwdArgs *)kp;             // (the kernel's only explicit argument: offset 0)
+        const int nfb = (int)gridDim.x - fa.main_blocks, fb = (int)blockIdx.x - fa.main_blocks;
+        const int n_big = min(fa.n_split, fa.n_split_gt_wave);
+        bool dead = false;
+        for (int p = fb; p < n_big; p += nfb) fin_block_big<VEC, G, R>(fa, p, lds, dead);
+        bool seen = false;
+        for (int pb = n_big + (fb * WAVES + wave) * RPW; pb < fa.n_split; pb += nfb * WAVES * RPW)
+            fin_group_batch<VEC, G, R>(fa, pb, pb + nfb * WAVES * RPW, lw, dead, seen);
+        // (Small-row sets kept back for these waves to take behind their rows - 400 .. 1 600 of 40 383 - moved
+        // nothing: 50.9-51.6 us against 51.0; the launch is 6 % slower than without the role's 96 workgroups, the
+        // share of the chip's wave slots they hold.)
+        return;
+    }
+    const int nw = a.main_blocks * WAVES;
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
     for (; it < a.n_tasks; it += nw)
@@ -1320,8 +1658,6 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     for (; it < n_wave_rows; it += nw)
         if (a.role_mask & 2) role_wave<VEC, G, R, FILT, OTF, EPI>(a, it, lw);
     it -= n_wave_rows;
-    constexpr int RPW = 64 / G;
-    const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
     if (a.role_mask & 4) role_small<VEC, G, R, OTF, EPI, FS>(a, it, nw, nsets, lw);
 }
 
@@ -1676,68 +2012,18 @@ __global__ __launch_bounds__(NW * 64) void k_agg_fin_cand(const FwdArgs a, int m
     fin_cand_row<VEC, G, R, NW, HEAD>(a, blockIdx.x, max_slots, dyn);
 }
 
-// The same finalize for split rows whose candidates fit one wave-level selection
-// ((tasks) * k <= 128, i.e. deg <= 8 * CHUNK at k = 16): one WAVE per row, no workgroup
-// barrier.  On graphs with many moderately large rows
-// (products-like: ~10^5 split rows) the 1024-thread tournament above is mostly idle.
-// s_key_w / s_src_w: the wave's own CAND_MAX_K LDS slots.
+// The winners of a split row (s_key_w / s_src_w [0, nsel): keys and source ids, in the selection's own order) ->
+// the row's weighted sum, its mean and stores, the bookkeeping of the kept edges.  One wave.
 template <int VEC, int G, int R, bool HEAD>
-__device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned long long *s_key_w, int *s_src_w)
+__device__ __forceinline__ void fin_winners_row(const FwdArgs &a, int p, int i, int rs, int deg, int t0, int nsel,
+                                                const unsigned long long *s_key_w, const int *s_src_w, int head_yy,
+                                                unsigned head_sv)
 {
     using RowT = Row<VEC, G, R>;
     constexpr int NG = 64 / G;
     const int lane = lane_id();
     const int gid = lane / G, lg = lane % G;
-    const int4 d = a.rdesc[p];
-    const int i = d.x, rs = d.y, deg = d.z;
-    if (a.skip_row(i)) return;                              // (wave-uniform)
-    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
-    int head_yy = 0;
-    unsigned head_sv = 0u;
-    if constexpr (HEAD) { head_yy = (int)a.head_y[i]; head_sv = a.head_sel[i]; }
-    if (a.k < 0) {
-        // (rows of at most 16 tasks come here: their partial rows are loaded together)
-        float *s_row = reinterpret_cast<float *>(s_key_w);      // head: the row through LDS (C <= 64 floats fit)
-        for (int c = lane; c < a.C; c += 64) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = t0 + u < t1 ? a.partial[(size_t)(t0 + u) * a.C + c] : 0.f;
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += v[u];
-            for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
-            if constexpr (HEAD) s_row[c] = s / (float)deg;
-            else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
-        }
-        if constexpr (HEAD) {
-            if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
-                wave_lds_sync();
-                HeadAcc ha;
-                if (gid == 0) {
-                    RowT row;
-                    const float4 t = *reinterpret_cast<const float4 *>(s_row + (4 * lg < a.C ? 4 * lg : 0));
-                    row.x[0][0] = t.x; row.x[0][1] = t.y; row.x[0][2] = t.z; row.x[0][3] = t.w;
-                    head_store_row<VEC, G, R>(a, row, i, lg, head_yy, head_sv, ha);
-                }
-                head_write_entry(a, a.head_nmain + p, ha);
-            }
-        }
-        return;
-    }
     const bool emit = a.sel_src != nullptr;
-    const int n = (t1 - t0) * a.k;                            // <= 128 by the launch split
-    auto slot = [&](int q) { return (size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k; };
-    const unsigned long long key0 = lane < n ? a.cand_key[slot(lane)] : 0ull;
-    const unsigned long long key1 = lane + 64 < n ? a.cand_key[slot(lane + 64)] : 0ull;
-    const int src0 = lane < n ? a.cand_src[slot(lane)] : 0;
-    const int src1 = lane + 64 < n ? a.cand_src[slot(lane + 64)] : 0;
-    bool k0, k1;
-    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-    const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-    if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
-    if (k1) { const int o = n0 + prefix_popc(m1); s_key_w[o] = key1; s_src_w[o] = src1; }
-    wave_lds_sync();
     RowT acc;
     acc.zero();
     constexpr int GU = R >= 3 ? 2 : 4;                        // winner rows in flight per lane group
@@ -1781,6 +2067,69 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     if (gid == 0) acc.store(a.out + (size_t)i * a.C, a.C, lg);
 }
 
+// The same finalize for split rows whose candidates fit one wave-level selection
+// ((tasks) * k <= 128, i.e. deg <= 8 * CHUNK at k = 16): one WAVE per row, no workgroup
+// barrier.  On graphs with many moderately large rows
+// (products-like: ~10^5 split rows) the 1024-thread tournament above is mostly idle.
+// s_key_w / s_src_w: the wave's own CAND_MAX_K LDS slots.
+template <int VEC, int G, int R, bool HEAD>
+__device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned long long *s_key_w, int *s_src_w)
+{
+    using RowT = Row<VEC, G, R>;
+    const int lane = lane_id();
+    const int gid = lane / G, lg = lane % G;
+    const int4 d = a.rdesc[p];
+    const int i = d.x, rs = d.y, deg = d.z;
+    if (a.skip_row(i)) return;                              // (wave-uniform)
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    int head_yy = 0;
+    unsigned head_sv = 0u;
+    if constexpr (HEAD) { head_yy = (int)a.head_y[i]; head_sv = a.head_sel[i]; }
+    if (a.k < 0) {
+        // (rows of at most 16 tasks come here: their partial rows are loaded together)
+        float *s_row = reinterpret_cast<float *>(s_key_w);      // head: the row through LDS (C <= 64 floats fit)
+        for (int c = lane; c < a.C; c += 64) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = t0 + u < t1 ? a.partial[(size_t)(t0 + u) * a.C + c] : 0.f;
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+            for (int t = t0 + 16; t < t1; ++t) s += a.partial[(size_t)t * a.C + c];
+            if constexpr (HEAD) s_row[c] = s / (float)deg;
+            else a.out[(size_t)i * a.C + c] = a.epilogue(s / (float)deg, i, c);
+        }
+        if constexpr (HEAD) {
+            if constexpr (VEC == 4 && R == 1 && (G == 8 || G == 16)) {
+                wave_lds_sync();
+                HeadAcc ha;
+                if (gid == 0) {
+                    RowT row;
+                    const float4 t = *reinterpret_cast<const float4 *>(s_row + (4 * lg < a.C ? 4 * lg : 0));
+                    row.x[0][0] = t.x; row.x[0][1] = t.y; row.x[0][2] = t.z; row.x[0][3] = t.w;
+                    head_store_row<VEC, G, R>(a, row, i, lg, head_yy, head_sv, ha);
+                }
+                head_write_entry(a, a.head_nmain + p, ha);
+            }
+        }
+        return;
+    }
+    const int n = (t1 - t0) * a.k;                            // <= 128 by the launch split
+    auto slot = [&](int q) { return (size_t)(t0 + q / a.k) * CAND_MAX_K + q % a.k; };
+    const unsigned long long key0 = lane < n ? a.cand_key[slot(lane)] : 0ull;
+    const unsigned long long key1 = lane + 64 < n ? a.cand_key[slot(lane + 64)] : 0ull;
+    const int src0 = lane < n ? a.cand_src[slot(lane)] : 0;
+    const int src1 = lane + 64 < n ? a.cand_src[slot(lane + 64)] : 0;
+    bool k0, k1;
+    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+    const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
+    if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
+    if (k1) { const int o = n0 + prefix_popc(m1); s_key_w[o] = key1; s_src_w[o] = src1; }
+    wave_lds_sync();
+    fin_winners_row<VEC, G, R, HEAD>(a, p, i, rs, deg, t0, nsel, s_key_w, s_src_w, head_yy, head_sv);
+}
+
 // 4 rows per 256-thread workgroup
 template <int VEC, int G, int R, bool HEAD>
 __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int first, int count)
@@ -1792,7 +2141,6 @@ __global__ __launch_bounds__(BLOCK) void k_agg_fin_wave(const FwdArgs a, int fir
     if (q >= count) return;                                   // wave-uniform
     fin_wave_row<VEC, G, R, HEAD>(a, first + q, s_key[wave], s_src[wave]);
 }
-
 // Both in ONE launch when the moderate split rows are few (arxiv-like graphs: a few hundred
 // split rows in all): workgroups [0, n_big) run the tournament of one big row each, the
 // others one moderate row per wave - 140 workgroups that all start at once instead of 825
@@ -1928,6 +2276,10 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 // profiling (sngnn_profile_enable(reps)): every launch is issued `reps` times back to back
 // between its two events, so the event pair's own cost is spread over reps launches
 extern int g_prof_reps;
+// sngnn_tuning_set(9, v): 0 = the split rows' finalize as a launch of its own (round 4's form), 1 = inside the main
+// launch when it fits (launch_agg_fwd_impl), v > 1 = inside it on v workgroups
+extern int g_fin_inline;
+unsigned long long next_fin_nonce();
 
 template <int VEC, int G, int R, int EPI>
 int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hipStream_t st)
@@ -1936,9 +2288,39 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     constexpr int RPW = 64 / G;
     const int n_small = a0.N - a0.n_med_end;
     const int64_t items = (int64_t)a0.n_tasks + (a0.n_med_end - a0.n_split) + ceil_div(n_small, RPW);
-    // persistent grid: what the chip holds at the kernel's occupancy, or less
-    const int grid = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD);
     FwdArgs a = a0;
+    // the split rows' finalize inside this launch (fin_block_big / fin_group_batch): rows that rank from candidates,
+    // no head behind them - when the role's chain of round trips fits under the work items' time.  Both sides in us,
+    // measured at arxiv size on MI355X (tools/sweep_fwd.py FIN=..): a wave takes ~5.8 us per work item; the role
+    // starts ~6 us in (the tasks are the first items), a big row takes a workgroup ~12 us, a batch of 64 / G
+    // moderate rows a wave ~12.5.  The smallest number of workgroups that ends the role by 3/4 of the launch (every
+    // one of them is six waves' worth of work items the others have to take over: +1 us per 50 at arxiv size); none
+    // does - small graphs: the launch is shorter than one big row's chain - and the finalize stays a launch.
+    const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k > 0 && a.head_sel == nullptr &&
+                        a.fin_done != nullptr && (a.role_mask & 7) == 7;
+    const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
+    const int fin_batches = ceil_div(a.n_split - fin_big, RPW);
+    int fin_blocks = 0;
+    auto fin_times = [&](int nb, double &t_main, double &t_fin) {
+        const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD - nb) * WAVES;
+        t_main = 5.8 * (double)ceil_div(items, main_waves);
+        t_fin = 6.0 + 12.0 * ceil_div(fin_big, nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
+    };
+    double t_main = 0., t_fin = 0.;
+    if (fin_ok && g_fin_inline > 1) fin_blocks = std::min(g_fin_inline, FIN_BLOCKS_MAX);      // (forced: tuning knob 9)
+    else if (fin_ok) {
+        for (int nb = 8; nb <= FIN_BLOCKS_MAX && fin_blocks == 0; nb += 8) {
+            fin_times(nb, t_main, t_fin);
+            if (t_fin <= 0.75 * t_main) fin_blocks = nb;
+        }
+    }
+    const bool fin_inline = fin_blocks > 0;
+    // persistent grid: what the chip holds at the kernel's occupancy, or less (the finalize role's workgroups
+    // are resident from the start: they come out of the same budget)
+    const int grid_main = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD - fin_blocks);
+    const int grid = grid_main + fin_blocks;
+    a.main_blocks = grid_main;
+    if (fin_inline) a.fin_nonce = next_fin_nonce();
     // head_part: one entry per workgroup of the head role, then one per split row.  (The role rides in the
     // mixed finalize launch - 512 threads then - where there is one, else in a launch of its own.)
     a.head_nmain = a.head_sel ? head_role_blocks(a.N, G, head_role_in_finalize(a) ? 512 : BLOCK) : 0;
@@ -1955,7 +2337,7 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
         }
     }
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
-    for (int rep = 0; rep < reps; ++rep)
+    for (int rep = 0; rep < reps && !fin_inline; ++rep)
         if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;
     if (ev) {
         SN_HIP(hipEventRecord(ev[2], st));

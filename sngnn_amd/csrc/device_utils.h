@@ -64,6 +64,20 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Stores and loads other workgroups of the SAME launch see (agent scope: written through / read past the XCD's
+// own L2, which is not coherent with the other seven).  Relaxed: the caller orders them (st: s_waitcnt vmcnt(0)
+// in front of the word that publishes them; ld: issued behind the load that saw that word).
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every vector memory operation this wave has issued is complete at the scope it named
+__device__ __forceinline__ void wave_vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int prefix_popc(unsigned long long mask)
 {

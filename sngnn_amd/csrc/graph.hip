@@ -592,10 +592,10 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {
     if (!g || C < 1) return -1;
     // forward: unit rows | norms | scores of split rows | one partial row per split task |
-    //          CAND_MAX_K candidate keys and source ids per task
+    //          CAND_MAX_K candidate keys and source ids per task | one done word per task (role_fin)
     int64_t fwd = sngnn::fwd_table_bytes(g->Ntot, C) +
                   (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
-                  (int64_t)g->n_tasks * 32 * 8 + (int64_t)g->n_tasks * 32 * 4;
+                  (int64_t)g->n_tasks * 32 * 8 + (int64_t)g->n_tasks * 32 * 4 + (int64_t)g->n_tasks * 8;
     // backward: {w, ds} record per edge | dnT per node | partT per split task | partS (2 rows) per
     //           split-source task
     //           (attention mode: 2 rows + 4 scalars) | partS (2 rows) per split-source task

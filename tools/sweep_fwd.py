@@ -34,6 +34,9 @@ if os.environ.get("FILTER") is not None:          # A/B of the fp16 filter (csrc
 if os.environ.get("MIN_DEG") is not None:         # wave rows below this in-degree skip the filter (knob 8)
     lib.sngnn_tuning_set(8, int(os.environ["MIN_DEG"]))
     print("filter only for wave rows with in-degree >=", os.environ["MIN_DEG"])
+if os.environ.get("FIN") is not None:             # knob 9: 0 = the split rows' finalize as a launch of its own, 1 = the library's rule, v > 1 = inside the main launch on v workgroups
+    lib.sngnn_tuning_set(9, int(os.environ["FIN"]))
+    print("finalize inside the main launch:", os.environ["FIN"])
 if os.environ.get("ROLES") is not None:           # only some row classes of the main kernel (timing only)
     lib.sngnn_tuning_set(0, int(os.environ["ROLES"]))
     print("role mask", os.environ["ROLES"], "(1 tasks, 2 wave rows, 4 small rows)")
