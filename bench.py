@@ -360,6 +360,18 @@ def main():
         # of a single launch between two events (which carries the event pair's own ~4.5 us)
         norm_ms, main_ms, fin_ms, _ = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 6, 20)
         _, main_single_ms, _, empty_ms = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 30, 1)
+        # where the split rows were finalized (sngnn_tuning_set knob 9): inside the main launch - then kernel_ms
+        # holds that work too and finalize_kernel_ms is an empty interval - or in a launch of its own
+        fin_wgs = int(lib.sngnn_last_forward_finalize_workgroups())
+        fin_ab = None
+        if fin_wgs > 0 and world == 1 and not plus_plus:
+            # the same step with the finalize as a launch of its own (round 4's form), same box, same graph
+            lib.sngnn_tuning_set(9, 0)
+            dt0, _, _, _ = measure(R, args.steps, args.warmup)
+            n0, m0, f0, _ = profile_forward(lib, _lib, ops, graph, table, args.top_k, args.thr, 6, 20)
+            lib.sngnn_tuning_set(9, 1)
+            fin_ab = {"ms_per_step": dt0 / args.steps * 1e3, "normalize_kernel_ms": n0, "kernel_ms_batched_events": m0,
+                      "finalize_kernel_ms": f0}
         b_alg = algorithmic_bytes(e_prime, n, c)
         traffic = rocprof_us = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -431,6 +443,13 @@ def main():
                                               "arithmetic, no selection, no second fetch of kept rows; edges_only = the column "
                                               "list's gather alone.  kernel_over_floor = kernel_ms_batched_events / gather_floor_ms",
                          "normalize_kernel_ms": norm_ms, "finalize_kernel_ms": fin_ms,
+                         "finalize_workgroups_in_main": fin_wgs,
+                         "finalize_what": ("the split rows (in-degree > 128) are finalized by the last workgroups of the main "
+                                           "launch, each row as soon as its tasks have published their candidates: kernel_ms "
+                                           "holds that work, finalize_kernel_ms is an empty interval; "
+                                           "finalize_as_a_launch = the same step with sngnn_tuning_set(9, 0)") if fin_wgs > 0
+                         else "the split rows' finalize is the launch behind the main kernel",
+                         "finalize_as_a_launch": fin_ab,
                          "launches_ms_sum": norm_ms + main_batched_ms + fin_ms,
                          "kernel_ms_batched_events": main_batched_ms,
                          "timer": "kernel_ms = max(HIP events on the launch stream around batches of 20 back-to-back "

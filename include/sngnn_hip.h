@@ -279,8 +279,19 @@ int sngnn_agg_forward_rows(const sngnn_graph_t *g, const float *n, const float *
  * default 3 - anything else leaves grad_h incomplete: timing only);
  * knob 5 = sngnn_linear_forward*, sngnn_cosine_dense, sngnn_knn_graph: 0 (default) = products on the bf16 matrix
  * cores after an exact three-way split of both operands (fp32 accumulation, an fp32 contraction's
- * rounding), 1 = fp32 MFMAs */
+ * rounding), 1 = fp32 MFMAs;
+ * knobs 6, 7, 8 = the kNN builder's route, the dense cosine's contraction split, the in-degree below which a wave row
+ * skips the fp16 filter (csrc/knn.hip, toolbox.hip, agg_fwd.hip);
+ * knob 9 = where the split rows (in-degree > 128) of sngnn_agg_forward* are finalized: 1 (default) = inside the main
+ * launch - by its last workgroups, each row as soon as its tasks have published their candidates - when that
+ * chain of round trips fits under the launch's own time (arxiv-sized graphs and up; calls that rank from
+ * candidates, no head epilogue), else in a launch of its own; 0 = always a launch of its own; v > 1 = inside the
+ * main launch on v workgroups.  Same selections and kept weights either way; the rows' sums agree bit for bit for
+ * rows of at most 128 candidates and to rounding (another summation order) for the bigger ones. */
 int sngnn_tuning_set(int which, int value);
+/* how many workgroups of the last sngnn_agg_forward* launch on this process finalized split rows (0 = the
+ * finalize was a launch of its own, or there was nothing to finalize) - measurement aid, see knob 9 */
+int sngnn_last_forward_finalize_workgroups(void);
 /* test aid: out[p] = the filter pass's approximate cosine of nodes pair_a[p], pair_b[p] (dev i64) */
 int sngnn_filter_pair_scores(const void *filt, int C, const int64_t *pair_a, const int64_t *pair_b,
                              int64_t n_pairs, float *out, void *stream);

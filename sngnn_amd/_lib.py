@@ -50,6 +50,7 @@ SIGNATURES = {
     "sngnn_filter_wanted": (_i32, [_vp, _i32, _i32, _f32]),
     "sngnn_agg_forward_rows": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "sngnn_tuning_set": (_i32, [_i32, _i32]),
+    "sngnn_last_forward_finalize_workgroups": (_i32, []),
     "sngnn_filter_pair_scores": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp, _vp]),
     "sngnn_agg_forward_normalized": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
                                             _vp]),

@@ -76,6 +76,8 @@ static int g_table_mode = 0;
 // (sngnn_tuning_set(8, d): wave rows with fewer than d in-edges skip the fp16 filter; -1 = the library's rule)
 static int g_filt_min_deg = -1;
 int sngnn::g_fin_inline = 1;
+int sngnn::g_last_fin_blocks = 0;
+extern "C" int sngnn_last_forward_finalize_workgroups(void) { return sngnn::g_last_fin_blocks; }
 // a value no earlier call of this process has used (role_fin: the tasks' done words)
 unsigned long long sngnn::next_fin_nonce()
 {

@@ -2278,7 +2278,7 @@ int launch_split_finalize(const FwdArgs &a, int max_split_deg, hipStream_t st)
 extern int g_prof_reps;
 // sngnn_tuning_set(9, v): 0 = the split rows' finalize as a launch of its own (round 4's form), 1 = inside the main
 // launch when it fits (launch_agg_fwd_impl), v > 1 = inside it on v workgroups
-extern int g_fin_inline;
+extern int g_fin_inline, g_last_fin_blocks;
 unsigned long long next_fin_nonce();
 
 template <int VEC, int G, int R, int EPI>
@@ -2290,28 +2290,32 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     const int64_t items = (int64_t)a0.n_tasks + (a0.n_med_end - a0.n_split) + ceil_div(n_small, RPW);
     FwdArgs a = a0;
     // the split rows' finalize inside this launch (fin_block_big / fin_group_batch): rows that rank from candidates,
-    // no head behind them - when the role's chain of round trips fits under the work items' time.  Both sides in us,
-    // measured at arxiv size on MI355X (tools/sweep_fwd.py FIN=..): a wave takes ~5.8 us per work item; the role
-    // starts ~6 us in (the tasks are the first items), a big row takes a workgroup ~12 us, a batch of 64 / G
-    // moderate rows a wave ~12.5.  The smallest number of workgroups that ends the role by 3/4 of the launch (every
-    // one of them is six waves' worth of work items the others have to take over: +1 us per 50 at arxiv size); none
-    // does - small graphs: the launch is shorter than one big row's chain - and the finalize stays a launch.
+    // no head behind them - when it pays.  All figures in us, measured on MI355X (tools/sweep_fwd.py FIN=..,
+    // arxiv and products size): a wave takes ~5.8 us per work item; the role starts ~6 us in (the tasks are the
+    // first items), a big row takes a workgroup ~17 us, a batch of 64 / G moderate rows a wave ~12.5.
+    //   * the role must end by 3/4 of the launch: the smallest number nb of workgroups that does;
+    //   * each of them is six waves' worth of slots the work items lose: the launch grows by nb / (slots - nb);
+    //   * against that, the launch it replaces: ~4.6 us + its rows over the whole chip, + the boundary (1.1).
+    // Arxiv size, C 40: 96 workgroups, +3.3 us against 7.1 saved (measured: 70.2 -> 64.5 us per forward).  Products
+    // size: 168 workgroups would cost 0.5 ms against 0.27 saved - stays a launch (measured with 64 forced: 9.23
+    // against 9.18 ms).  Small graphs, narrow rows (C 32: a 35 us launch): nothing ends the role in time - a launch.
     const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k > 0 && a.head_sel == nullptr &&
                         a.fin_done != nullptr && (a.role_mask & 7) == 7;
     const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
     const int fin_batches = ceil_div(a.n_split - fin_big, RPW);
+    constexpr int SLOTS = 256 * FWD_WAVES_PER_SIMD;
     int fin_blocks = 0;
-    auto fin_times = [&](int nb, double &t_main, double &t_fin) {
-        const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD - nb) * WAVES;
-        t_main = 5.8 * (double)ceil_div(items, main_waves);
-        t_fin = 6.0 + 12.0 * ceil_div(fin_big, nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
-    };
-    double t_main = 0., t_fin = 0.;
     if (fin_ok && g_fin_inline > 1) fin_blocks = std::min(g_fin_inline, FIN_BLOCKS_MAX);      // (forced: tuning knob 9)
     else if (fin_ok) {
         for (int nb = 8; nb <= FIN_BLOCKS_MAX && fin_blocks == 0; nb += 8) {
-            fin_times(nb, t_main, t_fin);
-            if (t_fin <= 0.75 * t_main) fin_blocks = nb;
+            const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), SLOTS - nb) * WAVES;
+            const double t_main = 5.8 * (double)ceil_div(items, main_waves);
+            const double t_fin = 6.0 + 17.0 * ceil_div(fin_big, nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
+            if (t_fin > 0.75 * t_main) continue;
+            const double t_sep = 4.6 + 1.1 + 12.0 * fin_big / (256.0 * 3) + 12.5 * fin_batches / (256.0 * 24);
+            const double loss = 5.8 * (double)ceil_div(items, (int64_t)SLOTS * WAVES) * nb / (double)(SLOTS - nb);
+            if (loss + 1.0 < t_sep) fin_blocks = nb;
+            break;                                            // (more workgroups only cost more)
         }
     }
     const bool fin_inline = fin_blocks > 0;
@@ -2320,6 +2324,7 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     const int grid_main = (int)std::min<int64_t>(ceil_div(items, WAVES), 256 * FWD_WAVES_PER_SIMD - fin_blocks);
     const int grid = grid_main + fin_blocks;
     a.main_blocks = grid_main;
+    g_last_fin_blocks = fin_blocks;
     if (fin_inline) a.fin_nonce = next_fin_nonce();
     // head_part: one entry per workgroup of the head role, then one per split row.  (The role rides in the
     // mixed finalize launch - 512 threads then - where there is one, else in a launch of its own.)
