@@ -1317,10 +1317,10 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
 // other workgroups stream the wave rows and small rows.  What bounds the role is round trips, not work (an
 // agent-scope load comes from memory: 2-3 us under the main roles' traffic), so both forms below keep as many
 // rows' loads in flight as the registers hold:
-//   * rows of more than 128 candidates (arxiv size: 94, up to 1 584 candidates): one WORKGROUP per row - every wave
-//     selects among a quarter of the candidates (512 keys per round, eight per lane, all loads of a round in flight
-//     together), wave 0 among the four waves' winners.  (One wave per row, 96 new candidates per round: 17
-//     dependent round trips for the biggest row - the launch's critical path, 66 us against 48.)
+//   * rows of more than 128 candidates (arxiv size: 94, up to 1 584 candidates): two WAVES per row, two rows per
+//     workgroup - a wave selects among half of the candidates (512 keys per round, eight per lane, all loads of a
+//     round in flight together), the even wave among the pair's winners.  (One wave per row, 96 new candidates per
+//     round: 17 dependent round trips for the biggest row - the launch's critical path, 66 us against 48.)
 //   * the others: one lane GROUP per row, 64 / G rows per wave at once (fin_group_batch) - the accumulation runs in
 //     the order of the one-wave-per-row finalize launch (fin_wave_row), so the rows' bits are the same in both.
 //   Progress: a task never waits, and workgroups are dispatched in index order, so whenever a finalize workgroup is
@@ -1468,7 +1468,10 @@ __device__ __forceinline__ void fin_group_batch(const FwdArgs &a, int pb, int pb
     RowT part[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) part[g].zero();
-    constexpr int STEP = R == 1 ? 8 : (R == 2 ? 4 : 2);      // rows in flight per group: a multiple of 64 / G
+    // rows in flight per group: a multiple of 64 / G.  (Eight at R == 1: 84 registers - three spilled, 12-16 bytes of
+    // scratch per lane for EVERY wave of the launch - and no faster: 64.6-64.9 against 64.9-65.2 us per forward,
+    // while the launch without the role lost 0.4 us to the scratch set-up.)
+    constexpr int STEP = R == 1 ? (NG > 4 ? NG : 4) : (R == 2 ? 4 : 2);
     static_assert(STEP % NG == 0, "the partial sum of a winner must be a compile-time index");
     const int nsel_max = wave_max_i(nsel);
     for (int w0 = 0; w0 < nsel_max; w0 += STEP) {
@@ -1508,49 +1511,52 @@ __device__ __forceinline__ void fin_group_batch(const FwdArgs &a, int pb, int pb
     wave_lds_sync();            // the wave's LDS scratch is reused by its next batch
 }
 
-// One row of more than 128 candidates, by the workgroup (called by all its waves; dead: workgroup-uniform).
+// Two rows of more than 128 candidates each, by the workgroup: waves 0, 1 take the halves of row p0's candidates,
+// waves 2, 3 those of row p0 + 1 (none: they only keep the barriers company); the even wave of a pair merges.
+// Called by all waves of the workgroup - every wave passes the same three barriers whatever its row's state.
 // LDS per wave: its winners' keys [0, 64) words | source ids [64, 96) | count [96] | ready flag [97].
 template <int VEC, int G, int R>
-__device__ __forceinline__ void fin_block_big(const FwdArgs &a, int p, int (*lds)[WaveLds<G>::WORDS], bool &dead)
+__device__ __forceinline__ void fin_block_pair(const FwdArgs &a, int p0, int n_big, int (*lds)[WaveLds<G>::WORDS],
+                                               bool &dead)
 {
     int lane = lane_id();
     asm volatile("" : "+v"(lane));                          // (opaque per call: fin_group_batch's note)
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, half = wave & 1;
     int *lw = lds[wave];
-    const int4 d = a.rdesc[p];
+    const int p = p0 + (wave >> 1);
+    const bool valid = p < n_big;
+    const int pc = valid ? p : p0;
+    const int4 d = a.rdesc[pc];
     const int i = d.x, rs = d.y, deg = d.z;
-    if (a.skip_row(i)) return;                              // (workgroup-uniform; its tasks skipped it too)
-    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    const bool act = valid && !a.skip_row(i);               // (wave-uniform; a skipped row's tasks skipped it too)
+    const int t0 = a.split_task0[pc], t1 = a.split_task0[pc + 1];
     unsigned long long *s_key_w = reinterpret_cast<unsigned long long *>(lw);
     int *s_src_w = lw + 2 * CAND_MAX_K;
-    // every wave waits for all of the row's tasks, then the waves agree
-    bool ready = false;
-    for (int spin = 0; !dead && spin < FIN_SPIN_MAX; ++spin) {
+    // both waves of a pair wait for all of the row's tasks, then they agree
+    bool ready = !act;
+    for (int spin = 0; !ready && !dead && spin < FIN_SPIN_MAX; ++spin) {
         bool mine = true;
         for (int t = t0 + lane; t < t1; t += 64) mine = mine && ld_agent(a.fin_done + t) == a.fin_nonce;
-        if (__all(mine)) { ready = true; break; }
-        __builtin_amdgcn_s_sleep(16);
+        if (__all(mine)) ready = true;
+        else __builtin_amdgcn_s_sleep(16);
     }
     if (lane == 0) lw[97] = ready ? 1 : 0;
     __syncthreads();
-    bool all_ready = true;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) all_ready = all_ready && lds[w][97] != 0;
-    if (!all_ready) {
+    const bool run = act && ready && lds[wave ^ 1][97] != 0;
+    if (act && !run) {
         dead = true;
-        if (wave == 0)
+        if (half == 0)
             for (int c = lane; c < a.C; c += 64) a.out[(size_t)i * a.C + c] = __uint_as_float(0x7FC00000u);
-        __syncthreads();                                    // (the flags are read before anybody writes the next row's)
-        return;
     }
-    if (wave == 0)
-        for (int t = t0 + lane; t < t1; t += 64) st_agent(a.fin_done + t, 0ull);      // consumed (every wave has seen them)
+    if (run && half == 0)
+        for (int t = t0 + lane; t < t1; t += 64) st_agent(a.fin_done + t, 0ull);      // consumed (both waves have seen them)
     const int n = (t1 - t0) * a.k;
     auto slot = [&](int q) { return fin_slot(a, t0, q); };
-    // this wave's quarter, in rounds of 512 keys: lanes [0, 32) of the first hold the running winners (k <=
-    // CAND_MAX_K = 32), the rest 480 new candidates; source ids: the winners' only, behind the selection
-    const int per = (n + WAVES - 1) / WAVES;
-    const int qlo = wave * per, qhi = min(n, qlo + per);
+    // this wave's half, in rounds of 512 keys: lanes [0, 32) of the first hold the running winners (k <=
+    // CAND_MAX_K = 32), the rest 480 new candidates - all loads of a round in flight together; source ids: the
+    // winners' only, behind the selection
+    const int per = (n + 1) / 2;
+    const int qlo = half * per, qhi = run ? min(n, qlo + per) : qlo;
     constexpr int NK = 8, NEW = 64 * NK - CAND_MAX_K;
     int nsel = 0;
     for (int q0 = qlo; q0 < qhi; q0 += NEW) {
@@ -1583,28 +1589,23 @@ __device__ __forceinline__ void fin_block_big(const FwdArgs &a, int p, int (*lds
     }
     if (lane == 0) lw[96] = nsel;
     __syncthreads();
-    // wave 0: the four waves' winners (<= 32 each) -> one selection
-    unsigned long long key0 = 0ull, key1 = 0ull;
-    int src0 = 0, src1 = 0;
-    if (wave == 0) {
-        const int wa = lane >> 5, idx = lane & 31;          // key0: waves 0, 1; key1: waves 2, 3
+    // the even wave: the pair's winners (<= 32 each) -> one selection
+    unsigned long long key0 = 0ull;
+    int src0 = 0;
+    if (half == 0) {
+        const int wa = wave + (lane >> 5), idx = lane & 31;
         if (idx < lds[wa][96]) {
             key0 = reinterpret_cast<const unsigned long long *>(lds[wa])[idx];
             src0 = lds[wa][2 * CAND_MAX_K + idx];
         }
-        if (idx < lds[wa + 2][96]) {
-            key1 = reinterpret_cast<const unsigned long long *>(lds[wa + 2])[idx];
-            src1 = lds[wa + 2][2 * CAND_MAX_K + idx];
-        }
     }
-    __syncthreads();                                        // (read before the other waves reuse their regions)
-    if (wave != 0) return;
+    __syncthreads();                                        // (read before the odd waves reuse their regions)
+    if (half != 0 || !run) return;
     bool k0, k1;
-    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-    const int n0 = __popcll(m0), nfin = n0 + __popcll(m1);
+    wave_topk_keys(key0, 0ull, a.k, a.lowbits, k0, k1);
+    const unsigned long long m0 = __ballot(k0);
+    const int nfin = __popcll(m0);
     if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
-    if (k1) { const int o = n0 + prefix_popc(m1); s_key_w[o] = key1; s_src_w[o] = src1; }
     wave_lds_sync();
     fin_winners_row<VEC, G, R, false>(a, p, i, rs, deg, t0, nfin, s_key_w, s_src_w, 0, 0u);
     wave_lds_sync();
@@ -1640,7 +1641,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
         const int nfb = (int)gridDim.x - fa.main_blocks, fb = (int)blockIdx.x - fa.main_blocks;
         const int n_big = min(fa.n_split, fa.n_split_gt_wave);
         bool dead = false;
-        for (int p = fb; p < n_big; p += nfb) fin_block_big<VEC, G, R>(fa, p, lds, dead);
+        for (int p0 = 2 * fb; p0 < n_big; p0 += 2 * nfb) fin_block_pair<VEC, G, R>(fa, p0, n_big, lds, dead);
         bool seen = false;
         for (int pb = n_big + (fb * WAVES + wave) * RPW; pb < fa.n_split; pb += nfb * WAVES * RPW)
             fin_group_batch<VEC, G, R>(fa, pb, pb + nfb * WAVES * RPW, lw, dead, seen);
@@ -2289,10 +2290,10 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     const int n_small = a0.N - a0.n_med_end;
     const int64_t items = (int64_t)a0.n_tasks + (a0.n_med_end - a0.n_split) + ceil_div(n_small, RPW);
     FwdArgs a = a0;
-    // the split rows' finalize inside this launch (fin_block_big / fin_group_batch): rows that rank from candidates,
+    // the split rows' finalize inside this launch (fin_block_pair / fin_group_batch): rows that rank from candidates,
     // no head behind them - when it pays.  All figures in us, measured on MI355X (tools/sweep_fwd.py FIN=..,
     // arxiv and products size): a wave takes ~5.8 us per work item; the role starts ~6 us in (the tasks are the
-    // first items), a big row takes a workgroup ~17 us, a batch of 64 / G moderate rows a wave ~12.5.
+    // first items), a pair of big rows takes a workgroup ~17 us, a batch of 64 / G moderate rows a wave ~12.5.
     //   * the role must end by 3/4 of the launch: the smallest number nb of workgroups that does;
     //   * each of them is six waves' worth of slots the work items lose: the launch grows by nb / (slots - nb);
     //   * against that, the launch it replaces: ~4.6 us + its rows over the whole chip, + the boundary (1.1).
@@ -2310,7 +2311,7 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
         for (int nb = 8; nb <= FIN_BLOCKS_MAX && fin_blocks == 0; nb += 8) {
             const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), SLOTS - nb) * WAVES;
             const double t_main = 5.8 * (double)ceil_div(items, main_waves);
-            const double t_fin = 6.0 + 17.0 * ceil_div(fin_big, nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
+            const double t_fin = 6.0 + 17.0 * ceil_div(ceil_div(fin_big, 2), nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
             if (t_fin > 0.75 * t_main) continue;
             const double t_sep = 4.6 + 1.1 + 12.0 * fin_big / (256.0 * 3) + 12.5 * fin_batches / (256.0 * 24);
             const double loss = 5.8 * (double)ceil_div(items, (int64_t)SLOTS * WAVES) * nb / (double)(SLOTS - nb);

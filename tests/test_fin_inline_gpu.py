@@ -1,4 +1,4 @@
-"""The split rows' finalize INSIDE the main launch (csrc/agg_fwd_impl.h: fin_block_big / fin_group_batch;
+"""The split rows' finalize INSIDE the main launch (csrc/agg_fwd_impl.h: fin_block_pair / fin_group_batch;
 sngnn_tuning_set(9, v): 0 = a launch of its own, 1 = the library's rule, v > 1 = inside the launch on v
 workgroups).  The library's rule takes it only where the launch is long enough (arxiv-sized graphs and up), so
 the small graphs of the other test files run the separate launch: here the role is FORCED and held against
