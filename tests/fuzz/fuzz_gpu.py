@@ -19,6 +19,9 @@ from tests.helpers import check_selection, random_graph  # noqa: E402
 dev = torch.device("cuda:0")
 FILTER_MODE = int(os.environ.get("SNGNN_FUZZ_FILTER", "1"))      # 0 never / 1 auto / 2 always (csrc/agg_fwd_filter.h)
 _lib.load().sngnn_filter_enable(FILTER_MODE)
+# where split rows are finalized (sngnn_tuning_set knob 9): 0 a launch of its own / 1 the library's rule / v > 1 inside
+# the main launch on v workgroups - small graphs only get there when forced
+_lib.load().sngnn_tuning_set(9, int(os.environ.get("SNGNN_FUZZ_FIN", "1")))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t_end = time.time() + budget

@@ -18,6 +18,9 @@ from sngnn_amd.synth import Data  # noqa: E402
 from tests.helpers import random_graph  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("SNGNN_FUZZ_FIN"):      # where split rows are finalized (sngnn_tuning_set knob 9; fuzz_gpu.py)
+    from sngnn_amd import _lib  # noqa: E402
+    _lib.load().sngnn_tuning_set(9, int(os.environ["SNGNN_FUZZ_FIN"]))
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t_end = time.time() + budget
