@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-finalize-ab", action="store_true",
+                    help="skip the leg that times the same step with the split rows' finalize as a launch of its own "
+                         "(profiling runs: one form of the main kernel per trace)")
     args = ap.parse_args()
 
     # (before anything initialises the HIP runtime, which reads it once: the host driver only
@@ -364,7 +367,7 @@ def main():
         # holds that work too and finalize_kernel_ms is an empty interval - or in a launch of its own
         fin_wgs = int(lib.sngnn_last_forward_finalize_workgroups())
         fin_ab = None
-        if fin_wgs > 0 and world == 1 and not plus_plus:
+        if fin_wgs > 0 and world == 1 and not plus_plus and not args.no_finalize_ab:
             # the same step with the finalize as a launch of its own (round 4's form), same box, same graph
             lib.sngnn_tuning_set(9, 0)
             dt0, _, _, _ = measure(R, args.steps, args.warmup)

@@ -4,8 +4,8 @@
 # summaries you want judged into profiles/.
 set -e -o pipefail
 TAG=${1:-r01}
-ARGS=${2:---steps 100 --warmup 10 --no-epoch --no-cpu-baseline --no-variants}
-PMC_ARGS=${3:---steps 20 --warmup 5 --no-epoch --no-cpu-baseline --no-variants}
+ARGS=${2:---steps 100 --warmup 10 --no-epoch --no-cpu-baseline --no-variants --no-finalize-ab}
+PMC_ARGS=${3:---steps 20 --warmup 5 --no-epoch --no-cpu-baseline --no-variants --no-finalize-ab}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof/$TAG
 mkdir -p $OUT
