@@ -177,3 +177,4 @@ def test_forced_role_in_the_other_instantiations(cuda, lib, what):
             assert_close(y, x, what=what + " gradient", rtol=1e-5, atol=1e-6)
         else:
             assert torch.equal(x, y)
+
