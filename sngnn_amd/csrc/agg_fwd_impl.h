@@ -2297,9 +2297,9 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     //   * the role must end by 3/4 of the launch: the smallest number nb of workgroups that does;
     //   * each of them is six waves' worth of slots the work items lose: the launch grows by nb / (slots - nb);
     //   * against that, the launch it replaces: ~4.6 us + its rows over the whole chip, + the boundary (1.1).
-    // Arxiv size, C 40: 96 workgroups, +3.3 us against 7.1 saved (measured: 70.2 -> 64.5 us per forward).  Products
-    // size: 168 workgroups would cost 0.5 ms against 0.27 saved - stays a launch (measured with 64 forced: 9.23
-    // against 9.18 ms).  Small graphs, narrow rows (C 32: a 35 us launch): nothing ends the role in time - a launch.
+    // Arxiv size, C 40: 48 workgroups, +1.6 us against 7.1 saved (measured: 70.2 -> 64.5-65.3 us per forward).
+    // Products size: 128 workgroups - a wash (the launch 4.35 ms with the finalize inside against 4.12 + 0.26).
+    // Small graphs, narrow rows (C 32: a 35 us launch): nothing ends the role in time - a launch.
     const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k > 0 && a.head_sel == nullptr &&
                         a.fin_done != nullptr && (a.role_mask & 7) == 7;
     const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
