@@ -184,6 +184,22 @@ def gather_floor(lib, _lib, graph, table, mode, batches=6, reps=20):
     return float(np.median(ms[1:]))
 
 
+def copy_floor(table, batches=6, reps=20):
+    """The normalisation pass's floor on this box: a plain device copy of the table (4NC bytes read + 4NC written =
+    the pass's bytes but for the 4N of norms, no arithmetic), average duration in ms, timed like gather_floor."""
+    dst = torch.empty_like(table)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(batches):
+        ev[0].record()
+        for _ in range(reps):
+            dst.copy_(table)
+        ev[1].record()
+        ev[1].synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]) / reps)
+    return float(np.median(ms[1:]))
+
+
 def time_loop(fn, warmup, steps, sync):
     for _ in range(warmup):
         fn()
@@ -393,6 +409,8 @@ def main():
         if c % 4 == 0 and c <= 256:
             floor_edges_ms = gather_floor(lib, _lib, graph, table, 0)
             floor_ms = gather_floor(lib, _lib, graph, table, 1)
+        # the floor under the normalisation pass: a device copy of the same table
+        copy_ms = copy_floor(table[:n] if table.size(0) != n else table)
         # the kernel figure: the live batched-event average, but never less than the committed
         # rocprofv3 average of the same command (dispatch to completion of one kernel: back-to-back
         # launches of one kernel can overlap a ramp with a drain and read lower); kernel_ms_source
@@ -445,6 +463,12 @@ def main():
                                               "per entry of the column list in CSR order, own row in, output row out) with no "
                                               "arithmetic, no selection, no second fetch of kept rows; edges_only = the column "
                                               "list's gather alone.  kernel_over_floor = kernel_ms_batched_events / gather_floor_ms",
+                         "normalize_floor_ms": copy_ms,
+                         "step_over_floors": None if not floor_ms else ms_per_step / (floor_ms + copy_ms),
+                         "floors_what": "normalize_floor_ms = a plain device copy of the table (the normalisation pass's bytes, no "
+                                        "arithmetic; torch copy_, batched events); step_over_floors = ms_per_step / (gather_floor_ms + "
+                                        "normalize_floor_ms): the whole step against the two measured floors of its two passes, "
+                                        "launch boundaries not counted",
                          "normalize_kernel_ms": norm_ms, "finalize_kernel_ms": fin_ms,
                          "finalize_workgroups_in_main": fin_wgs,
                          "finalize_what": ("the split rows (in-degree > 128) are finalized by the last workgroups of the main "

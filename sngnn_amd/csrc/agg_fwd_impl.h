@@ -1234,7 +1234,10 @@ __device__ __forceinline__ void role_wave(const FwdArgs &a, int item, int *lds_w
 // ---------------------------------------------------------------------------
 // Class A: one CHUNK-edge task of a split row.
 // ---------------------------------------------------------------------------
-template <int VEC, int G, int R, bool FILT, bool OTF>
+// FIN: the row's finalize runs in THIS launch (fin_block_pair / fin_group_batch / fin_stream_row) - what it reads
+// or overwrites is stored at agent scope, then the task says "done".  The launches whose finalize is the next
+// launch run the FIN = false instantiation: plain stores, the code of round 4.
+template <int VEC, int G, int R, bool FILT, bool OTF, bool FIN>
 __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wave)
 {
     using RowT = Row<VEC, G, R>;
@@ -1279,31 +1282,46 @@ __device__ __forceinline__ void role_task(const FwdArgs &a, int tq, int *lds_wav
             wave_lds_sync();
             ws = wave_select(s_sc, e1 - e0, e0, a.k, a.thr, a.lowbits);
         }
-        // (agent-scope stores: the row's finalize may run in another workgroup of THIS launch - role_fin - on
-        // another XCD; what it reads, and what it overwrites, must be in memory before the task says "done")
+        // (FIN: agent-scope stores - the row's finalize runs in another workgroup of THIS launch, on another XCD;
+        // what it reads, and what it overwrites, must be in memory before the task says "done")
+        auto put = [](auto *q, auto v) {
+            if constexpr (FIN) st_agent(q, v);
+            else *q = v;
+        };
         unsigned long long *ck = a.cand_key + (size_t)tq * CAND_MAX_K;
         const unsigned long long m0 = __ballot(ws.kept0), m1 = __ballot(ws.kept1);
         const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
-        if (ws.kept0) st_agent(ck + prefix_popc(m0), ws.key0);
-        if (ws.kept1) st_agent(ck + n0 + prefix_popc(m1), ws.key1);
-        if (lane >= nsel && lane < a.k) st_agent(ck + lane, 0ull);          // empty slots (k <= 32 < 64)
+        if (ws.kept0) put(ck + prefix_popc(m0), ws.key0);
+        if (ws.kept1) put(ck + n0 + prefix_popc(m1), ws.key1);
+        if (lane >= nsel && lane < a.k) put(ck + lane, 0ull);          // empty slots (k <= 32 < 64)
         int32_t *cs = a.cand_src + (size_t)tq * CAND_MAX_K;       // saves the finalize a dependent load
-        if (ws.kept0) st_agent(cs + prefix_popc(m0), a.col[rs + e0 + lane]);
-        if (ws.kept1) st_agent(cs + n0 + prefix_popc(m1), a.col[rs + e0 + 64 + lane]);
+        if (ws.kept0) put(cs + prefix_popc(m0), a.col[rs + e0 + lane]);
+        if (ws.kept1) put(cs + n0 + prefix_popc(m1), a.col[rs + e0 + 64 + lane]);
         if (a.wsel) {     // the finalize overwrites the kept edges of the row
             float *w = a.wsel + rs + e0;
-            if (lane < e1 - e0) st_agent(w + lane, SNGNN_UNSELECTED);
-            if (lane + 64 < e1 - e0) st_agent(w + lane + 64, SNGNN_UNSELECTED);
+            if (lane < e1 - e0) put(w + lane, SNGNN_UNSELECTED);
+            if (lane + 64 < e1 - e0) put(w + lane + 64, SNGNN_UNSELECTED);
         }
         if constexpr (!OTF)
-            if (a.kbits && lane < 4) st_agent(a.kbits + a.kb_tbase + 4 * tq + lane, 0u);      // the finalize sets the winners' bits
-        if (a.main_blocks < (int)gridDim.x) {                     // (uniform) publish
+            if (a.kbits && lane < 4) put(a.kbits + a.kb_tbase + 4 * tq + lane, 0u);      // the finalize sets the winners' bits
+    } else if (!rank) {
+        acc.reduce_across_groups();
+        if constexpr (FIN) {
+            if (gid == 0) {
+                float *pr = a.partial + (size_t)tq * a.C;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if ((r * G + lg) * VEC < a.C) st_agent_vec<VEC>(pr + (r * G + lg) * VEC, acc.x[r]);
+            }
+        } else {
+            if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
+        }
+    }
+    if constexpr (FIN) {
+        if (cand || !rank) {                                      // (uniform) publish
             wave_vmem_drain();
             if (lane == 0) st_agent(a.fin_done + tq, a.fin_nonce);
         }
-    } else if (!rank) {
-        acc.reduce_across_groups();
-        if (gid == 0) acc.store(a.partial + (size_t)tq * a.C, a.C, lg);
     }
     wave_lds_sync();            // the wave's LDS scratch is reused by its next item
 }
@@ -1511,6 +1529,64 @@ __device__ __forceinline__ void fin_group_batch(const FwdArgs &a, int pb, int pb
     wave_lds_sync();            // the wave's LDS scratch is reused by its next batch
 }
 
+// A split row of a call that selects nothing (top_k < 0: SNConv): the sum of its tasks' partial rows, one wave per
+// row, a lane per channel - in the finalize launch's own order (sixteen slices, slice s = tasks s, s + 16, .. added
+// in turn, then the slices in order: fin_cand_row / fin_wave_row), sixteen loads in flight.  seen / p_next: the
+// look-ahead of fin_group_batch.
+template <int VEC, int G, int R>
+__device__ __forceinline__ void fin_stream_row(const FwdArgs &a, int p, int p_next, bool &dead, bool &seen)
+{
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));                          // (opaque per call: fin_group_batch's note)
+    const int4 d = a.rdesc[p];
+    const int i = d.x, deg = d.z;
+    const bool was_seen = seen;
+    seen = false;
+    if (a.skip_row(i)) return;                              // (wave-uniform; its tasks skipped it too)
+    const int t0 = a.split_task0[p], t1 = a.split_task0[p + 1];
+    bool ready = was_seen;
+    for (int spin = 0; !ready && !dead && spin < FIN_SPIN_MAX; ++spin) {
+        bool mine = true;
+        for (int t = t0 + lane; t < t1; t += 64) mine = mine && ld_agent(a.fin_done + t) == a.fin_nonce;
+        if (__all(mine)) ready = true;
+        else __builtin_amdgcn_s_sleep(16);
+    }
+    if (!ready) {
+        dead = true;
+        for (int c = lane; c < a.C; c += 64) a.out[(size_t)i * a.C + c] = __uint_as_float(0x7FC00000u);
+        return;
+    }
+    for (int t = t0 + lane; t < t1; t += 64) st_agent(a.fin_done + t, 0ull);      // consumed (a replayed launch finds zeros)
+    bool mine_next = p_next < a.n_split;
+    if (mine_next) {
+        const int u0 = a.split_task0[p_next], u1 = a.split_task0[p_next + 1];
+        for (int t = u0 + lane; t < u1; t += 64) mine_next = mine_next && ld_agent(a.fin_done + t) == a.fin_nonce;
+    }
+    for (int c0 = 0; c0 < a.C; c0 += 64) {
+        const int c = c0 + lane;
+        const bool in = c < a.C;
+        float sl[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sl[u] = 0.f;
+        for (int tb = t0; tb < t1; tb += 16) {
+#pragma unroll
+            for (int h = 0; h < 16; h += 8) {                  // (eight loads in flight: sixteen spilled registers)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (in && tb + h + u < t1) ? ld_agent(a.partial + (size_t)(tb + h + u) * a.C + c) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sl[h + u] += v[u];
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += sl[u];
+        if (in) a.out[(size_t)i * a.C + c] = a.epilogue(sum / (float)deg, i, c);
+    }
+    seen = __all(mine_next) != 0;
+}
+
 // Two rows of more than 128 candidates each, by the workgroup: waves 0, 1 take the halves of row p0's candidates,
 // waves 2, 3 those of row p0 + 1 (none: they only keep the barriers company); the even wave of a pair merges.
 // Called by all waves of the workgroup - every wave passes the same three barriers whatever its row's state.
@@ -1620,7 +1696,9 @@ __device__ __forceinline__ void fin_block_pair(const FwdArgs &a, int p0, int n_b
 // FS: the filter also in front of the small rows (small_rows_set_filt) - its own instantiation: compiled into
 // the plain FILT kernel it cost that kernel's other calls 2.5 us (41.8 against 39.3 us at top_k 1 / thr 0.99
 // without the small-row form: six spilled registers)
-template <int VEC, int G, int R, bool FILT, bool OTF, int EPI = 0, bool FS = false>
+// FIN: the launch's last workgroups finalize the split rows (role_task's note); its own instantiation, so the
+// launches without the role run the kernel they ran before it existed
+template <int VEC, int G, int R, bool FILT, bool OTF, int EPI = 0, bool FS = false, bool FIN = false>
 __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const FwdArgs a)
 {
     static_assert(!(FILT && OTF), "the filter belongs to the table mode");
@@ -1630,7 +1708,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     int *lw = lds[wave];
     constexpr int RPW = 64 / G;
     const int nsets = (a.N - a.n_med_end + RPW - 1) / RPW;
-    if ((int)blockIdx.x >= a.main_blocks) {                   // (workgroup-uniform) the finalize role
+    if constexpr (FIN) if ((int)blockIdx.x >= a.main_blocks) {                   // (workgroup-uniform) the finalize role
         // Its arguments through the kernel-argument segment itself, behind an opaque pointer: read through `a`,
         // the role's two dozen fields were loaded at the kernel's entry and held in scalar registers across the
         // OTHER roles (55-72 spilled scalars, 6-8 spilled vector registers, 60 bytes of scratch per lane in
@@ -1639,10 +1717,14 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
         asm volatile("" : "+s"(kp));
         const FwdArgs &fa = *(const FwdArgs *)kp;             // (the kernel's only explicit argument: offset 0)
         const int nfb = (int)gridDim.x - fa.main_blocks, fb = (int)blockIdx.x - fa.main_blocks;
+        bool dead = false, seen = false;
+        if (fa.k < 0) {                                       // (uniform) nothing selected: sums of partial rows
+            for (int p = fb * WAVES + wave; p < fa.n_split; p += nfb * WAVES)
+                fin_stream_row<VEC, G, R>(fa, p, p + nfb * WAVES, dead, seen);
+            return;
+        }
         const int n_big = min(fa.n_split, fa.n_split_gt_wave);
-        bool dead = false;
         for (int p0 = 2 * fb; p0 < n_big; p0 += 2 * nfb) fin_block_pair<VEC, G, R>(fa, p0, n_big, lds, dead);
-        bool seen = false;
         for (int pb = n_big + (fb * WAVES + wave) * RPW; pb < fa.n_split; pb += nfb * WAVES * RPW)
             fin_group_batch<VEC, G, R>(fa, pb, pb + nfb * WAVES * RPW, lw, dead, seen);
         // (Small-row sets kept back for these waves to take behind their rows - 400 .. 1 600 of 40 383 - moved
@@ -1654,7 +1736,7 @@ __global__ __launch_bounds__(BLOCK, FWD_WAVES_PER_SIMD) void k_agg_fwd(const Fwd
     const int n_wave_rows = a.n_med_end - a.n_split;
     int it = blockIdx.x * WAVES + wave;
     for (; it < a.n_tasks; it += nw)
-        if (a.role_mask & 1) role_task<VEC, G, R, FILT, OTF>(a, a.task_order[it], lw);
+        if (a.role_mask & 1) role_task<VEC, G, R, FILT, OTF, FIN>(a, a.task_order[it], lw);
     it -= a.n_tasks;
     for (; it < n_wave_rows; it += nw)
         if (a.role_mask & 2) role_wave<VEC, G, R, FILT, OTF, EPI>(a, it, lw);
@@ -2300,7 +2382,9 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     // Arxiv size, C 40: 48 workgroups, +1.6 us against 7.1 saved (measured: 70.2 -> 64.5-65.3 us per forward).
     // Products size: 128 workgroups - a wash (the launch 4.35 ms with the finalize inside against 4.12 + 0.26).
     // Small graphs, narrow rows (C 32: a 35 us launch): nothing ends the role in time - a launch.
-    const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k > 0 && a.head_sel == nullptr &&
+    //   Calls that select nothing (top_k < 0: fin_stream_row, one wave per row): ~4 us per row + 2.5 per sixteen tasks
+    // of the biggest row.
+    const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k != 0 && a.head_sel == nullptr &&
                         a.fin_done != nullptr && (a.role_mask & 7) == 7;
     const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
     const int fin_batches = ceil_div(a.n_split - fin_big, RPW);
@@ -2311,9 +2395,12 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
         for (int nb = 8; nb <= FIN_BLOCKS_MAX && fin_blocks == 0; nb += 8) {
             const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), SLOTS - nb) * WAVES;
             const double t_main = 5.8 * (double)ceil_div(items, main_waves);
-            const double t_fin = 6.0 + 17.0 * ceil_div(ceil_div(fin_big, 2), nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
+            const double t_fin = a.k < 0
+                ? 6.0 + 4.0 * ceil_div(a.n_split, nb * WAVES) + 2.5 * ceil_div(ceil_div(max_split_deg, CHUNK), 16)
+                : 6.0 + 17.0 * ceil_div(ceil_div(fin_big, 2), nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
             if (t_fin > 0.75 * t_main) continue;
-            const double t_sep = 4.6 + 1.1 + 12.0 * fin_big / (256.0 * 3) + 12.5 * fin_batches / (256.0 * 24);
+            const double t_sep = a.k < 0 ? 4.6 + 1.1 + 4.0 * a.n_split / (256.0 * 24)
+                                         : 4.6 + 1.1 + 12.0 * fin_big / (256.0 * 3) + 12.5 * fin_batches / (256.0 * 24);
             const double loss = 5.8 * (double)ceil_div(items, (int64_t)SLOTS * WAVES) * nb / (double)(SLOTS - nb);
             if (loss + 1.0 < t_sep) fin_blocks = nb;
             break;                                            // (more workgroups only cost more)
@@ -2331,17 +2418,23 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     // mixed finalize launch - 512 threads then - where there is one, else in a launch of its own.)
     a.head_nmain = a.head_sel ? head_role_blocks(a.N, G, head_role_in_finalize(a) ? 512 : BLOCK) : 0;
     if (ev) SN_HIP(hipEventRecord(ev[0], st));
+#define SNGNN_FWD_LAUNCH(FILTV, OTFV, FSV)                                                              \
+    do {                                                                                              \
+        if (fin_inline) k_agg_fwd<VEC, G, R, FILTV, OTFV, EPI, FSV, true><<<grid, BLOCK, 0, st>>>(a);  \
+        else k_agg_fwd<VEC, G, R, FILTV, OTFV, EPI, FSV, false><<<grid, BLOCK, 0, st>>>(a);            \
+    } while (0)
     for (int rep = 0; rep < reps && grid > 0; ++rep) {
         if (a.nrm == nullptr) {                                  // OTF: a.n holds the raw rows
-            k_agg_fwd<VEC, G, R, false, true, EPI><<<grid, BLOCK, 0, st>>>(a);
+            SNGNN_FWD_LAUNCH(false, true, false);
         } else if constexpr (VEC == 4 && G >= 16 && G * R <= 128) {     // the (G, R) that C in 36 .. 512 maps to
-            if (a.filt && a.k >= 0 && a.filt_small) k_agg_fwd<VEC, G, R, true, false, EPI, true><<<grid, BLOCK, 0, st>>>(a);
-            else if (a.filt && a.k >= 0) k_agg_fwd<VEC, G, R, true, false, EPI><<<grid, BLOCK, 0, st>>>(a);
-            else k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
+            if (a.filt && a.k >= 0 && a.filt_small) SNGNN_FWD_LAUNCH(true, false, true);
+            else if (a.filt && a.k >= 0) SNGNN_FWD_LAUNCH(true, false, false);
+            else SNGNN_FWD_LAUNCH(false, false, false);
         } else {
-            k_agg_fwd<VEC, G, R, false, false, EPI><<<grid, BLOCK, 0, st>>>(a);
+            SNGNN_FWD_LAUNCH(false, false, false);
         }
     }
+#undef SNGNN_FWD_LAUNCH
     if (ev) SN_HIP(hipEventRecord(ev[1], st));
     for (int rep = 0; rep < reps && !fin_inline; ++rep)
         if (int rc = launch_split_finalize<VEC, G, R>(a, max_split_deg, st)) return rc;

@@ -75,6 +75,22 @@ template <typename T> __device__ __forceinline__ T ld_agent(const T *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// VEC consecutive floats at agent scope in ONE store instruction (the compiler's own atomic stores are one dword
+// each: four address computations where a row's store has one - six spilled registers in the task role)
+template <int VEC> __device__ __forceinline__ void st_agent_vec(float *p, const float (&x)[VEC])
+{
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = {x[0], x[1], x[2], x[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else if constexpr (VEC == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 v = {x[0], x[1]};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(x[0]) : "memory");
+    }
+}
 // every vector memory operation this wave has issued is complete at the scope it named
 __device__ __forceinline__ void wave_vmem_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

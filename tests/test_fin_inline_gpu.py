@@ -178,3 +178,37 @@ def test_forced_role_in_the_other_instantiations(cuda, lib, what):
         else:
             assert torch.equal(x, y)
 
+
+
+@pytest.mark.parametrize("C,hubs,blocks,relu", [
+    (40, ((0, 2999), (1, 2500), (2, 1300), (3, 700), (4, 400), (5, 300), (6, 200), (7, 140)), 2, False),
+    (7, ((0, 2999), (1, 2100), (2, 129)), 3, False),
+    (200, ((0, 2999), (1, 2100), (2, 129)), 2, True),
+    (64, tuple((v, 129 + 37 * v) for v in range(60)), 5, True),
+])
+def test_forced_role_without_selection(cuda, lib, C, hubs, blocks, relu):
+    """top_k None (SNConv): the role adds the tasks' partial rows in the finalize launch's own order - every row
+    bit for bit, with and without a store epilogue, table mode and on the fly."""
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    n = 6000 if len(hubs) > 10 else 3000
+    ei = random_graph(n, 20000, seed=C + len(hubs), hubs=hubs)
+    g = Graph(ei.to(cuda), n, True, True)
+    h = torch.randn(n, C, generator=torch.Generator().manual_seed(C)).to(cuda)
+    for table_mode in (0, 1):
+        lib.sngnn_tuning_set(2, table_mode)
+        outs = []
+        for mode in (0, blocks):
+            lib.sngnn_tuning_set(9, mode)
+            if relu and C % 4 == 0:
+                bias = torch.linspace(-0.2, 0.2, C, device=cuda)
+                y = ops.aggregate(h, g, None, 0.0, epilogue=ops.HiddenEpilogue(True, 0.0, False), bias=bias)
+            else:
+                y = ops.aggregate_forward(g, h, None, 0.0)[0]
+            torch.cuda.synchronize()
+            assert lib.sngnn_last_forward_finalize_workgroups() == mode
+            outs.append(y.cpu())
+        assert torch.equal(outs[0], outs[1]), f"table mode {table_mode}"
+    ref = oracle_aggregate(h.cpu(), ei, True, True, None, 0.0)
+    lib.sngnn_tuning_set(9, blocks)
+    assert_close(ops.aggregate_forward(g, h, None, 0.0)[0], ref["out"])
