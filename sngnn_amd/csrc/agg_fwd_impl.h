@@ -2385,7 +2385,9 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     //   Calls that select nothing (top_k < 0: fin_stream_row, one wave per row): ~4 us per row + 2.5 per sixteen tasks
     // of the biggest row.
     const bool fin_ok = g_fin_inline != 0 && a.n_split > 0 && a.use_cand && a.k != 0 && a.head_sel == nullptr &&
-                        a.fin_done != nullptr && (a.role_mask & 7) == 7;
+                        a.fin_done != nullptr && ((a.role_mask & 7) == 7 || g_fin_inline > 1);
+    // (a forced role with the tasks masked out - knobs 9 and 0 - is the test of the bounded wait: the split rows come
+    // back as NaN after FIN_SPIN_MAX polls, tests/test_fin_inline_gpu.py)
     const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
     const int fin_batches = ceil_div(a.n_split - fin_big, RPW);
     constexpr int SLOTS = 256 * FWD_WAVES_PER_SIMD;

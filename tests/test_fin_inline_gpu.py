@@ -22,6 +22,7 @@ def lib(cuda):
     handle = _lib.load()
     yield handle
     handle.sngnn_tuning_set(9, 1)
+    handle.sngnn_tuning_set(0, 7)
     handle.sngnn_tuning_set(2, 0)
     handle.sngnn_filter_enable(1)
 
@@ -212,3 +213,38 @@ def test_forced_role_without_selection(cuda, lib, C, hubs, blocks, relu):
     ref = oracle_aggregate(h.cpu(), ei, True, True, None, 0.0)
     lib.sngnn_tuning_set(9, blocks)
     assert_close(ops.aggregate_forward(g, h, None, 0.0)[0], ref["out"])
+
+
+@pytest.mark.parametrize("k", [16, None])
+def test_the_wait_is_bounded(cuda, lib, k):
+    """Tasks that never come (masked out: knob 0) - the role gives up after its bounded number of polls and writes the
+    rows it could not finalize as NaN: a loud wrong answer within seconds, never a hung GPU.  Every other row is
+    computed as usual, and the next call (tasks back) is clean: no stale state."""
+    import time
+    from sngnn_amd.graph import Graph
+    from sngnn_amd import ops
+    n, C = 3000, 40
+    hubs = ((0, 2999), (1, 1500), (2, 600), (3, 200), (4, 150))
+    ei = random_graph(n, 20000, seed=3, hubs=hubs)
+    g = Graph(ei.to(cuda), n, True, True)
+    h = torch.randn(n, C, device=cuda)
+    lib.sngnn_tuning_set(9, 0)
+    want = ops.aggregate_forward(g, h, k, 0.0)[0].clone()
+    deg = torch.from_numpy(np.diff(g.array("rowptr").astype(np.int64))).to(cuda)
+    split = deg > 128
+    assert int(split.sum()) >= 5
+    lib.sngnn_tuning_set(9, 2)
+    lib.sngnn_tuning_set(0, 6)                      # wave rows and small rows only: no task ever says "done"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = ops.aggregate_forward(g, h, k, 0.0)[0]
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t0
+    assert took < 30.0, f"the bounded wait took {took:.1f} s"
+    assert bool(torch.isnan(out[split]).all()), "rows without their tasks must come back as NaN"
+    assert torch.equal(out[~split], want[~split])
+    lib.sngnn_tuning_set(0, 7)
+    again = ops.aggregate_forward(g, h, k, 0.0)[0]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(again).all())
+    assert_close(again, want, rtol=1e-6, atol=1e-7)
