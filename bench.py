@@ -233,6 +233,11 @@ def main():
                          "the line's `locality_0.8` sub-result is that case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-epoch", action="store_true")
+    ap.add_argument("--preheat-ms", type=float, default=60.0,
+                    help="untimed run of the same step in front of the W warmup steps, until the device has been busy this "
+                         "long: after an idle spell the first ~15 ms of work run ~7 %% slower (tools/micro/ramp.py: 67.6 us "
+                         "per call in the first 200-call window, 63.2 in every later one) - the clocks ramp; the figure a "
+                         "training run sees is the steady one.  0 = off; the cold figure is reported beside it either way")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-finalize-ab", action="store_true",
                     help="skip the leg that times the same step with the split rows' finalize as a launch of its own "
@@ -352,6 +357,16 @@ def main():
     R = build_rank(args.locality, args.exchange)
     n, c, ei, x, h_local, graph, plan = R["n"], R["c"], R["ei"], R["x"], R["h_local"], R["graph"], R["plan"]
     e_prime = graph.num_edges
+    # device preheat (--preheat-ms): the same step, untimed, until the device has been busy that long
+    preheat_steps = 0
+    if args.preheat_ms > 0:
+        t_probe, _ = time_loop(R["step"], 1, 3, sync_all)
+        preheat_steps = int(min(20000, max(1, np.ceil(args.preheat_ms * 1e-3 / max(t_probe / 3, 1e-6)))))
+        if world > 1:       # every rank runs the same number of steps (collectives inside)
+            cnt = torch.tensor([preheat_steps], dtype=torch.int64, device=device)
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            preheat_steps = int(cnt.item())
+        time_loop(R["step"], 0, preheat_steps, sync_all)
     dt, e_all, halo_all, out = measure(R, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
 
@@ -439,6 +454,9 @@ def main():
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "preheat": {"ms": args.preheat_ms, "steps": preheat_steps,
+                        "what": "untimed steps in front of the warmup steps (the same step): a device coming out of idle runs "
+                                "its first ~15 ms ~7 % slower; cold_start = the same W + K measurement from an idle device"},
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ogbn-{args.workload}-sized synthetic graph, {layer}, "
@@ -638,6 +656,14 @@ def main():
             result["max_abs_err_vs_oracle"] = err
     if world == 1 and rank == 0 and plus_plus:
         result.update(products_training(ops, graph, R, args, e_prime, n, c))
+    if world == 1 and rank == 0 and args.preheat_ms > 0:
+        # the same W + K measurement from an idle device (the CPU baseline above left it idle for ~a second; a short
+        # sleep for the runs that skipped it)
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        dt_cold, _, _, _ = measure(R, args.steps, args.warmup)
+        result["cold_start"] = {"ms_per_step": dt_cold / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                                "what": "W warmup + K timed steps straight after one second of idle, no preheat"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
