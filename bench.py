@@ -570,6 +570,19 @@ def main():
                                   "effective_frac": vb / (vmain * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "effective_frac_step": vb / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": vtraffic}
+            # the same call scored on the fly from h (sngnn_tuning_set(2, 2): no normalisation pass, no table - ONE launch
+            # with the finalize inside; same selections bit for bit).  Not the library's default for ranking calls: every
+            # decision within 2 delta of a cut is re-scored exactly, so its time depends on the DATA (nearly parallel rows
+            # - a deep layer's input - re-score everything), where the table form costs the same whatever h holds
+            lib.sngnn_tuning_set(2, 2)
+            odt, _ = time_loop(lambda: ops.aggregate_forward(graph, h_local, args.top_k, args.thr)[0], 20,
+                               args.steps, torch.cuda.synchronize)
+            lib.sngnn_tuning_set(2, 0)
+            oms = odt / args.steps * 1e3
+            variants["C40_thr0.0_on_the_fly"] = {
+                "channels": c, "thr": args.thr, "ms_per_step": oms, "edges_per_s": e_prime / (oms * 1e-3),
+                "algorithmic_bytes": b_alg, "effective_frac_step": b_alg / (oms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "what": "scored on the fly from h: one launch; data-dependent (see bench.py), not the default for ranking calls"}
             result["variants"] = variants
         hg = h_local.clone().requires_grad_(True)
         gout = torch.randn_like(h_local)
