@@ -469,6 +469,17 @@ __device__ __forceinline__ void wave_topk_keys(unsigned long long key0, unsigned
     kept1 = kept[1];
 }
 
+// the same among CANDIDATES (keys that already won a selection: wave_topk_keys_n's PREFIX note) - the finalize's calls
+__device__ __forceinline__ void wave_topk_cands(unsigned long long key0, unsigned long long key1,
+                                                int k, int lowbits, bool &kept0, bool &kept1)
+{
+    const unsigned long long key[2] = {key0, key1};
+    bool kept[2];
+    wave_topk_keys_n<2, true>(key, k, lowbits, kept);
+    kept0 = kept[0];
+    kept1 = kept[1];
+}
+
 __device__ __forceinline__ float key_score(unsigned long long key)
 {
     const unsigned u = (unsigned)(key >> 32);
@@ -1381,8 +1392,18 @@ __device__ __forceinline__ void group_topk_keys_n(const unsigned long long (&key
 #pragma unroll
     for (int u = 0; u < NK; ++u) hi[u] = (unsigned)(key[u] >> 32);
     bool done = fits, exact = false;
-    unsigned Th = 0;
-    for (int b = 31; b >= 0; --b) {
+    // the score bits all of the group's keys share need no search (wave_topk_keys_n's PREFIX note); the wave starts at
+    // the highest bit in which any of its groups' keys differ
+    unsigned o = 0u, an = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < NK; ++u)
+        if (key[u] != 0ull) { o |= hi[u]; an &= hi[u]; }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) { o |= __shfl_xor(o, m, 64); an &= __shfl_xor(an, m, 64); }
+    const unsigned diff = o ^ an;                             // (a group without keys: all ones - and `fits`)
+    const int top = diff ? 31 - __clz(diff) : -1;
+    unsigned Th = top >= 0 ? (an & ~((2u << top) - 1u)) : an;
+    for (int b = wave_max_i(done ? -1 : top); b >= 0; --b) {
         if (__all(done)) break;
         const unsigned cand = Th | (1u << b);
         float c = 0.f;
@@ -1648,7 +1669,7 @@ __device__ __forceinline__ void fin_block_pair(const FwdArgs &a, int p0, int n_b
         if (had) { key[0] = s_key_w[lane]; src_run = s_src_w[lane]; }
         wave_lds_sync();                                   // the winners are in registers before their slots are reused
         bool kp[NK];
-        wave_topk_keys_n<NK>(key, a.k, a.lowbits, kp);
+        wave_topk_keys_n<NK, true>(key, a.k, a.lowbits, kp);
         int off = 0;
 #pragma unroll
         for (int u = 0; u < NK; ++u) {
@@ -1678,7 +1699,7 @@ __device__ __forceinline__ void fin_block_pair(const FwdArgs &a, int p0, int n_b
     __syncthreads();                                        // (read before the odd waves reuse their regions)
     if (half != 0 || !run) return;
     bool k0, k1;
-    wave_topk_keys(key0, 0ull, a.k, a.lowbits, k0, k1);
+    wave_topk_cands(key0, 0ull, a.k, a.lowbits, k0, k1);
     const unsigned long long m0 = __ballot(k0);
     const int nfin = __popcll(m0);
     if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }
@@ -2018,7 +2039,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
                 q[u] = g * 256 + u * 64 + lane;
                 key[u] = q[u] < n ? kA[q[u]] : 0ull;
             }
-            wave_topk_keys_n<4>(key, a.k, a.lowbits, kp);
+            wave_topk_keys_n<4, true>(key, a.k, a.lowbits, kp);
             int off = g * a.k;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -2037,7 +2058,7 @@ __device__ __forceinline__ void fin_cand_row(const FwdArgs &a, int p, int max_sl
         const unsigned long long key0 = lane < n ? kA[lane] : 0ull;
         const unsigned long long key1 = lane + 64 < n ? kA[lane + 64] : 0ull;
         bool k0, k1;
-        wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+        wave_topk_cands(key0, key1, a.k, a.lowbits, k0, k1);
         const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
         const int n0 = __popcll(m0);
         if (k0) { const int o = prefix_popc(m0); kB[o] = key0; sB[o] = sA[lane]; }
@@ -2204,7 +2225,7 @@ __device__ __forceinline__ void fin_wave_row(const FwdArgs &a, int p, unsigned l
     const int src0 = lane < n ? a.cand_src[slot(lane)] : 0;
     const int src1 = lane + 64 < n ? a.cand_src[slot(lane + 64)] : 0;
     bool k0, k1;
-    wave_topk_keys(key0, key1, a.k, a.lowbits, k0, k1);
+    wave_topk_cands(key0, key1, a.k, a.lowbits, k0, k1);
     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
     const int n0 = __popcll(m0), nsel = n0 + __popcll(m1);
     if (k0) { const int o = prefix_popc(m0); s_key_w[o] = key0; s_src_w[o] = src0; }

@@ -126,7 +126,13 @@ __device__ __forceinline__ unsigned long long sel_key(float s, unsigned idx)
 // the first bit in which the k-th and the (k+1)-th differ, ~15 of the 32 + lowbits steps of a full
 // search; the position bits are searched only when equal scores straddle the cut.  The kept set
 // is the full search's, bit for bit.
-template <int NK>
+// PREFIX: the search starts below the score bits that ALL keys share (their AND and OR agree there: a step on such a
+// bit keeps or drops every key at once, so the threshold's bits are the keys' own).  Twelve cross-lane steps to find
+// them - not worth it where the keys are a row's raw scores (both signs: they differ in the first bit), worth it
+// where they are candidates that already won a selection (the split rows' finalize: all close to the row's best;
+// on nearly parallel rows - a deep layer's input - they share 20 bits and more, and the full search was the launch's
+// critical path: 60 us against 50).
+template <int NK, bool PREFIX = false>
 __device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)[NK], int k, int lowbits,
                                                  bool (&kept)[NK])
 {
@@ -142,7 +148,19 @@ __device__ __forceinline__ void wave_topk_keys_n(const unsigned long long (&key)
 #pragma unroll
     for (int q = 0; q < NK; ++q) hi[q] = (unsigned)(key[q] >> 32);
     unsigned Th = 0;
-    for (int b = 31; b >= 0; --b) {
+    int b_first = 31;
+    if constexpr (PREFIX) {
+        unsigned o = 0u, an = 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+            if (key[q] != 0ull) { o |= hi[q]; an &= hi[q]; }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { o |= __shfl_xor(o, m, 64); an &= __shfl_xor(an, m, 64); }
+        const unsigned diff = o ^ an;                         // (cnt > k >= 0: there are keys)
+        b_first = diff ? 31 - __clz(diff) : -1;               // the highest bit in which two keys differ
+        Th = b_first >= 0 ? (an & ~((2u << b_first) - 1u)) : an;
+    }
+    for (int b = b_first; b >= 0; --b) {
         const unsigned cand = Th | (1u << b);
         int c = 0;
 #pragma unroll
