@@ -78,7 +78,7 @@ static int g_filt_min_deg = -1;
 int sngnn::g_fin_inline = 1;
 int sngnn::g_last_fin_blocks = 0;
 extern "C" int sngnn_last_forward_finalize_workgroups(void) { return sngnn::g_last_fin_blocks; }
-// a value no earlier call of this process has used (role_fin: the tasks' done words)
+// a value no earlier call of this process has used (the finalize role: the tasks' done words)
 unsigned long long sngnn::next_fin_nonce()
 {
     static std::atomic<unsigned long long> counter{0};

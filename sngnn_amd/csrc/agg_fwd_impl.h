@@ -82,7 +82,7 @@ struct FwdArgs {
     int use_cand;                   // split rows keep chunk-local candidates (k <= CAND_MAX_K and they fit LDS)
     int lowbits;                    // bits needed for a row-local edge index
     int n_split_gt_wave;        // split rows with more than 128 / k tasks (descending order: the first ones)
-    // The split rows' finalize INSIDE the main launch (round 5; role_fin below): workgroups [main_blocks, gridDim.x)
+    // The split rows' finalize INSIDE the main launch (round 5; fin_block_pair / fin_group_batch / fin_stream_row below): workgroups [main_blocks, gridDim.x)
     // take no work items - their waves finalize split rows, each as soon as the row's tasks have published their
     // candidates (fin_done[task] == fin_nonce).  main_blocks == gridDim.x: the finalize is the next launch.
     int main_blocks;

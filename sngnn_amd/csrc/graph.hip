@@ -592,7 +592,7 @@ int64_t sngnn_graph_workspace_bytes(const sngnn_graph_t *g, int C)
 {
     if (!g || C < 1) return -1;
     // forward: unit rows | norms | scores of split rows | one partial row per split task |
-    //          CAND_MAX_K candidate keys and source ids per task | one done word per task (role_fin)
+    //          CAND_MAX_K candidate keys and source ids per task | one done word per task (the finalize role: agg_fwd_impl.h)
     int64_t fwd = sngnn::fwd_table_bytes(g->Ntot, C) +
                   (g->split_edges + 3) / 4 * 4 * 4 + ((int64_t)g->n_tasks * C + 3) / 4 * 4 * 4 +
                   (int64_t)g->n_tasks * 32 * 8 + (int64_t)g->n_tasks * 32 * 4 + (int64_t)g->n_tasks * 8;
