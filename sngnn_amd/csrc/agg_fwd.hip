@@ -260,7 +260,7 @@ static int forward_normalized(const sngnn_graph_t *g, const RowCfg &cfg, const f
                            : nullptr;
     a.cand_src = a.cand_key ? (int32_t *)(a.cand_key + (size_t)g->n_tasks * CAND_MAX_K) : nullptr;
     a.fin_done = a.cand_src ? (unsigned long long *)(a.cand_src + (size_t)g->n_tasks * CAND_MAX_K) : nullptr;   // 8-byte aligned
-    a.fin_nonce = 0ull; a.main_blocks = 0;
+    a.fin_nonce = 0ull; a.main_blocks = 0; a.n_edges = (long long)g->Ep;
     a.k_magic = top_k >= 2 ? (unsigned)(0xFFFFFFFFu / (unsigned)top_k + 1u) : 0u;
     const int max_split = g->n_split ? g->rdeg[0] : 0;
     a.use_cand = fwd_use_candidates(a.k, C, max_split) ? 1 : 0;

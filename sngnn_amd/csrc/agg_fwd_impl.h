@@ -89,6 +89,7 @@ struct FwdArgs {
     unsigned long long *fin_done;   // [n_tasks] workspace; left zero by the wave that consumed them
     unsigned long long fin_nonce;   // this call's own value (never 0, never an earlier call's)
     unsigned k_magic;               // ceil(2^32 / k) for k >= 2: q / k = __umulhi(q, k_magic) for q < 2^32 / k (fin_slot)
+    long long n_edges;              // E' of the call's graph (host side: the launcher's estimate of the launch's time)
     int role_mask;              // measurement aid (sngnn_tuning_set): bit 0 tasks, 1 wave rows, 2 small rows
     // row filter (sngnn_agg_forward_rows): only the target rows i with row_flag[i] == row_want are
     // computed and written; nullptr = all rows.  (A rank's interior rows - all sources local - run
@@ -2400,8 +2401,8 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     //   * the role must end by 3/4 of the launch: the smallest number nb of workgroups that does;
     //   * each of them is six waves' worth of slots the work items lose: the launch grows by nb / (slots - nb);
     //   * against that, the launch it replaces: ~4.6 us + its rows over the whole chip, + the boundary (1.1).
-    // Arxiv size, C 40: 48 workgroups, +1.6 us against 7.1 saved (measured: 70.2 -> 64.5-65.3 us per forward).
-    // Products size: 128 workgroups - a wash (the launch 4.35 ms with the finalize inside against 4.12 + 0.26).
+    // Arxiv size, C 40: 48 workgroups, +1.6 us against 7.1 saved (measured: 68.1 -> 62.0 us per forward, hot device).
+    // Products size: 64 workgroups, 4.65 -> 4.55 ms per forward.
     // Small graphs, narrow rows (C 32: a 35 us launch): nothing ends the role in time - a launch.
     //   Calls that select nothing (top_k < 0: fin_stream_row, one wave per row): ~4 us per row + 2.5 per sixteen tasks
     // of the biggest row.
@@ -2412,15 +2413,23 @@ int launch_agg_fwd_impl(const FwdArgs &a0, int max_split_deg, hipEvent_t *ev, hi
     const int fin_big = std::min(a.n_split, a.n_split_gt_wave);
     const int fin_batches = ceil_div(a.n_split - fin_big, RPW);
     constexpr int SLOTS = 256 * FWD_WAVES_PER_SIMD;
+    // (eight rows per batch, C <= 32: sixteen keys per lane and eight partial sums - twice the time; measured at
+    // arxiv size, C 32, top_k 1: the role on 32 workgroups 51.8 against 50.7 us as a launch)
+    constexpr double t_batch = RPW >= 8 ? 25.0 : 12.5;
     int fin_blocks = 0;
     if (fin_ok && g_fin_inline > 1) fin_blocks = std::min(g_fin_inline, FIN_BLOCKS_MAX);      // (forced: tuning knob 9)
     else if (fin_ok) {
         for (int nb = 8; nb <= FIN_BLOCKS_MAX && fin_blocks == 0; nb += 8) {
             const int64_t main_waves = (int64_t)std::min<int64_t>(ceil_div(items, WAVES), SLOTS - nb) * WAVES;
-            const double t_main = 5.8 * (double)ceil_div(items, main_waves);
+            // the launch's time: work items at their latency-bound pace, or - big graphs, whose items are mostly
+            // 128-edge tasks - the forward's bytes at the rate this kernel reaches (0.8 x B_fwd at 4.8 TB/s; products
+            // size: 4.3 ms estimated, 4.1-4.2 measured; there 64 workgroups are the best count: 4.55 ms per forward
+            // against 4.65 with the finalize as a launch, 4.64 with 48 or 128)
+            const double b_fwd = (double)a.n_edges * (4.0 * a.C + 8.0) + (double)a.N * (8.0 * a.C + 8.0);
+            const double t_main = std::max(5.8 * (double)ceil_div(items, main_waves), 0.8 * b_fwd / 4.8e6);
             const double t_fin = a.k < 0
                 ? 6.0 + 4.0 * ceil_div(a.n_split, nb * WAVES) + 2.5 * ceil_div(ceil_div(max_split_deg, CHUNK), 16)
-                : 6.0 + 17.0 * ceil_div(ceil_div(fin_big, 2), nb) + 12.5 * ceil_div(fin_batches, nb * WAVES);
+                : 6.0 + 17.0 * ceil_div(ceil_div(fin_big, 2), nb) + t_batch * ceil_div(fin_batches, nb * WAVES);
             if (t_fin > 0.75 * t_main) continue;
             const double t_sep = a.k < 0 ? 4.6 + 1.1 + 4.0 * a.n_split / (256.0 * 24)
                                          : 4.6 + 1.1 + 12.0 * fin_big / (256.0 * 3) + 12.5 * fin_batches / (256.0 * 24);
